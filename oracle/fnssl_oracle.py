@@ -1,0 +1,280 @@
+"""CPU oracle for the FN-SSL DP-IPD forward path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-numpy restatement of the reference algorithm.  It exists so
+that the HIP path can be checked on a GPU box where ``/root/reference`` does not
+exist.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import it; nothing under ``fn-ssl_amd/`` does, and the
+product path has no CPU fallback.
+
+Parity is PINNED: ``tests/golden/make_golden.py`` imports the real reference
+(``/root/reference/FN-SSL/Lightning/{Model,Module,utils_}.py``) in the build
+container, runs it on seeded inputs with weights from
+``fnssl.weights`` and commits the outputs under ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function below against them.
+
+Each function cites the reference lines it restates (paths relative to
+``/root/reference/``).  All arithmetic is float32 unless noted.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+WIN_LEN = 512
+HOP = 256
+NFFT = 512
+NBIN = 257
+SEG_FRAMES = 12
+
+
+# --------------------------------------------------------------------------- #
+# front end
+# --------------------------------------------------------------------------- #
+def hann_periodic(n: int = WIN_LEN) -> np.ndarray:
+    """torch.hann_window(n) (periodic).  FN-SSL/Module.py:61."""
+    k = np.arange(n, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)).astype(F32)
+
+
+def n_frames(ns: int, win_len: int = WIN_LEN, hop: int = HOP) -> int:
+    """FN-SSL/Module.py:56: floor((ns - win_len) / hop + 1)."""
+    return int(np.floor((ns - win_len) / hop + 1))
+
+
+def stft(signal: np.ndarray) -> np.ndarray:
+    """STFT.forward, FN-SSL/Module.py:48-68.
+
+    signal [nb, ns, nch] float32 -> complex64 [nb, 257, nt, nch]; Hann-512
+    periodic window, hop 256, center=False, not normalised.  The DFT itself is
+    evaluated in float64 and rounded once, i.e. it is the exact value the
+    reference's float32 FFT approximates.
+    """
+    signal = np.asarray(signal, dtype=F32)
+    nb, ns, nch = signal.shape
+    nt = n_frames(ns)
+    win = hann_periodic()
+    idx = (np.arange(nt)[:, None] * HOP + np.arange(WIN_LEN)[None, :])  # [nt, 512]
+    out = np.zeros((nb, NBIN, nt, nch), dtype=np.complex64)
+    for c in range(nch):
+        frames = signal[:, :, c][:, idx] * win[None, None, :]            # f32 product
+        spec = np.fft.rfft(frames.astype(np.float64), n=NFFT, axis=-1)   # [nb, nt, 257]
+        out[:, :, :, c] = np.transpose(spec, (0, 2, 1)).astype(np.complex64)
+    return out
+
+
+def n_pairs(nch: int, ch_mode: str) -> int:
+    return nch * (nch - 1) // 2 if ch_mode == "MM" else nch - 1
+
+
+def pair_list(nch: int, ch_mode: str):
+    """Mic index pairs in the row order AddChToBatch produces.
+
+    FN-SSL/Module.py:387-393 ('M': (0, j)), :397-402 ('MM': i<j, i-major).
+    """
+    if ch_mode == "M":
+        return [(0, j) for j in range(1, nch)]
+    if ch_mode == "MM":
+        return [(i, j) for i in range(nch - 1) for j in range(i + 1, nch)]
+    raise ValueError("ch_mode must be 'M' or 'MM'")
+
+
+def add_ch_to_batch(data: np.ndarray, ch_mode: str) -> np.ndarray:
+    """AddChToBatch.forward, FN-SSL/Module.py:383-404.
+
+    [nb, nch, nf, nt] complex -> [nb*np, 2, nf, nt] complex64.
+    """
+    nb, nch = data.shape[:2]
+    pairs = pair_list(nch, ch_mode)
+    out = np.zeros((nb * len(pairs), 2) + data.shape[2:], dtype=np.complex64)
+    for b in range(nb):
+        for p, (i, j) in enumerate(pairs):
+            out[b * len(pairs) + p, 0] = data[b, i]
+            out[b * len(pairs) + p, 1] = data[b, j]
+    return out
+
+
+def remove_ch_from_batch(data: np.ndarray, nb: int) -> np.ndarray:
+    """RemoveChFromBatch.forward, FN-SSL/Module.py:412-421."""
+    nmic = data.shape[0] // nb
+    return np.ascontiguousarray(data.reshape((nb, nmic) + data.shape[1:])).astype(F32)
+
+
+def forgetting_coefs(nt: int, sample_length: int = 298):
+    """Per-frame (a_t, b_t) of the recursion mu_t = a_t*mu_{t-1} + b_t*mean_t.
+
+    FN-SSL/utils.py:26-44.  For t < sample_length the reference builds
+    ``alp`` as a float32 tensor (``torch.min(torch.tensor([...]))``) and forms
+    ``1 - alp`` in float32; afterwards it uses the Python double ``alpha`` whose
+    two coefficients are each rounded to float32 when they meet the tensor.
+    t = 0 gives alp = -1, i.e. mu_0 = 2*mean_0.
+    """
+    alpha = (sample_length - 1) / (sample_length + 1)
+    a = np.empty(nt, dtype=F32)
+    b = np.empty(nt, dtype=F32)
+    for t in range(nt):
+        if t < sample_length:
+            alp = F32(min((t - 1) / (t + 1), alpha))
+            a[t] = alp
+            b[t] = F32(1.0) - alp
+        else:
+            a[t] = F32(alpha)
+            b[t] = F32(1.0 - alpha)
+    return a, b
+
+
+def forgetting_norm(mag: np.ndarray, sample_length: int = 298) -> np.ndarray:
+    """forgetting_norm, FN-SSL/utils.py:9-55.  mag [B,C,F,T] -> mu [B,1,1,T]."""
+    assert mag.ndim == 4
+    B, C, Fq, T = mag.shape
+    m = mag.reshape(B, C * Fq, T).astype(F32)
+    a, b = forgetting_coefs(T, sample_length)
+    mu = np.zeros((B,), dtype=F32)
+    out = np.empty((B, T), dtype=F32)
+    for t in range(T):
+        mean_t = m[:, :, t].mean(axis=1, dtype=F32)
+        mu = (a[t] * mu).astype(F32) + (b[t] * mean_t).astype(F32)
+        out[:, t] = mu
+    return out.reshape(B, 1, 1, T)
+
+
+def data_preprocess(mic_sig: np.ndarray, ch_mode: str = "MM", eps: float = 1e-6,
+                    sample_length: int = 298) -> np.ndarray:
+    """Input half of data_preprocess, FN-SSL/Lightning/main.py:200-225
+    (= FN-SSL/Learner.py:392-414).
+
+    mic_sig [nb, ns, nch] -> x [nb*np, 4, 256, nt] float32 with channels
+    [Re i, Re j, Im i, Im j], normalised by (mu_t + eps), DC bin dropped
+    (fre_range_used = 1..256, main.py:130).
+    """
+    spec = stft(mic_sig)                               # [nb, 257, nt, nch]
+    spec = np.transpose(spec, (0, 3, 1, 2))            # [nb, nch, 257, nt]  main.py:207
+    reb = add_ch_to_batch(spec, ch_mode)               # [nb', 2, 257, nt]
+    mag = np.abs(reb).astype(F32)
+    mu = forgetting_norm(mag, sample_length)           # [nb', 1, 1, nt]
+    den = (mu + F32(eps)).astype(F32)
+    re = (reb.real.astype(F32) / den).astype(F32)
+    im = (reb.imag.astype(F32) / den).astype(F32)
+    x = np.concatenate([re, im], axis=1)               # [nb', 4, 257, nt]
+    return np.ascontiguousarray(x[:, :, 1:NBIN, :])
+
+
+# --------------------------------------------------------------------------- #
+# network
+# --------------------------------------------------------------------------- #
+def _sigmoid(x):
+    return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32)
+
+
+def lstm_dir(x: np.ndarray, w_ih, w_hh, b_ih, b_hh, reverse: bool = False,
+             h0=None, c0=None) -> np.ndarray:
+    """One direction of a 1-layer batch_first nn.LSTM with zero initial state.
+
+    PyTorch semantics (gate order i, f, g, o):
+        g_t = W_ih x_t + b_ih + W_hh h_{t-1} + b_hh
+        c_t = sigmoid(f) * c_{t-1} + sigmoid(i) * tanh(g)
+        h_t = sigmoid(o) * tanh(c_t)
+    x [N, T, I] -> h [N, T, H].  Used by FN-SSL/Model.py:25-29,38,46.
+    """
+    x = np.asarray(x, dtype=F32)
+    N, T, _ = x.shape
+    H = w_hh.shape[1]
+    xw = (x.reshape(N * T, -1) @ w_ih.T.astype(F32)).reshape(N, T, 4 * H)
+    xw = (xw + (b_ih + b_hh).astype(F32)).astype(F32)
+    whhT = np.ascontiguousarray(w_hh.T.astype(F32))
+    h = np.zeros((N, H), dtype=F32) if h0 is None else h0.astype(F32)
+    c = np.zeros((N, H), dtype=F32) if c0 is None else c0.astype(F32)
+    out = np.empty((N, T, H), dtype=F32)
+    steps = range(T - 1, -1, -1) if reverse else range(T)
+    for t in steps:
+        g = (xw[:, t] + h @ whhT).astype(F32)
+        i = _sigmoid(g[:, 0:H])
+        f = _sigmoid(g[:, H:2 * H])
+        gg = np.tanh(g[:, 2 * H:3 * H], dtype=F32)
+        o = _sigmoid(g[:, 3 * H:4 * H])
+        c = (f * c + i * gg).astype(F32)
+        h = (o * np.tanh(c, dtype=F32)).astype(F32)
+        out[:, t] = h
+    return out
+
+
+def lstm(x: np.ndarray, sd: dict, prefix: str, bidirectional: bool) -> np.ndarray:
+    """nn.LSTM forward (output only); bi-dir output is [fwd || bwd]."""
+    p = lambda n: sd[prefix + n]  # noqa: E731
+    fwd = lstm_dir(x, p("weight_ih_l0"), p("weight_hh_l0"), p("bias_ih_l0"), p("bias_hh_l0"))
+    if not bidirectional:
+        return fwd
+    bwd = lstm_dir(x, p("weight_ih_l0_reverse"), p("weight_hh_l0_reverse"),
+                   p("bias_ih_l0_reverse"), p("bias_hh_l0_reverse"), reverse=True)
+    return np.concatenate([fwd, bwd], axis=-1)
+
+
+def fnblock_forward(sd: dict, prefix: str, x: np.ndarray, fb_skip=None, *,
+                    is_first: bool, is_online: bool):
+    """FNblock.forward in eval mode, FN-SSL/Model.py:31-50.
+
+    x [nb, nt, nf, C] -> (x_out [nb, nt, nf, Hn], fb_skip [nb*nt, nf, 2*Hf],
+    nb_skip [nb*nf, nt, Hn]).  The incoming ``nb_skip`` argument is overwritten
+    by the reference (:34) so it is not a parameter here; dropout is identity.
+    """
+    nb, nt, nf, _ = x.shape
+    nb_skip = np.transpose(x, (0, 2, 1, 3)).reshape(nb * nf, nt, -1)          # :34
+    xf = x.reshape(nb * nt, nf, -1)                                           # :35
+    if not is_first:
+        xf = (xf + fb_skip).astype(F32)                                       # :36-37
+    f = lstm(xf, sd, prefix + "fullLstm.", True)                              # :38
+    fb_out = f                                                                # :39
+    v = np.transpose(f.reshape(nb, nt, nf, -1), (0, 2, 1, 3)).reshape(nb * nf, nt, -1)  # :41
+    if is_first:
+        v = np.concatenate([v, nb_skip], axis=-1)                             # :42-43
+    else:
+        v = (v + nb_skip).astype(F32)                                         # :44-45
+    n = lstm(v, sd, prefix + "narrLstm.", not is_online)                      # :46
+    nb_out = n                                                                # :47
+    xo = np.transpose(n.reshape(nb, nf, nt, -1), (0, 2, 1, 3))                # :49
+    return np.ascontiguousarray(xo), fb_out, nb_out
+
+
+def head_forward(sd: dict, x: np.ndarray) -> np.ndarray:
+    """Pool + emb2ipd + tanh + re|im packing, FN-SSL/Model.py:79-87.
+
+    x [nb, nt, nf, 256] -> [nb, nt//12, 2*nf].  AvgPool2d((12,1)) floors.
+    """
+    nb, nt, nf, C = x.shape
+    nt2 = nt // SEG_FRAMES
+    xs = np.transpose(x, (0, 2, 1, 3))[:, :, :nt2 * SEG_FRAMES]               # [nb, nf, nt2*12, C]
+    pooled = (xs.reshape(nb, nf, nt2, SEG_FRAMES, C).sum(axis=3, dtype=F32) / F32(SEG_FRAMES)).astype(F32)
+    ipd = np.tanh((pooled @ sd["emb2ipd.weight"].T.astype(F32) + sd["emb2ipd.bias"]).astype(F32),
+                  dtype=F32)                                                  # [nb, nf, nt2, 2]
+    ipd = np.transpose(ipd, (0, 2, 1, 3))                                     # [nb, nt2, nf, 2]
+    return np.ascontiguousarray(np.concatenate([ipd[..., 0], ipd[..., 1]], axis=2))
+
+
+def fnssl_forward(sd: dict, x: np.ndarray, is_online: bool = True, is_doa: bool = False) -> np.ndarray:
+    """FN_SSL.forward, FN-SSL/Model.py:72-90.  x [nb', 4, nf, nt] -> [nb', nt//12, 2nf]."""
+    x = np.transpose(np.asarray(x, dtype=F32), (0, 3, 2, 1))                  # :73
+    x, fb, _ = fnblock_forward(sd, "block_1.", x, is_first=True, is_online=is_online)
+    x, fb, _ = fnblock_forward(sd, "block_2.", x, fb, is_first=False, is_online=is_online)
+    x, fb, _ = fnblock_forward(sd, "block_3.", x, fb, is_first=False, is_online=is_online)
+    res = head_forward(sd, x)
+    if is_doa:
+        res = (res @ sd["ipd2doa.weight"].T.astype(F32) + sd["ipd2doa.bias"]).astype(F32)  # :88-89
+    return res
+
+
+def predict_step(sd: dict, batch: np.ndarray, ch_mode: str = "MM", is_online: bool = True) -> np.ndarray:
+    """MyModel.predict_step, FN-SSL/Lightning/main.py:184-189.  batch [nb, nch, ns]."""
+    x = data_preprocess(np.transpose(batch, (0, 2, 1)), ch_mode)
+    return fnssl_forward(sd, x, is_online=is_online)
+
+
+# --------------------------------------------------------------------------- #
+# work accounting (SURVEY.md §8d / BASELINE.md §3)
+# --------------------------------------------------------------------------- #
+def flops_per_tf_point(is_online: bool = True, input_size: int = 4) -> int:
+    """LSTM matmul flops (2 per MAC) for one (pair, bin, frame) TF point."""
+    def l(i, h, ndir):
+        return 2 * 4 * h * (i + h) * ndir
+    hn, nd = (256, 1) if is_online else (128, 2)
+    total = l(input_size, 128, 2) + l(256 + input_size, hn, nd)
+    total += 2 * (l(256, 128, 2) + l(256, hn, nd))
+    return total

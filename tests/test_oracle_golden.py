@@ -1,0 +1,124 @@
+"""Pin the numpy oracle (oracle/fnssl_oracle.py) to outputs of the real reference.
+
+The golden .npz files were produced by tests/golden/make_golden.py, which imports
+the reference's own Model.py / Module.py / utils_.py.  CPU only.
+"""
+import numpy as np
+
+from conftest import assert_close, load_golden, rs_randn
+from fnssl import weights as W
+from oracle import fnssl_oracle as O
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def test_g1_stft():
+    g = load_golden("g1_stft")
+    sig = rs_randn(g["seed"], g["shape"])
+    got = O.stft(sig)
+    want = g["out"]
+    assert got.dtype == np.complex64 and got.shape == want.shape == (2, 257, 24, 4)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale
+
+
+def test_g2_pairs():
+    g = load_golden("g2_pairs")
+    np.testing.assert_array_equal(O.add_ch_to_batch(g["inp"], "MM"), g["out_mm"])
+    np.testing.assert_array_equal(O.add_ch_to_batch(g["inp"], "M"), g["out_m"])
+    assert O.pair_list(4, "MM") == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    assert O.pair_list(4, "M") == [(0, 1), (0, 2), (0, 3)]
+
+
+def test_g3_forgetting_norm():
+    g = load_golden("g3_fnorm")
+    mag = np.abs(rs_randn(g["seed"], g["shape"])) + np.float32(0.1)
+    assert_close(O.forgetting_norm(mag, 8), g["out_sl8"], 2e-6, 0, "sl8")
+    assert_close(O.forgetting_norm(mag, 298), g["out_sl298"], 2e-6, 0, "sl298")
+    mag_l = np.abs(rs_randn(g["seed_long"], g["shape_long"])) + np.float32(0.1)
+    assert_close(O.forgetting_norm(mag_l, 298), g["out_long"], 2e-6, 0, "long (both branches)")
+    # first frame: alp = -1  ->  mu_0 = 2 * mean_0
+    a, b = O.forgetting_coefs(4, 298)
+    assert a[0] == -1 and b[0] == 2 and a[1] == 0 and b[1] == 1
+
+
+def test_g4_features():
+    g = load_golden("g4_features")
+    sig3 = rs_randn(g["seed3"], g["shape3"])
+    assert_close(O.data_preprocess(sig3, "MM"), g["x3"], 2e-5, 2e-5, "x3")
+    sig4 = rs_randn(g["seed4"], g["shape4"], float(g["scale4"]))
+    x4 = O.data_preprocess(sig4, "MM")
+    assert x4.shape == (12, 4, 256, 24)
+    assert_close(x4[:, :, ::16, :], g["x4_sub"], 2e-5, 2e-5, "x4 MM")
+    assert_close(O.data_preprocess(sig4, "M")[:, :, ::16, :], g["x4m_sub"], 2e-5, 2e-5, "x4 M")
+
+
+def test_g5_lstm():
+    g = load_golden("g5_lstm")
+    ci = 0
+    while "case%d_cfg" % ci in g:
+        I, H, bi, wseed, xseed, N, T = [int(v) for v in g["case%d_cfg" % ci]]
+        sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(I, H, bool(bi))], seed=wseed)
+        x = rs_randn(xseed, (N, T, I))
+        got = O.lstm(x, sd, "L.", bool(bi))
+        assert_close(got, g["case%d_out" % ci], what="lstm case %d" % ci, **TOL)
+        ci += 1
+    assert ci == 7
+
+
+def test_g6_fnblock():
+    g = load_golden("g6_fnblock")
+    for oi, online in enumerate([True, False]):
+        t = "on" if online else "off"
+        s1, sx, s2 = [int(v) for v in g[t + "_seeds"]]
+        sd1 = {"b1." + k: v for k, v in W.make_fnblock_state(s1, 4, 32, online, True).items()}
+        sd2 = {"b2." + k: v for k, v in W.make_fnblock_state(s2, 32, 32, online, False).items()}
+        x = rs_randn(sx, (2, 6, 8, 4))
+        y1, fb1, nb1 = O.fnblock_forward(sd1, "b1.", x, is_first=True, is_online=online)
+        y2, fb2, nb2 = O.fnblock_forward(sd2, "b2.", y1, fb1, is_first=False, is_online=online)
+        for name, got in [("y1", y1), ("fb1", fb1), ("nb1", nb1), ("y2", y2), ("fb2", fb2), ("nb2", nb2)]:
+            assert_close(got, g[t + "_" + name], what=t + " " + name, **TOL)
+
+
+def test_g7_fnssl_small_and_g11_floor():
+    g = load_golden("g7_fnssl")
+    for online in (True, False):
+        t = "on" if online else "off"
+        sw, sa, sb, sc = [int(v) for v in g[t + "_seeds"]]
+        sd = W.make_fnssl_state(sw, is_online=online)
+        assert W.n_params(sd) == (2511362 if online else 2118146)
+        assert_close(O.fnssl_forward(sd, rs_randn(sa, (2, 4, 16, 24)), online), g[t + "_a"], what=t + " a", **TOL)
+        assert_close(O.fnssl_forward(sd, rs_randn(sc, (3, 4, 16, 29)), online), g[t + "_c"], what=t + " c", **TOL)
+        assert g[t + "_c"].shape == (3, 2, 32)
+
+
+def test_g7_fnssl_256bins_and_g8_doa():
+    g = load_golden("g7_fnssl")
+    for online in (True, False):
+        t = "on" if online else "off"
+        sw, sa, sb, sc = [int(v) for v in g[t + "_seeds"]]
+        sd = W.make_fnssl_state(sw, is_online=online)
+        assert_close(O.fnssl_forward(sd, rs_randn(sb, (1, 4, 256, 36)), online), g[t + "_b"], what=t + " b", **TOL)
+    sw, sx = [int(v) for v in g["doa_seeds"]]
+    sd = W.make_fnssl_state(sw, is_online=True, is_doa=True)
+    got = O.fnssl_forward(sd, rs_randn(sx, (1, 4, 256, 12)), True, True)
+    assert got.shape == (1, 1, 180)
+    assert_close(got, g["doa_out"], what="doa", **TOL)
+
+
+def test_g9_config1_end_to_end():
+    g = load_golden("g9_config1")
+    sw, sx = [int(v) for v in g["seeds"]]
+    sd = W.make_fnssl_state(sw, is_online=True)
+    batch = rs_randn(sx, g["shape"], float(g["scale"]))
+    x = O.data_preprocess(np.transpose(batch, (0, 2, 1)), "MM")
+    assert x.shape == (1, 4, 256, 249)
+    assert_close(x[:, :, ::32, ::8], g["x_sub"], 2e-5, 2e-5, "features")
+    out = O.fnssl_forward(sd, x, True)
+    assert out.shape == (1, 20, 512)
+    assert_close(out, g["out"], what="config1 out", rtol=1e-4, atol=1e-5)
+
+
+def test_flop_accounting_matches_baseline_md():
+    assert O.flops_per_tf_point(True) == 4997120
+    assert O.flops_per_tf_point(False) == 4210688

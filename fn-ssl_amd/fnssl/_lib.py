@@ -1,0 +1,121 @@
+"""ctypes binding of csrc/libfnssl_hip.so (declarations: include/fnssl.h).
+
+The library must share the HIP runtime instance PyTorch uses (streams and
+device pointers are passed across), so ``torch`` is imported first: its bundled
+``libamdhip64.so`` has SONAME ``libamdhip64.so.7`` and the dynamic loader then
+resolves the library's dependency to that already-loaded object.  ``load()``
+verifies that exactly one HIP runtime is mapped.
+
+There is no fallback: if the shared object is missing this raises, and every
+op in ``fnssl.ops`` refuses non-ROCm tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before the library, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
+
+ABI_VERSION = 1
+CH_MODE = {"M": 0, "MM": 1}
+
+# every symbol include/fnssl.h declares
+SYMBOLS = [
+    "fnssl_abi_version", "fnssl_last_error", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
+    "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
+    "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
+    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
+]
+
+
+class View(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("so", C.c_longlong), ("si", C.c_longlong), ("st", C.c_longlong)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [
+        ("src0", View), ("src1", View), ("src2", View),
+        ("c0", C.c_int), ("c2", C.c_int),
+        ("out", C.c_void_p),
+        ("out_so", C.c_longlong), ("out_si", C.c_longlong), ("out_st", C.c_longlong),
+        ("hidden", C.c_int), ("ndir", C.c_int), ("nseq", C.c_int), ("q_inner", C.c_int), ("nsteps", C.c_int),
+        ("wpack", C.c_void_p * 2),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("variant", C.c_int),
+    ]
+
+
+class Net(C.Structure):
+    _fields_ = [
+        ("wpack", ((C.c_void_p * 2) * 2) * 3),
+        ("emb_w", C.c_void_p), ("emb_b", C.c_void_p),
+        ("doa_wt", C.c_void_p), ("doa_b", C.c_void_p),
+        ("input_size", C.c_int), ("is_online", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def _hip_runtimes_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        return []
+
+
+def load():
+    """Load (once) and return the ctypes library handle."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "fnssl: %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C fn-ssl_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise RuntimeError("fnssl: %s lacks symbols %s" % (LIB_PATH, missing))
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise RuntimeError("fnssl: two HIP runtimes are mapped (%s); streams cannot be shared" % rts)
+
+    vp, i, ll, sz, f = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_float
+    lib.fnssl_abi_version.restype = i
+    lib.fnssl_last_error.restype = C.c_char_p
+    lib.fnssl_num_frames.argtypes = [i]
+    lib.fnssl_num_pairs.argtypes = [i, i]
+    lib.fnssl_stft.argtypes = [vp, i, i, i, vp, vp, vp]
+    lib.fnssl_forgetting_coefs.argtypes = [i, i, vp, vp]
+    lib.fnssl_pair_features.argtypes = [vp, vp, vp, vp, i, i, i, i, f, vp, vp, i, vp]
+    lib.fnssl_nchw_to_seq.argtypes = [vp, i, i, i, i, vp, vp]
+    lib.fnssl_lstm_packed_floats.argtypes = [i, i, i]
+    lib.fnssl_lstm_packed_floats.restype = sz
+    lib.fnssl_lstm_pack.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.fnssl_lstm_workspace_bytes.argtypes = [i, i, i]
+    lib.fnssl_lstm_workspace_bytes.restype = sz
+    lib.fnssl_lstm_forward.argtypes = [C.POINTER(LstmDesc), vp]
+    lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
+    lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
+    lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.fnssl_forward_workspace_bytes.restype = sz
+    lib.fnssl_forward.argtypes = [C.POINTER(Net), vp, i, i, i, vp, vp, sz, i, vp]
+    lib.fnssl_timing_enable.argtypes = [i]
+    lib.fnssl_timing_collect.argtypes = [i, vp, vp, vp, vp]
+    if lib.fnssl_abi_version() != ABI_VERSION:
+        raise RuntimeError("fnssl: ABI version mismatch (library %d, binding %d)"
+                           % (lib.fnssl_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    """Raise RuntimeError (like ATen does for shape errors) on a non-zero status."""
+    if rc != 0:
+        msg = load().fnssl_last_error().decode("utf-8", "replace")
+        raise RuntimeError("fnssl %s failed (%d): %s" % (what, rc, msg))

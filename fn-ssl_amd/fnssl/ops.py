@@ -1,0 +1,322 @@
+"""Torch-tensor front of the C-ABI library: PyTorch supplies device memory and
+the current HIP stream, every numeric op is a HIP kernel in libfnssl_hip.so.
+
+No function here computes on the CPU or with ATen kernels; non-ROCm tensors are
+rejected (``RuntimeError``), mirroring how the reference surfaces shape errors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CH_MODE, LstmDesc, Net, View, check
+
+SEG_FRAMES = 12
+NBIN = 257
+NF = 256
+
+
+def _need_dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError("fnssl: expected a ROCm device tensor (this path has no CPU implementation), got %s"
+                               % (t.device if isinstance(t, torch.Tensor) else type(t)))
+        if t.dtype != torch.float32:
+            raise RuntimeError("fnssl: expected float32, got %s" % t.dtype)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# --------------------------------------------------------------------------- #
+# front end
+# --------------------------------------------------------------------------- #
+def num_frames(ns: int) -> int:
+    return _lib.load().fnssl_num_frames(int(ns))
+
+
+def num_pairs(nch: int, ch_mode: str) -> int:
+    return _lib.load().fnssl_num_pairs(int(nch), CH_MODE[ch_mode])
+
+
+def stft(sig: torch.Tensor):
+    """sig [nb, ns, nch] -> (spec [nb, nch, nt, 257, 2], magsum [nb, nch, nt]).  Module.py:48-68."""
+    _need_dev(sig)
+    if sig.ndim != 3:
+        raise RuntimeError("fnssl.stft: expected [nb, ns, nch], got %s" % (tuple(sig.shape),))
+    sig = sig.contiguous()
+    nb, ns, nch = sig.shape
+    nt = num_frames(ns)
+    spec = torch.empty((nb, nch, max(nt, 0), NBIN, 2), dtype=torch.float32, device=sig.device)
+    magsum = torch.empty((nb, nch, max(nt, 0)), dtype=torch.float32, device=sig.device)
+    check(_lib.load().fnssl_stft(_ptr(sig), nb, ns, nch, _ptr(spec), _ptr(magsum), _stream()), "stft")
+    return spec, magsum
+
+
+_coef_cache = {}
+
+
+def forgetting_coefs_host(nt: int, sample_length: int = 298):
+    a = np.empty(nt, dtype=np.float32)
+    b = np.empty(nt, dtype=np.float32)
+    check(_lib.load().fnssl_forgetting_coefs(nt, sample_length, a.ctypes.data_as(C.c_void_p),
+                                             b.ctypes.data_as(C.c_void_p)), "forgetting_coefs")
+    return a, b
+
+
+def forgetting_coefs(nt: int, sample_length: int, device):
+    key = (nt, sample_length, str(device))
+    if key not in _coef_cache:
+        a, b = forgetting_coefs_host(nt, sample_length)
+        _coef_cache[key] = (torch.from_numpy(a).to(device), torch.from_numpy(b).to(device))
+    return _coef_cache[key]
+
+
+def pair_features(spec, magsum, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int = 298,
+                  layout: int = 0):
+    """main.py:207-225.  Returns (x, mu); x is [nb', nt, 256, 4] (layout 0) or [nb', 4, 256, nt] (layout 1)."""
+    _need_dev(spec, magsum)
+    nb, nch, nt = magsum.shape
+    np_ = num_pairs(nch, ch_mode)
+    if np_ <= 0:
+        raise RuntimeError("fnssl.pair_features: need at least 2 channels, got %d" % nch)
+    ca, cb = forgetting_coefs(nt, sample_length, spec.device)
+    mu = torch.empty((nb * np_, nt), dtype=torch.float32, device=spec.device)
+    shape = (nb * np_, nt, NF, 4) if layout == 0 else (nb * np_, 4, NF, nt)
+    x = torch.empty(shape, dtype=torch.float32, device=spec.device)
+    check(_lib.load().fnssl_pair_features(_ptr(spec), _ptr(magsum), _ptr(ca), _ptr(cb), nb, nch, nt,
+                                          CH_MODE[ch_mode], eps, _ptr(mu), _ptr(x), layout, _stream()),
+          "pair_features")
+    return x, mu
+
+
+def preprocess(sig, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int = 298, layout: int = 0):
+    """Waveforms [nb, ns, nch] -> network features (data_preprocess, main.py:200-225)."""
+    spec, magsum = stft(sig)
+    x, _ = pair_features(spec, magsum, ch_mode, eps, sample_length, layout)
+    return x
+
+
+def nchw_to_seq(x):
+    """[n, c, nf, nt] -> [n, nt, nf, c] (Model.py:73) as a contiguous tensor."""
+    _need_dev(x)
+    x = x.contiguous()
+    n, c, nf, nt = x.shape
+    y = torch.empty((n, nt, nf, c), dtype=torch.float32, device=x.device)
+    check(_lib.load().fnssl_nchw_to_seq(_ptr(x), n, c, nf, nt, _ptr(y), _stream()), "nchw_to_seq")
+    return y
+
+
+# --------------------------------------------------------------------------- #
+# LSTM
+# --------------------------------------------------------------------------- #
+def pack_lstm_host(w_ih, w_hh, b_ih, b_hh, c0: int, c2: int) -> np.ndarray:
+    """Pack one direction's nn.LSTM parameters (numpy / CPU tensors) into the kernel's weight stream."""
+    arrs = [np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+            for a in (w_ih, w_hh, b_ih, b_hh)]
+    hidden = arrs[1].shape[1]
+    if arrs[0].shape != (4 * hidden, c0 + c2) or arrs[1].shape != (4 * hidden, hidden):
+        raise RuntimeError("fnssl.pack_lstm: weight shapes %s / %s do not match c0+c2=%d, H=%d"
+                           % (arrs[0].shape, arrs[1].shape, c0 + c2, hidden))
+    lib = _lib.load()
+    n = lib.fnssl_lstm_packed_floats(c0, c2, hidden)
+    if n == 0:
+        raise RuntimeError("fnssl.pack_lstm: unsupported sizes c0=%d c2=%d H=%d (multiples of 4 / 16)" % (c0, c2, hidden))
+    out = np.empty(n, dtype=np.float32)
+    check(lib.fnssl_lstm_pack(*[a.ctypes.data_as(C.c_void_p) for a in arrs], c0, c2, hidden,
+                              out.ctypes.data_as(C.c_void_p)), "lstm_pack")
+    return out
+
+
+def pack_lstm(w_ih, w_hh, b_ih, b_hh, c0: int, c2: int, device) -> torch.Tensor:
+    return torch.from_numpy(pack_lstm_host(w_ih, w_hh, b_ih, b_hh, c0, c2)).to(device)
+
+
+def _view(t, mode):
+    """4-D logical [nb, nt, nf, C] tensor -> (View, q_inner) for 'full' (seq=(b,t), step=f) or
+    'narrow' (seq=(b,f), step=t)."""
+    sb, st, sf, sc = t.stride()
+    if sc != 1:
+        raise RuntimeError("fnssl.lstm: channel dimension must be contiguous")
+    if mode == "full":
+        return View(t.data_ptr(), sb, st, sf)
+    return View(t.data_ptr(), sb, sf, st)
+
+
+def _conform(t):
+    """Channel-contiguous, 16-byte aligned, strides multiples of 4 floats — else copy (plumbing only)."""
+    if t is None:
+        return None
+    ok = t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % 4 == 0 for s in t.stride()[:-1])
+    return t if ok else t.contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device, tag: str):
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _ws_cache.clear()
+
+
+def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0):
+    """One (bi)LSTM layer over strided views.
+
+    mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
+    x0 (+ x1) is the summed input, x2 the concatenated one (either may be None); all are logical
+    [nb, nt, nf, C] tensors with arbitrary strides.  ``packed`` is a list of 1 or 2 device weight
+    streams; ``out`` a logical [nb, nt, nf, ndir*hidden] tensor (any strides) that is written in place.
+    """
+    _need_dev(x0, x1, x2, out, *packed)
+    if mode not in ("full", "narrow"):
+        raise RuntimeError("fnssl.lstm_layer: mode must be 'full' or 'narrow'")
+    ref = x0 if x0 is not None else x2
+    if ref is None:
+        raise RuntimeError("fnssl.lstm_layer: no input")
+    x0, x1, x2 = _conform(x0), _conform(x1), _conform(x2)
+    nb, nt, nf = ref.shape[:3]
+    ndir = len(packed)
+    if tuple(out.shape) != (nb, nt, nf, ndir * hidden):
+        raise RuntimeError("fnssl.lstm_layer: out shape %s != %s" % (tuple(out.shape), (nb, nt, nf, ndir * hidden)))
+    d = LstmDesc()
+    if x0 is not None:
+        d.src0 = _view(x0, mode)
+        d.c0 = x0.shape[3]
+    if x1 is not None:
+        if x0 is None or x1.shape != x0.shape:
+            raise RuntimeError("fnssl.lstm_layer: x1 must match x0")
+        d.src1 = _view(x1, mode)
+    if x2 is not None:
+        d.src2 = _view(x2, mode)
+        d.c2 = x2.shape[3]
+    ov = _view(out, mode)
+    d.out, d.out_so, d.out_si, d.out_st = ov.p, ov.so, ov.si, ov.st
+    d.hidden, d.ndir = hidden, ndir
+    d.nseq = nb * (nt if mode == "full" else nf)
+    d.q_inner = nt if mode == "full" else nf
+    d.nsteps = nf if mode == "full" else nt
+    d.wpack[0] = packed[0].data_ptr()
+    d.wpack[1] = packed[1].data_ptr() if ndir == 2 else 0
+    lib = _lib.load()
+    wsb = lib.fnssl_lstm_workspace_bytes(d.nseq, hidden, ndir)
+    ws = _workspace(wsb, out.device, "lstm")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    d.variant = variant
+    check(lib.fnssl_lstm_forward(C.byref(d), _stream()), "lstm_forward")
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# head / whole network
+# --------------------------------------------------------------------------- #
+def head(x, w, b):
+    """x [nb, nf, nt, 256] -> [nb, nt//12, 2*nf]  (Model.py:79-87)."""
+    _need_dev(x, w, b)
+    x = x.contiguous()
+    nb, nf, nt, c = x.shape
+    if c != 256:
+        raise RuntimeError("fnssl.head: emb2ipd is Linear(256, 2); got %d channels" % c)
+    out = torch.empty((nb, nt // SEG_FRAMES, 2 * nf), dtype=torch.float32, device=x.device)
+    check(_lib.load().fnssl_head(_ptr(x), nb, nf, nt, _ptr(w.contiguous()), _ptr(b.contiguous()), _ptr(out),
+                                 _stream()), "head")
+    return out
+
+
+def linear(x, wt, b):
+    """y = x @ wt + b with wt = weight^T [k, n_out]."""
+    _need_dev(x, wt, b)
+    x = x.contiguous()
+    k = x.shape[-1]
+    m = x.numel() // k
+    n_out = wt.shape[1]
+    y = torch.empty(tuple(x.shape[:-1]) + (n_out,), dtype=torch.float32, device=x.device)
+    check(_lib.load().fnssl_linear(_ptr(x), m, k, _ptr(wt.contiguous()), _ptr(b), n_out, _ptr(y), _stream()),
+          "linear")
+    return y
+
+
+class DeviceNet:
+    """Device-resident packed parameters of an FN_SSL network (the ``fnssl_net`` struct)."""
+
+    def __init__(self, state: dict, device, is_online: bool = True, is_doa: bool = False, input_size: int = 4,
+                 prefix: str = ""):
+        self.device = torch.device(device)
+        self.is_online, self.is_doa, self.input_size = bool(is_online), bool(is_doa), int(input_size)
+        self._keep = []
+        net = Net()
+        g = lambda k: state[prefix + k]  # noqa: E731
+        for blk in range(3):
+            bp = "block_%d." % (blk + 1)
+            fin = input_size if blk == 0 else 256
+            specs = [("fullLstm.", fin, 0, True),
+                     ("narrLstm.", 256, input_size if blk == 0 else 0, not is_online)]
+            for li, (lp, c0, c2, bidir) in enumerate(specs):
+                for di, sfx in enumerate(["", "_reverse"] if bidir else [""]):
+                    t = pack_lstm(g(bp + lp + "weight_ih_l0" + sfx), g(bp + lp + "weight_hh_l0" + sfx),
+                                  g(bp + lp + "bias_ih_l0" + sfx), g(bp + lp + "bias_hh_l0" + sfx), c0, c2,
+                                  self.device)
+                    self._keep.append(t)
+                    net.wpack[blk][li][di] = t.data_ptr()
+        self.emb_w = self._dev(g("emb2ipd.weight"))
+        self.emb_b = self._dev(g("emb2ipd.bias"))
+        net.emb_w, net.emb_b = self.emb_w.data_ptr(), self.emb_b.data_ptr()
+        if is_doa:
+            self.doa_wt = self._dev(g("ipd2doa.weight")).t().contiguous()
+            self.doa_b = self._dev(g("ipd2doa.bias"))
+            net.doa_wt, net.doa_b = self.doa_wt.data_ptr(), self.doa_b.data_ptr()
+        net.input_size, net.is_online = self.input_size, int(self.is_online)
+        self.net = net
+
+    def _dev(self, a):
+        t = a.detach() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a, dtype=np.float32))
+        return t.to(self.device, torch.float32).contiguous()
+
+    def forward(self, x0: torch.Tensor, chunk_pairs: int = 0) -> torch.Tensor:
+        """x0 [nb', nt, nf, input_size] -> [nb', nt//12, 2*nf] (or [.., 180] with the DOA layer)."""
+        _need_dev(x0)
+        x0 = x0.contiguous()
+        nb, nt, nf, cin = x0.shape
+        if cin != self.input_size:
+            raise RuntimeError("fnssl.forward: expected %d input channels, got %d" % (self.input_size, cin))
+        lib = _lib.load()
+        wsb = lib.fnssl_forward_workspace_bytes(nb, nf, nt, int(self.is_online), chunk_pairs)
+        ws = _workspace(wsb, x0.device, "forward")
+        last = 180 if self.is_doa else 2 * nf
+        out = torch.empty((nb, nt // SEG_FRAMES, last), dtype=torch.float32, device=x0.device)
+        check(lib.fnssl_forward(C.byref(self.net), _ptr(x0), nb, nf, nt, _ptr(out), _ptr(ws), ws.numel(),
+                                chunk_pairs, _stream()), "forward")
+        return out
+
+
+# --------------------------------------------------------------------------- #
+# measurement hooks
+# --------------------------------------------------------------------------- #
+def timing_enable(on: bool):
+    check(_lib.load().fnssl_timing_enable(1 if on else 0), "timing_enable")
+
+
+def timing_collect(cap: int = 64):
+    names = ((C.c_char * 64) * cap)()
+    ms = (C.c_double * cap)()
+    cnt = (C.c_longlong * cap)()
+    fl = (C.c_double * cap)()
+    n = _lib.load().fnssl_timing_collect(cap, names, ms, cnt, fl)
+    return {names[i].value.decode(): {"ms": ms[i], "count": cnt[i], "flops": fl[i]} for i in range(n)}

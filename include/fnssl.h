@@ -1,0 +1,202 @@
+/*
+ * fnssl.h — C ABI of libfnssl_hip.so: the MI355X (gfx950) implementation of the
+ * FN-SSL DP-IPD forward path.
+ *
+ * The reference (Audio-WestlakeU/FN-SSL) is pure PyTorch and has no FFI of its
+ * own; every entry point below replaces the PyTorch call sequence named in its
+ * comment (paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only: raw DEVICE pointers (fp32 unless stated), ints, a
+ *     `void* stream` that is a hipStream_t (0 = the null stream);
+ *   - the caller owns every buffer; the library never allocates or frees
+ *     device memory and never synchronises the device: all work is enqueued on
+ *     `stream` and the call returns immediately;
+ *   - return 0 on success, <0 on error (FNSSL_E_*); `fnssl_last_error()` gives
+ *     a thread-local message.  Nothing throws across the ABI;
+ *   - thread-safe for concurrent calls on distinct streams; one process per GPU.
+ *   - "pack" functions are host-only (no GPU needed) and write HOST memory.
+ */
+#ifndef FNSSL_H_
+#define FNSSL_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FNSSL_ABI_VERSION 1
+
+#define FNSSL_OK 0
+#define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
+#define FNSSL_E_HIP (-2)         /* a HIP runtime call or kernel launch failed */
+#define FNSSL_E_WORKSPACE (-3)   /* workspace too small                       */
+
+#define FNSSL_CH_MODE_M 0        /* pairs (0, j)            Module.py:387-393 */
+#define FNSSL_CH_MODE_MM 1       /* pairs (i, j), i < j     Module.py:397-402 */
+
+#define FNSSL_WIN_LEN 512
+#define FNSSL_HOP 256
+#define FNSSL_NBIN 257           /* rFFT bins incl. DC                        */
+#define FNSSL_NF 256             /* bins kept by the network (1..256)         */
+#define FNSSL_SEG_FRAMES 12      /* AvgPool2d((12,1))       Model.py:68       */
+
+int fnssl_abi_version(void);
+const char* fnssl_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Front end                                                                 */
+/* ------------------------------------------------------------------------- */
+
+/* Number of STFT frames: floor((ns - 512) / 256 + 1).  Module.py:56. */
+int fnssl_num_frames(int ns);
+
+/* Number of mic pairs per utterance for a channel mode.  Module.py:388,396. */
+int fnssl_num_pairs(int nch, int ch_mode);
+
+/*
+ * Replaces STFT.forward (FN-SSL/Module.py:48-68): per channel Hann-512
+ * (periodic) windowed 512-point rFFT, hop 256, center=False, unnormalised.
+ *   sig     [nb, ns, nch]                      (reference layout, main.py:185)
+ *   spec    [nb, nch, nt, 257] interleaved (re, im) pairs  (k fastest)
+ *   magsum  [nb, nch, nt]  = sum_k |X[k]| over all 257 bins (feeds the
+ *           recursive normalisation; may be NULL)
+ */
+int fnssl_stft(const float* sig, int nb, int ns, int nch,
+               float* spec, float* magsum, void* stream);
+
+/*
+ * Host helper: per-frame coefficients (a_t, b_t) of
+ *   mu_t = a_t * mu_{t-1} + b_t * mean_t
+ * with the reference's float32 rounding (FN-SSL/utils.py:26-44).
+ * a, b: HOST arrays of nt floats.
+ */
+int fnssl_forgetting_coefs(int nt, int sample_length, float* a, float* b);
+
+/*
+ * Replaces AddChToBatch + torch.abs + forgetting_norm + real/imag normalise +
+ * cat + DC-drop (FN-SSL/Lightning/main.py:207-225, Module.py:383-404,
+ * utils.py:9-55).
+ *   spec, magsum  outputs of fnssl_stft
+ *   coef_a/b      DEVICE arrays [nt] from fnssl_forgetting_coefs
+ *   mu            [nb*np, nt] (written; the recursive mean, = forgetting_norm's output)
+ *   x             features, channels [Re i, Re j, Im i, Im j], bins 1..256:
+ *                 layout 0: [nb*np, nt, 256, 4]  (what the LSTM kernels read)
+ *                 layout 1: [nb*np, 4, 256, nt]  (the tensor data_preprocess returns)
+ */
+int fnssl_pair_features(const float* spec, const float* magsum,
+                        const float* coef_a, const float* coef_b,
+                        int nb, int nch, int nt, int ch_mode, float eps,
+                        float* mu, float* x, int layout, void* stream);
+
+/* x [n, c, nf, nt] -> y [n, nt, nf, c]  (the permute at FN-SSL/Model.py:73). */
+int fnssl_nchw_to_seq(const float* x, int n, int c, int nf, int nt, float* y, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* LSTM recurrence (replaces nn.LSTM, FN-SSL/Model.py:25-29,38,46)            */
+/* ------------------------------------------------------------------------- */
+
+/* A strided view of sequences: element (q, step, ch) lives at
+ *   p[(q / q_inner) * so + (q % q_inner) * si + step * st + ch]   (floats)
+ * with q_inner taken from the descriptor.  Channels are contiguous. */
+typedef struct {
+  const float* p;
+  long long so, si, st;
+} fnssl_view;
+
+typedef struct {
+  /* input = [ (src0 + src1)[0:c0] | src2[0:c2] ] along channels
+   * (the residual adds / the concat of FNblock.forward, Model.py:36-37,42-45).
+   * src1.p and src2.p may be NULL (c2 = 0).  c0 % 4 == 0, c2 % 4 == 0.       */
+  fnssl_view src0, src1, src2;
+  int c0, c2;
+  /* output h, written at channel offset dir * hidden (bi-dir: [fwd || bwd]) */
+  float* out;
+  long long out_so, out_si, out_st;
+  int hidden;          /* H: 16, 32, 64, 128 or 256                           */
+  int ndir;            /* 1 = forward only, 2 = bidirectional                 */
+  int nseq;            /* number of sequences                                 */
+  int q_inner;         /* see fnssl_view                                      */
+  int nsteps;          /* sequence length                                     */
+  const float* wpack[2];   /* DEVICE packed weights per direction (fnssl_lstm_pack) */
+  float* workspace;    /* DEVICE, >= fnssl_lstm_workspace_bytes()             */
+  size_t workspace_bytes;
+  int variant;         /* 0 = default; see DESIGN.md (kernel variants)        */
+} fnssl_lstm_desc;
+
+/* Floats in one direction's packed weight stream for (input_size = c0 + c2, hidden). */
+size_t fnssl_lstm_packed_floats(int c0, int c2, int hidden);
+
+/*
+ * Host-only: pack one direction's PyTorch LSTM parameters
+ *   w_ih [4H, c0+c2], w_hh [4H, H], b_ih [4H], b_hh [4H]   (gate order i,f,g,o)
+ * into the MFMA-operand stream the kernel consumes (layout: DESIGN.md §3).
+ * packed: HOST buffer of fnssl_lstm_packed_floats() floats.
+ */
+int fnssl_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                    int c0, int c2, int hidden, float* packed);
+
+size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir);
+
+int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Head                                                                      */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Replaces pooling + emb2ipd + tanh + re|im packing (FN-SSL/Model.py:79-87).
+ *   x    narrow-band output in [nb, nf, nt, 256] layout
+ *   w    [2, 256], b [2]      (emb2ipd)
+ *   out  [nb, nt/12, 2*nf]
+ */
+int fnssl_head(const float* x, int nb, int nf, int nt, const float* w, const float* b,
+               float* out, void* stream);
+
+/* y[m, n_out] = x[m, k] @ wt[k, n_out] + b   (ipd2doa, Model.py:88-89; wt = weight^T). */
+int fnssl_linear(const float* x, int m, int k, const float* wt, const float* b, int n_out,
+                 float* y, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Whole network (replaces FN_SSL.forward, FN-SSL/Model.py:72-90)             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  /* packed LSTM streams, DEVICE: [block 0..2][0 = full-band, 1 = narrow-band][direction] */
+  const float* wpack[3][2][2];
+  const float* emb_w;     /* [2, 256] */
+  const float* emb_b;     /* [2]      */
+  const float* doa_wt;    /* [512, 180] = ipd2doa.weight^T, or NULL */
+  const float* doa_b;     /* [180] or NULL                          */
+  int input_size;         /* 4                                      */
+  int is_online;          /* narrow-band: 1 = uni-dir H=256, 0 = bi-dir H=128 */
+} fnssl_net;
+
+size_t fnssl_forward_workspace_bytes(int nb, int nf, int nt, int is_online, int chunk_pairs);
+
+/*
+ *   x0   [nb, nt, nf, input_size]   (layout 0 of fnssl_pair_features)
+ *   out  [nb, nt/12, 2*nf]  (or [nb, nt/12, 180] with the DOA layer)
+ *   chunk_pairs: pairs processed per pass (0 = all at once)
+ */
+int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
+                  float* out, void* workspace, size_t workspace_bytes, int chunk_pairs,
+                  void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Measurement hooks (bench.py: per-kernel HIP-event timing on the launch stream) */
+/* ------------------------------------------------------------------------- */
+
+/* enable = 1: every kernel launch is bracketed by hipEvents on its stream. */
+int fnssl_timing_enable(int enable);
+/* Drain recorded events (synchronises them) and reset.  Returns the number of
+ * distinct kernel names; names/ms/count/flops are HOST arrays of capacity cap. */
+int fnssl_timing_collect(int cap, char (*names)[64], double* total_ms, long long* count,
+                         double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNSSL_H_ */

@@ -1,0 +1,89 @@
+"""CPU tests of the host side: the C-ABI library loads and exports everything
+include/fnssl.h declares; host-only entry points (packing, coefficient table,
+shape helpers, argument validation) behave; and the packed LSTM weight stream,
+executed by a lane-level emulation of the kernel's MFMA data flow, reproduces the
+oracle.  No compute call touches a GPU here.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close, rs_randn
+from fnssl import _lib, ops
+from fnssl import weights as W
+from oracle import fnssl_oracle as O
+from wave_emulator import run_wave
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "fnssl.h")).read()
+    declared = sorted(set(re.findall(r"\b(fnssl_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), "library does not export %s" % name
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.fnssl_abi_version() == 1
+
+
+def test_shape_helpers_match_reference_formulas():
+    for ns in (512, 767, 768, 64000, 77056, 6400):
+        assert ops.num_frames(ns) == O.n_frames(ns)
+    assert ops.num_frames(100) == 0
+    assert ops.num_pairs(4, "MM") == 6 and ops.num_pairs(4, "M") == 3 and ops.num_pairs(2, "MM") == 1
+    assert ops.num_pairs(1, "MM") == 0
+
+
+def test_forgetting_coefs_bitwise():
+    for nt, sl in ((24, 8), (300, 298), (310, 298), (5, 298)):
+        a, b = ops.forgetting_coefs_host(nt, sl)
+        ra, rb = O.forgetting_coefs(nt, sl)
+        np.testing.assert_array_equal(a, ra)
+        np.testing.assert_array_equal(b, rb)
+
+
+def test_pack_rejects_bad_sizes():
+    lib = _lib.load()
+    assert lib.fnssl_lstm_packed_floats(4, 0, 128) == 8 * (1 + 1 + 8) * 4 * 256
+    assert lib.fnssl_lstm_packed_floats(256, 4, 256) == 16 * (1 + 16 + 1 + 16) * 4 * 256
+    assert lib.fnssl_lstm_packed_floats(3, 0, 128) == 0      # not a multiple of 4
+    assert lib.fnssl_lstm_packed_floats(4, 0, 24) == 0       # hidden not a multiple of 16
+    with pytest.raises(RuntimeError):
+        ops.pack_lstm_host(np.zeros((64, 6), np.float32), np.zeros((64, 16), np.float32),
+                           np.zeros(64, np.float32), np.zeros(64, np.float32), 6, 0)
+
+
+def test_lstm_forward_validates_before_touching_the_device():
+    lib = _lib.load()
+    d = _lib.LstmDesc()
+    d.hidden = 100
+    assert lib.fnssl_lstm_forward(C.byref(d), None) == -1
+    assert b"hidden size" in lib.fnssl_last_error()
+    with pytest.raises(RuntimeError, match="hidden size"):
+        _lib.check(-1, "lstm_forward")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    with pytest.raises(RuntimeError, match="ROCm device tensor"):
+        ops.stft(torch.zeros(1, 1024, 2))
+    with pytest.raises(RuntimeError, match="ROCm device tensor"):
+        ops.head(torch.zeros(1, 4, 12, 256), torch.zeros(2, 256), torch.zeros(2))
+
+
+@pytest.mark.parametrize("c0,c2,H,reverse", [(4, 0, 16, False), (32, 4, 32, False), (16, 0, 16, True),
+                                             (36, 0, 16, False), (8, 20, 16, True)])
+def test_packed_stream_through_mfma_emulation_matches_oracle(c0, c2, H, reverse):
+    I = c0 + c2
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(I, H, False)], seed=4000 + I + H)
+    T = 5
+    x = rs_randn(4100 + I, (16, T, I))
+    packed = ops.pack_lstm_host(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"],
+                                sd["L.bias_hh_l0"], c0, c2)
+    got = run_wave(packed, x[:, :, :c0] if c0 else None, x[:, :, c0:] if c2 else None, H, T, reverse)
+    want = O.lstm_dir(x, sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"],
+                      reverse=reverse)
+    assert_close(got, want, 1e-5, 1e-6, "emulated wave vs oracle")

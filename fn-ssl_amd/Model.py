@@ -1,0 +1,168 @@
+"""Drop-in for the reference's ``Model.py`` (FN-SSL/Model.py, = FN-SSL/Lightning/Model.py):
+same classes, constructor arguments, ``forward`` signatures, return shapes and
+``state_dict`` key names — so reference checkpoints load unchanged — but every
+``forward`` runs hand-written HIP kernels on an MI355X through libfnssl_hip.so.
+
+    FNblock(input_size, hidden_size=256, dropout=0.2, is_online=False, is_first=False)
+        .forward(x, nb_skip=None, fb_skip=None) -> (x, fb_skip, nb_skip)      Model.py:9,31,50
+    FN_SSL(input_size=4, hidden_size=256, is_online=True, is_doa=False)
+        .forward(x[nb', 4, nf, nt]) -> [nb', nt//12, 2*nf]                    Model.py:56,72,90
+    FN_lightning().arch = FN_SSL()                                            Model.py:92-99
+
+The ``nn.LSTM`` / ``nn.Linear`` sub-modules are kept purely as parameter
+containers (names, shapes, ``load_state_dict``, ``.cuda()``); they are never
+called.  The path is forward-only: modules must be in ``eval()`` mode (the
+reference's dropout is the identity there) and inputs must be ROCm tensors —
+there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from fnssl import ops
+
+
+def _lstm_streams(lstm: nn.LSTM, c0: int, c2: int, device):
+    """Pack an nn.LSTM's parameters into per-direction device weight streams."""
+    out = []
+    for sfx in [""] + (["_reverse"] if lstm.bidirectional else []):
+        out.append(ops.pack_lstm(getattr(lstm, "weight_ih_l0" + sfx), getattr(lstm, "weight_hh_l0" + sfx),
+                                 getattr(lstm, "bias_ih_l0" + sfx), getattr(lstm, "bias_hh_l0" + sfx),
+                                 c0, c2, device))
+    return out
+
+
+def _param_key(module: nn.Module):
+    """Changes whenever a parameter is replaced, moved or modified in place."""
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
+
+
+def _require_eval(m: nn.Module):
+    if m.training:
+        raise RuntimeError("%s: this is the forward-only MI355X path — call .eval() first "
+                           "(training / dropout are not part of it)" % type(m).__name__)
+
+
+class FNblock(nn.Module):
+    """Full-band BiLSTM over frequency followed by a narrow-band LSTM over time."""
+
+    def __init__(self, input_size, hidden_size=256, dropout=0.2, is_online=False, is_first=False):
+        super(FNblock, self).__init__()
+        self.input_size = input_size
+        self.full_hidden_size = hidden_size // 2
+        self.is_first = is_first
+        self.is_online = is_online
+        if self.is_online:
+            self.narr_hidden_size = hidden_size
+        else:
+            self.narr_hidden_size = hidden_size // 2
+        self.dropout = dropout
+
+        self.dropout_full = nn.Dropout(p=self.dropout)
+        self.dropout_narr = nn.Dropout(p=self.dropout)
+        self.fullLstm = nn.LSTM(input_size=self.input_size, hidden_size=self.full_hidden_size, batch_first=True,
+                                bidirectional=True)
+        if self.is_first:
+            self.narrLstm = nn.LSTM(input_size=2 * self.full_hidden_size + self.input_size,
+                                    hidden_size=self.narr_hidden_size, batch_first=True,
+                                    bidirectional=not self.is_online)
+        else:
+            self.narrLstm = nn.LSTM(input_size=2 * self.full_hidden_size, hidden_size=self.narr_hidden_size,
+                                    batch_first=True, bidirectional=not self.is_online)
+        self._packed = None
+        self._packed_key = None
+
+    def _streams(self, device):
+        key = (_param_key(self), str(device))
+        if self._packed is None or self._packed_key != key:
+            fh2 = 2 * self.full_hidden_size
+            full = _lstm_streams(self.fullLstm, self.input_size, 0, device)
+            narr = _lstm_streams(self.narrLstm, fh2, self.input_size if self.is_first else 0, device)
+            self._packed, self._packed_key = (full, narr), key
+        return self._packed
+
+    def forward(self, x, nb_skip=None, fb_skip=None):
+        """x [nb, nt, nf, C] -> (x [nb, nt, nf, Hn], fb_skip [nb*nt, nf, 2Hf], nb_skip [nb*nf, nt, Hn]).
+
+        As in the reference the incoming ``nb_skip`` is ignored: it is recomputed
+        from ``x`` (Model.py:34).  The returned ``x`` is a permuted view of the
+        narrow-band output, exactly like the reference's (Model.py:49).
+        """
+        _require_eval(self)
+        nb, nt, nf, nc = x.shape
+        full_w, narr_w = self._streams(x.device)
+        fh2 = 2 * self.full_hidden_size
+        nh = self.narr_hidden_size * (1 if self.is_online else 2)
+        if not self.is_first:
+            if fb_skip is None:
+                raise RuntimeError("FNblock: fb_skip is required unless is_first")
+            fb_prev = fb_skip.reshape(nb, nt, nf, -1)
+        f = torch.empty((nb, nt, nf, fh2), dtype=torch.float32, device=x.device)
+        ops.lstm_layer("full", x, None if self.is_first else fb_prev, None, full_w, self.full_hidden_size, f)
+        n = torch.empty((nb, nf, nt, nh), dtype=torch.float32, device=x.device)
+        n_logical = n.permute(0, 2, 1, 3)                      # [nb, nt, nf, Hn] view
+        if self.is_first:
+            ops.lstm_layer("narrow", f, None, x, narr_w, self.narr_hidden_size, n_logical)     # cat  :42-43
+        else:
+            ops.lstm_layer("narrow", f, x, None, narr_w, self.narr_hidden_size, n_logical)     # add  :44-45
+        return n_logical, f.view(nb * nt, nf, fh2), n.view(nb * nf, nt, nh)
+
+
+class FN_SSL(nn.Module):
+    """Three FN blocks + AvgPool(12) . Linear(256, 2) . tanh head -> DP-IPD [cos | sin]."""
+
+    def __init__(self, input_size=4, hidden_size=256, is_online=True, is_doa=False):
+        super(FN_SSL, self).__init__()
+        self.is_online = is_online
+        self.is_doa = is_doa
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.block_1 = FNblock(input_size=self.input_size, is_online=self.is_online, is_first=True)
+        self.block_2 = FNblock(input_size=self.hidden_size, is_online=self.is_online, is_first=False)
+        self.block_3 = FNblock(input_size=self.hidden_size, is_online=self.is_online, is_first=False)
+        self.emb2ipd = nn.Linear(256, 2)
+        self.pooling = nn.AvgPool2d(kernel_size=(12, 1))
+        self.tanh = nn.Tanh()
+        if self.is_doa:
+            self.ipd2doa = nn.Linear(512, 180)
+        self._net = None
+        self._net_key = None
+        self.chunk_pairs = 0      # pairs per pass inside the library (0 = whole batch)
+
+    def device_net(self, device) -> "ops.DeviceNet":
+        key = (_param_key(self), str(device))
+        if self._net is None or self._net_key != key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            self._net = ops.DeviceNet(sd, device, self.is_online, self.is_doa, self.input_size)
+            self._net_key = key
+        return self._net
+
+    def forward_seq(self, x0):
+        """x0 [nb', nt, nf, input_size] (the layout the front-end kernels emit) -> DP-IPD."""
+        _require_eval(self)
+        return self.device_net(x0.device).forward(x0, self.chunk_pairs)
+
+    def forward(self, x):
+        """x [nb', input_size, nf, nt] -> [nb', nt//12, 2*nf]  (or [.., 180] with is_doa)."""
+        _require_eval(self)
+        if x.ndim != 4 or x.shape[1] != self.input_size:
+            raise RuntimeError("FN_SSL: expected [nb, %d, nf, nt], got %s" % (self.input_size, tuple(x.shape)))
+        return self.forward_seq(ops.nchw_to_seq(x))               # permute(0,3,2,1), Model.py:73
+
+
+class FN_lightning(nn.Module):
+    """Wrapper whose ``arch.`` prefix matches Lightning checkpoints (Model.py:92-99)."""
+
+    def __init__(self):
+        super(FN_lightning, self).__init__()
+        self.arch = FN_SSL()
+
+    def forward(self, x):
+        return self.arch(x)
+
+
+if __name__ == "__main__":
+    inp = torch.randn((2, 4, 256, 298)).cuda()
+    net = FN_SSL().cuda().eval()
+    out = net(inp)
+    print(out.shape)
+    print('# parameters:', sum(param.numel() for param in net.parameters()))

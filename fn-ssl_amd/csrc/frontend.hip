@@ -30,9 +30,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
 
-// sig [nb, ns, nch] -> spec [nb, nch, nt, 257] (re, im), magsum [nb, nch, nt]
+// sig[b*sb + n*sn + c*sc] -> spec [nb, nch, nt, 257] (re, im), magsum [nb, nch, nt]
 __global__ void __launch_bounds__(kFramesPerBlock * 64)
-stft_kernel(const float* __restrict__ sig, int nb, int ns, int nch, int nt,
+stft_kernel(const float* __restrict__ sig, int nb, int nch, int nt, long long sb, long long sn, long long sc,
             float2* __restrict__ spec, float* __restrict__ magsum) {
   __shared__ float2 tw[256];                       // exp(-2*pi*i*k/512), k = 0..255
   __shared__ float2 buf[kFramesPerBlock][256];
@@ -50,15 +50,15 @@ stft_kernel(const float* __restrict__ sig, int nb, int ns, int nch, int nt,
   const int t = (int)(fr % nt);
   const int c = (int)((fr / nt) % nch);
   const int b = (int)(fr / ((long long)nt * nch));
-  const float* src = sig + ((long long)b * ns + (long long)t * kHop) * nch + c;
+  const float* src = sig + b * sb + (long long)t * kHop * sn + c * sc;
   float2* z = buf[wave];
 
   // z[m] = w[2m] x[2m] + i w[2m+1] x[2m+1], stored bit-reversed for the DIT FFT
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = lane + 64 * r;
-    const float x0 = src[(long long)(2 * m) * nch];
-    const float x1 = src[(long long)(2 * m + 1) * nch];
+    const float x0 = src[(long long)(2 * m) * sn];
+    const float x1 = src[(long long)(2 * m + 1) * sn];
     const float w0 = 0.5f - 0.5f * cospif((float)(2 * m) / 256.0f);       // periodic Hann-512
     const float w1 = 0.5f - 0.5f * cospif((float)(2 * m + 1) / 256.0f);
     z[bitrev8(m)] = make_float2(w0 * x0, w1 * x1);
@@ -222,7 +222,8 @@ int fnssl_forgetting_coefs(int nt, int sample_length, float* a, float* b) {
   return FNSSL_OK;
 }
 
-int fnssl_stft(const float* sig, int nb, int ns, int nch, float* spec, float* magsum, void* stream) {
+int fnssl_stft(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc, float* spec,
+               float* magsum, void* stream) {
   FNSSL_REQUIRE(sig && spec, "stft: null pointer");
   FNSSL_REQUIRE(nb > 0 && nch > 0, "stft: empty batch (nb %d, nch %d)", nb, nch);
   const int nt = fnssl_num_frames(ns);
@@ -232,7 +233,7 @@ int fnssl_stft(const float* sig, int nb, int ns, int nch, float* spec, float* ma
   FNSSL_REQUIRE(nblk < (1ll << 31), "stft: too many frames");
   fnssl::TimedLaunch tl("stft", fnssl::as_stream(stream));
   hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nblk), dim3(kFramesPerBlock * 64), 0,
-                     fnssl::as_stream(stream), sig, nb, ns, nch, nt, reinterpret_cast<float2*>(spec), magsum);
+                     fnssl::as_stream(stream), sig, nb, nch, nt, sb, sn, sc, reinterpret_cast<float2*>(spec), magsum);
   FNSSL_CHECK_LAUNCH("stft_kernel");
   return FNSSL_OK;
 }

@@ -16,6 +16,7 @@
 // WMODE=1 stages it through a 2-slot LDS ring filled by plain (compiler-counted)
 // global loads one chunk ahead; WMODE=0 reads it straight from L1/L2.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -415,6 +416,13 @@ int launch_t(const LstmParams& p, bool has1, int nwg, hipStream_t st) {
 //   1: NW=4  direct      2: NW=4  ring M=1     3: NW=8 ring M=2
 //   4: NW=12 ring M=2    5: NW=16 ring M=1     6: NW=8 direct     7: NW=12 ring M=1
 int default_variant(int H) {
+  // tuning override for experiments: FNSSL_LSTM_VARIANT_H256=3 etc.
+  char name[40];
+  snprintf(name, sizeof(name), "FNSSL_LSTM_VARIANT_H%d", H);
+  if (const char* e = getenv(name)) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 7) return v;
+  }
   if (H == 256) return 4;
   if (H == 128) return 5;
   return 2;

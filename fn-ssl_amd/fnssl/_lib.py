@@ -90,7 +90,7 @@ def load():
     lib.fnssl_last_error.restype = C.c_char_p
     lib.fnssl_num_frames.argtypes = [i]
     lib.fnssl_num_pairs.argtypes = [i, i]
-    lib.fnssl_stft.argtypes = [vp, i, i, i, vp, vp, vp]
+    lib.fnssl_stft.argtypes = [vp, i, i, i, ll, ll, ll, vp, vp, vp]
     lib.fnssl_forgetting_coefs.argtypes = [i, i, vp, vp]
     lib.fnssl_pair_features.argtypes = [vp, vp, vp, vp, i, i, i, i, f, vp, vp, i, vp]
     lib.fnssl_nchw_to_seq.argtypes = [vp, i, i, i, i, vp, vp]

@@ -54,12 +54,12 @@ def stft(sig: torch.Tensor):
     _need_dev(sig)
     if sig.ndim != 3:
         raise RuntimeError("fnssl.stft: expected [nb, ns, nch], got %s" % (tuple(sig.shape),))
-    sig = sig.contiguous()
-    nb, ns, nch = sig.shape
+    nb, ns, nch = sig.shape          # any strides: a permuted [nb, nch, ns] batch is read in place
     nt = num_frames(ns)
     spec = torch.empty((nb, nch, max(nt, 0), NBIN, 2), dtype=torch.float32, device=sig.device)
     magsum = torch.empty((nb, nch, max(nt, 0)), dtype=torch.float32, device=sig.device)
-    check(_lib.load().fnssl_stft(_ptr(sig), nb, ns, nch, _ptr(spec), _ptr(magsum), _stream()), "stft")
+    sb, sn, sc = sig.stride()
+    check(_lib.load().fnssl_stft(_ptr(sig), nb, ns, nch, sb, sn, sc, _ptr(spec), _ptr(magsum), _stream()), "stft")
     return spec, magsum
 
 

@@ -59,12 +59,15 @@ int fnssl_num_pairs(int nch, int ch_mode);
 /*
  * Replaces STFT.forward (FN-SSL/Module.py:48-68): per channel Hann-512
  * (periodic) windowed 512-point rFFT, hop 256, center=False, unnormalised.
- *   sig     [nb, ns, nch]                      (reference layout, main.py:185)
+ *   sig     logical [nb, ns, nch] (reference layout, main.py:185) addressed as
+ *           sig[b*sb + n*sn + c*sc] (floats) — so the [nb, nch, ns] batch the
+ *           dataloader yields is read in place (sb = nch*ns, sn = 1, sc = ns)
  *   spec    [nb, nch, nt, 257] interleaved (re, im) pairs  (k fastest)
  *   magsum  [nb, nch, nt]  = sum_k |X[k]| over all 257 bins (feeds the
  *           recursive normalisation; may be NULL)
  */
 int fnssl_stft(const float* sig, int nb, int ns, int nch,
+               long long sb, long long sn, long long sc,
                float* spec, float* magsum, void* stream);
 
 /*

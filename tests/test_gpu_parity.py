@@ -1,0 +1,333 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel and the whole
+DP-IPD path against the numpy oracle on seeded inputs and against the committed
+golden vectors that were generated from the real reference.
+
+Tolerance (north_star): fp32, rtol 1e-4 (+ atol 1e-5 because the outputs are tanh
+of small numbers, SURVEY.md §7 "hard parts").  Integer/index work (pair order,
+shapes) is exact.  Nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden, rs_randn
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm device; none visible (the HIP path has no CPU fallback)")
+    from fnssl import _lib
+    _lib.load()                      # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def lstm_state(I, H, bidir, seed):
+    from fnssl import weights as W
+    return W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(I, H, bidir)], seed=seed)
+
+
+def packed_dirs(sd, c0, c2, bidir, dev):
+    from fnssl import ops
+    out = []
+    for sfx in [""] + (["_reverse"] if bidir else []):
+        out.append(ops.pack_lstm(sd["L.weight_ih_l0" + sfx], sd["L.weight_hh_l0" + sfx], sd["L.bias_ih_l0" + sfx],
+                                 sd["L.bias_hh_l0" + sfx], c0, c2, dev))
+    return out
+
+
+# --------------------------------------------------------------------------- front end
+def test_stft_matches_oracle_and_golden(dev):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    g = load_golden("g1_stft")
+    sig = rs_randn(g["seed"], g["shape"])
+    spec, magsum = ops.stft(to_dev(sig, dev))
+    got = torch.view_as_complex(spec).permute(0, 3, 2, 1).cpu().numpy()      # [nb, 257, nt, nch]
+    scale = np.abs(g["out"]).max()
+    assert got.shape == g["out"].shape
+    assert np.abs(got - g["out"]).max() <= 5e-6 * scale, "vs reference golden"
+    assert np.abs(got - O.stft(sig)).max() <= 5e-6 * scale, "vs oracle"
+    want_sum = np.abs(O.stft(sig)).sum(axis=1).transpose(0, 2, 1)             # [nb, nch, nt]
+    assert_close(magsum.cpu().numpy(), want_sum, 2e-6, 0, "magsum")
+
+
+def test_stft_reads_permuted_batch_in_place(dev):
+    from fnssl import ops
+    batch = to_dev(rs_randn(7, (3, 2, 512 + 5 * 256)), dev)                  # [nb, nch, ns] like the dataloader
+    a, _ = ops.stft(batch.permute(0, 2, 1))
+    b, _ = ops.stft(batch.permute(0, 2, 1).contiguous())
+    assert torch.equal(a, b)
+
+
+def test_stft_rejects_short_signal(dev):
+    from fnssl import ops
+    with pytest.raises(RuntimeError, match="shorter than one"):
+        ops.stft(torch.zeros(1, 100, 2, device=dev))
+
+
+@pytest.mark.parametrize("ch_mode", ["MM", "M"])
+def test_features_match_oracle(dev, ch_mode):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    sig = rs_randn(21, (2, 512 + 30 * 256, 4), 0.05)
+    want = O.data_preprocess(sig, ch_mode)                                   # [nb', 4, 256, nt]
+    x1 = ops.preprocess(to_dev(sig, dev), ch_mode, layout=1).cpu().numpy()
+    x0 = ops.preprocess(to_dev(sig, dev), ch_mode, layout=0).cpu().numpy()
+    assert_close(x1, want, 2e-5, 2e-5, "layout 1")
+    np.testing.assert_array_equal(x0, np.transpose(x1, (0, 3, 2, 1)))
+
+
+def test_features_golden_and_both_norm_branches(dev):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    g = load_golden("g4_features")
+    sig4 = rs_randn(g["seed4"], g["shape4"], float(g["scale4"]))
+    x = ops.preprocess(to_dev(sig4, dev), "MM", layout=1).cpu().numpy()
+    assert_close(x[:, :, ::16, :], g["x4_sub"], 2e-5, 2e-5, "golden x4 MM")
+    # nt > sample_length exercises the second branch of forgetting_norm (utils.py:39-44)
+    sig = rs_randn(22, (1, 512 + 19 * 256, 2))
+    spec, magsum = ops.stft(to_dev(sig, dev))
+    _, mu = ops.pair_features(spec, magsum, "MM", sample_length=8)
+    mag = np.abs(O.add_ch_to_batch(np.transpose(O.stft(sig), (0, 3, 1, 2)), "MM"))
+    assert_close(mu.cpu().numpy(), O.forgetting_norm(mag, 8)[:, 0, 0, :], 3e-6, 0, "mu, sample_length=8")
+
+
+def test_nchw_to_seq_is_the_reference_permute(dev):
+    from fnssl import ops
+    x = to_dev(rs_randn(31, (3, 4, 37, 45)), dev)
+    assert torch.equal(ops.nchw_to_seq(x), x.permute(0, 3, 2, 1).contiguous())
+
+
+def test_module_dropins(dev):
+    import Module as at_module
+    g = load_golden("g2_pairs")
+    d = to_dev(g["inp"], dev)
+    np.testing.assert_array_equal(at_module.AddChToBatch("MM")(d).cpu().numpy(), g["out_mm"])
+    np.testing.assert_array_equal(at_module.AddChToBatch("M")(d).cpu().numpy(), g["out_m"])
+    g1 = load_golden("g1_stft")
+    sig = rs_randn(g1["seed"], g1["shape"])
+    st = at_module.STFT(512, 0.5, 512)(to_dev(sig, dev))
+    assert st.dtype == torch.complex64 and tuple(st.shape) == g1["out"].shape
+    assert np.abs(st.cpu().numpy() - g1["out"]).max() <= 5e-6 * np.abs(g1["out"]).max()
+
+
+# --------------------------------------------------------------------------- LSTM kernel
+LSTM_CASES = [
+    # c0, c2, H, bidir, mode, nb, nt, nf
+    (4, 0, 16, True, "full", 2, 5, 7),
+    (32, 4, 32, False, "narrow", 2, 6, 9),
+    (4, 0, 128, True, "full", 1, 19, 6),
+    (256, 0, 128, True, "full", 2, 9, 5),
+    (256, 4, 256, False, "narrow", 1, 7, 21),
+    (256, 0, 256, False, "narrow", 2, 5, 17),
+    (256, 4, 128, True, "narrow", 1, 6, 18),
+    (48, 20, 64, False, "full", 1, 17, 4),
+]
+
+
+def run_layer(dev, c0, c2, H, bidir, mode, nb, nt, nf, variant=0, seed=0, with_skip=None):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    sd = lstm_state(c0 + c2, H, bidir, 1000 + seed)
+    x0 = rs_randn(1100 + seed, (nb, nt, nf, c0)) if c0 else None
+    x1 = rs_randn(1200 + seed, (nb, nt, nf, c0)) if (c0 and with_skip) else None
+    x2 = rs_randn(1300 + seed, (nb, nt, nf, c2)) if c2 else None
+    ndir = 2 if bidir else 1
+    out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+    ops.lstm_layer(mode, None if x0 is None else to_dev(x0, dev), None if x1 is None else to_dev(x1, dev),
+                   None if x2 is None else to_dev(x2, dev), packed_dirs(sd, c0, c2, bidir, dev), H, out, variant)
+    parts = []
+    if x0 is not None:
+        parts.append(x0 + x1 if x1 is not None else x0)
+    if x2 is not None:
+        parts.append(x2)
+    xin = np.concatenate(parts, axis=-1)
+    if mode == "full":
+        seqs = xin.reshape(nb * nt, nf, -1)
+        want = O.lstm(seqs, sd, "L.", bidir).reshape(nb, nt, nf, -1)
+    else:
+        seqs = np.transpose(xin, (0, 2, 1, 3)).reshape(nb * nf, nt, -1)
+        want = np.transpose(O.lstm(seqs, sd, "L.", bidir).reshape(nb, nf, nt, -1), (0, 2, 1, 3))
+    return out.cpu().numpy(), want
+
+
+@pytest.mark.parametrize("case", LSTM_CASES)
+def test_lstm_layer_matches_oracle(dev, case):
+    c0, c2, H, bidir, mode, nb, nt, nf = case
+    got, want = run_layer(dev, *case, seed=c0 + H)
+    assert not np.isnan(got).any(), "some outputs were never written"
+    assert_close(got, want, RTOL, ATOL, "lstm %s" % (case,))
+    got, want = run_layer(dev, *case, seed=c0 + H + 1, with_skip=True)
+    assert_close(got, want, RTOL, ATOL, "lstm + residual input %s" % (case,))
+
+
+@pytest.mark.parametrize("H,c0", [(256, 256), (128, 256), (128, 4)])
+def test_lstm_kernel_variants_are_bit_identical(dev, H, c0):
+    """All launch geometries (waves per workgroup, LDS ring or direct weight reads) run the same
+    k-ordered fp32 MFMA chain per sequence, so they must agree bit for bit."""
+    base, want = run_layer(dev, c0, 0, H, True if H == 128 else False, "narrow", 2, 6, 23, variant=1, seed=5,
+                           with_skip=c0 > 4)
+    assert_close(base, want, RTOL, ATOL, "variant 1")
+    for v in range(2, 8):
+        got, _ = run_layer(dev, c0, 0, H, True if H == 128 else False, "narrow", 2, 6, 23, variant=v, seed=5,
+                           with_skip=c0 > 4)
+        np.testing.assert_array_equal(got, base, err_msg="variant %d differs from variant 1" % v)
+
+
+def test_lstm_strided_views_and_ragged_tail(dev):
+    """Sequence count not a multiple of 16, outputs written into a permuted (narrow-layout) buffer."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    nb, nt, nf, H = 3, 7, 11, 32
+    sd = lstm_state(16, H, False, 77)
+    x = rs_randn(78, (nb, nt, nf, 16))
+    buf = torch.full((nb, nf, nt, H), float("nan"), device=dev)
+    ops.lstm_layer("narrow", to_dev(x, dev), None, None, packed_dirs(sd, 16, 0, False, dev), H,
+                   buf.permute(0, 2, 1, 3))
+    seqs = np.transpose(x, (0, 2, 1, 3)).reshape(nb * nf, nt, -1)
+    want = O.lstm(seqs, sd, "L.", False).reshape(nb, nf, nt, H)
+    assert_close(buf.cpu().numpy(), want, RTOL, ATOL, "narrow layout output")
+
+
+def test_lstm_rejects_bad_descriptors(dev):
+    from fnssl import ops
+    sd = lstm_state(16, 32, False, 5)
+    w = packed_dirs(sd, 16, 0, False, dev)
+    x = torch.zeros(1, 4, 4, 16, device=dev)
+    with pytest.raises(RuntimeError, match="out shape"):
+        ops.lstm_layer("full", x, None, None, w, 32, torch.zeros(1, 4, 4, 64, device=dev))
+    with pytest.raises(RuntimeError, match="ROCm device tensor"):
+        ops.lstm_layer("full", x.cpu(), None, None, w, 32, torch.zeros(1, 4, 4, 32, device=dev))
+
+
+# --------------------------------------------------------------------------- blocks / network
+@pytest.mark.parametrize("online", [True, False])
+def test_fnblock_golden(dev, online):
+    import Model as at_model
+    from fnssl import weights as W
+    g = load_golden("g6_fnblock")
+    t = "on" if online else "off"
+    s1, sx, s2 = [int(v) for v in g[t + "_seeds"]]
+    b1 = at_model.FNblock(4, hidden_size=32, is_online=online, is_first=True)
+    b1.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_fnblock_state(s1, 4, 32, online, True).items()})
+    b2 = at_model.FNblock(32, hidden_size=32, is_online=online, is_first=False)
+    b2.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_fnblock_state(s2, 32, 32, online, False).items()})
+    b1, b2 = b1.to(dev).eval(), b2.to(dev).eval()
+    x = to_dev(rs_randn(sx, (2, 6, 8, 4)), dev)
+    y1, fb1, nb1 = b1(x)
+    y2, fb2, nb2 = b2(y1, fb_skip=fb1, nb_skip=nb1)
+    for name, got in [("y1", y1), ("fb1", fb1), ("nb1", nb1), ("y2", y2), ("fb2", fb2), ("nb2", nb2)]:
+        assert tuple(got.shape) == g[t + "_" + name].shape, name
+        assert_close(got.contiguous().cpu().numpy(), g[t + "_" + name], RTOL, ATOL, t + " " + name)
+
+
+def build_net(dev, seed, online=True, doa=False):
+    import Model as at_model
+    from fnssl import weights as W
+    sd = W.make_fnssl_state(seed, is_online=online, is_doa=doa)
+    net = at_model.FN_SSL(is_online=online, is_doa=doa)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev).eval(), sd
+
+
+@pytest.mark.parametrize("online", [True, False])
+def test_fnssl_golden(dev, online):
+    g = load_golden("g7_fnssl")
+    t = "on" if online else "off"
+    sw, sa, sb, sc = [int(v) for v in g[t + "_seeds"]]
+    net, _ = build_net(dev, sw, online)
+    for key, seed, shape in (("_a", sa, (2, 4, 16, 24)), ("_b", sb, (1, 4, 256, 36)), ("_c", sc, (3, 4, 16, 29))):
+        got = net(to_dev(rs_randn(seed, shape), dev)).cpu().numpy()
+        assert_close(got, g[t + key], RTOL, ATOL, "FN_SSL %s%s" % (t, key))
+
+
+def test_fnssl_doa_golden(dev):
+    g = load_golden("g7_fnssl")
+    sw, sx = [int(v) for v in g["doa_seeds"]]
+    net, _ = build_net(dev, sw, True, True)
+    got = net(to_dev(rs_randn(sx, (1, 4, 256, 12)), dev)).cpu().numpy()
+    assert got.shape == (1, 1, 180)
+    assert_close(got, g["doa_out"], RTOL, ATOL, "DOA head")
+
+
+def test_fnssl_block_by_block_equals_fused(dev):
+    """FNblock.forward x3 + head (the reference's call sequence) == the fused library forward."""
+    from fnssl import ops
+    net, _ = build_net(dev, 55)
+    x = to_dev(rs_randn(56, (2, 4, 32, 26)), dev)
+    fused = net(x)
+    xs = x.permute(0, 3, 2, 1)
+    y, fb, nbs = net.block_1(xs)
+    y, fb, nbs = net.block_2(y, fb_skip=fb, nb_skip=nbs)
+    y, fb, nbs = net.block_3(y, fb_skip=fb, nb_skip=nbs)
+    out = ops.head(y.permute(0, 2, 1, 3), net.emb2ipd.weight.detach(), net.emb2ipd.bias.detach())
+    assert torch.equal(out, fused)
+
+
+def test_fnssl_requires_eval_and_device(dev):
+    import Model as at_model
+    net = at_model.FN_SSL().to(dev)
+    with pytest.raises(RuntimeError, match="eval"):
+        net(torch.zeros(1, 4, 16, 12, device=dev))
+    net.eval()
+    with pytest.raises(RuntimeError, match="ROCm device tensor"):
+        net(torch.zeros(1, 4, 16, 12))
+    with pytest.raises(RuntimeError, match="expected"):
+        net(torch.zeros(1, 3, 16, 12, device=dev))
+    assert tuple(net(torch.zeros(2, 4, 16, 11, device=dev)).shape) == (2, 0, 32)   # < 12 frames: empty, like AvgPool
+
+
+def test_predict_step_config1_golden(dev):
+    """BASELINE config 1: one 4 s 2-mic utterance, waveform -> DP-IPD, against the reference's output."""
+    import predict_step as ps
+    from fnssl import weights as W
+    g = load_golden("g9_config1")
+    sw, sx = [int(v) for v in g["seeds"]]
+    model = ps.MyModel(device=str(dev))
+    model.arch.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_fnssl_state(sw).items()})
+    model = model.to(dev).eval()
+    batch = to_dev(rs_randn(sx, g["shape"], float(g["scale"])), dev)
+    out = model.predict_step(batch, 0)
+    assert tuple(out.shape) == (1, 20, 512)
+    assert_close(out.cpu().numpy(), g["out"], RTOL, ATOL, "config 1 end to end")
+    feats = model.data_preprocess(batch.permute(0, 2, 1))[0]
+    assert tuple(feats.shape) == (1, 4, 256, 249)
+    assert_close(feats.cpu().numpy()[:, :, ::32, ::8], g["x_sub"], 2e-5, 2e-5, "config 1 features")
+
+
+# --------------------------------------------------------------------------- size-independent properties
+def test_pairs_are_independent_and_chunking_is_exact(dev):
+    """Every mic pair is an independent unit: a pair's output must not depend on
+    its batch mates, on the pass it is processed in, or on the launch geometry."""
+    net, _ = build_net(dev, 61)
+    x = to_dev(rs_randn(62, (7, 4, 48, 40)), dev)
+    whole = net(x)
+    net.chunk_pairs = 3
+    chunked = net(x)
+    net.chunk_pairs = 0
+    assert torch.equal(whole, chunked)
+    for p in (0, 3, 6):
+        assert torch.equal(net(x[p:p + 1]), whole[p:p + 1])
+
+
+def test_full_size_frame_slice_against_oracle(dev):
+    """BASELINE config-2 geometry (257 bins x 300 frames) on one 2-mic utterance vs the oracle."""
+    from oracle import fnssl_oracle as O
+    import predict_step as ps
+    net, sd = build_net(dev, 71)
+    batch = rs_randn(72, (1, 2, 77056), 0.05)
+    model = ps.MyModel(device=str(dev))
+    model.arch = net
+    out = model.predict_step(to_dev(batch, dev), 0).cpu().numpy()
+    want = O.predict_step(sd, batch, "MM", True)
+    assert out.shape == want.shape == (1, 25, 512)
+    assert_close(out, want, RTOL, ATOL, "257 x 300 utterance")

@@ -87,3 +87,14 @@ def test_packed_stream_through_mfma_emulation_matches_oracle(c0, c2, H, reverse)
     want = O.lstm_dir(x, sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"],
                       reverse=reverse)
     assert_close(got, want, 1e-5, 1e-6, "emulated wave vs oracle")
+
+
+def test_checkpoint_key_names_match_reference():
+    """state_dict keys/shapes are the drop-in contract; CPU-only check of the module."""
+    import Model as at_model
+    from fnssl import weights as W
+    for online in (True, False):
+        sd = at_model.FN_SSL(is_online=online).state_dict()
+        want = dict(W.fnssl_param_shapes(is_online=online))
+        assert {k: tuple(v.shape) for k, v in sd.items()} == want
+    assert list(at_model.FN_lightning().state_dict())[0].startswith("arch.block_1.fullLstm.")

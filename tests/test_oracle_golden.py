@@ -122,3 +122,26 @@ def test_g9_config1_end_to_end():
 def test_flop_accounting_matches_baseline_md():
     assert O.flops_per_tf_point(True) == 4997120
     assert O.flops_per_tf_point(False) == 4210688
+
+
+# --- the torch CPU baseline (oracle/torch_ref.py) is pinned to the same vectors -------------
+def test_torch_ref_fnssl_small():
+    import torch
+    from oracle import torch_ref as R
+    g = load_golden("g7_fnssl")
+    for online in (True, False):
+        t = "on" if online else "off"
+        sw, sa, sb, sc = [int(v) for v in g[t + "_seeds"]]
+        net = R.build(W.make_fnssl_state(sw, is_online=online), online)
+        with torch.no_grad():
+            got = net(torch.from_numpy(rs_randn(sa, (2, 4, 16, 24)))).numpy()
+        assert_close(got, g[t + "_a"], what="torch_ref " + t, rtol=1e-5, atol=1e-6)
+
+
+def test_torch_ref_features():
+    import torch
+    from oracle import torch_ref as R
+    g = load_golden("g4_features")
+    sig3 = rs_randn(g["seed3"], g["shape3"])
+    got = R.data_preprocess(torch.from_numpy(sig3), "MM").numpy()
+    assert_close(got, g["x3"], 1e-6, 1e-6, "torch_ref features")

@@ -224,10 +224,10 @@ int fnssl_forgetting_coefs(int nt, int sample_length, float* a, float* b) {
 
 int fnssl_stft(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc, float* spec,
                float* magsum, void* stream) {
-  FNSSL_REQUIRE(sig && spec, "stft: null pointer");
   FNSSL_REQUIRE(nb > 0 && nch > 0, "stft: empty batch (nb %d, nch %d)", nb, nch);
   const int nt = fnssl_num_frames(ns);
   FNSSL_REQUIRE(nt > 0, "stft: signal of %d samples is shorter than one %d-sample window", ns, kWin);
+  FNSSL_REQUIRE(sig && spec, "stft: null pointer");
   const long long nframes = (long long)nb * nch * nt;
   const long long nblk = (nframes + kFramesPerBlock - 1) / kFramesPerBlock;
   FNSSL_REQUIRE(nblk < (1ll << 31), "stft: too many frames");

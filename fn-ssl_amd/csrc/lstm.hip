@@ -41,6 +41,7 @@ struct LstmParams {
   int nseq, q_inner, nsteps, ndir;
   int wgs_per_dir;
   int quads_per_slice;
+  int chq, pad;   // ring chunk (quads) and per-slice padding (quads); 0 for direct variants
 };
 
 // ---- stream geometry (shared by packer and kernel) -------------------------
@@ -124,11 +125,12 @@ struct WStream<NW, M, 0> {
   unsigned vlane;
   unsigned cur;   // byte offset of the current quad in the stream
   unsigned bytes_per_step;
-  __device__ __forceinline__ void init(const float* wp, int lane, int /*w*/, int rps, char* /*smem*/) {
+  __device__ __forceinline__ void init(const float* wp, int lane, int /*w*/, int qps, int nslices, int /*chq*/,
+                                       int /*pad*/, char* /*smem*/) {
     rw = make_rsrc(wp);
     vlane = lane * 16;
     cur = 0;
-    bytes_per_step = rps * 1024u;
+    bytes_per_step = (unsigned)(qps * nslices) * 4096u;
   }
   __device__ __forceinline__ v4f record(int j) const { return bld4(rw, vlane, cur + j * 1024); }
   __device__ __forceinline__ void next_quad() {
@@ -137,49 +139,68 @@ struct WStream<NW, M, 0> {
   }
 };
 
+// LDS ring, 2 slots of `chq` quads.  The host picks chq and a per-slice padding so
+// that (quads_per_slice + pad) % chq == 0: chunk boundaries then coincide with slice
+// ends, i.e. the last commit of a slice sits right before the cell update (whose
+// stores would otherwise sit in front of the next commit's in-order vmcnt wait).
+// Record r of a chunk is staged by wave r % NW (its (r / NW)-th register, < M).
 template <int NW, int M>
 struct WStream<NW, M, 1> {
-  static constexpr int CH = NW * M;
-  static constexpr int CHQ = CH / 4;
-  static_assert(CH % 4 == 0, "chunk must be whole quads");
   rsrc_t rw;
   unsigned vlane;
   char* lds_rd;         // smem + lane*16
-  char* lds_wr;         // smem + (w*M)*1024 + lane*16
-  int recs_per_step;
-  int src_rec;          // stream record (mod recs_per_step) of this wave's next staged chunk part
-  int rq;               // quad index inside the ring, 0 .. 2*CHQ-1
+  char* lds_wr;         // smem + w*1024 + lane*16
+  int w;
+  int chq;              // quads per chunk
+  int ch;               // records per chunk
+  int qps4;             // real records per slice
+  int vslice4;          // virtual records per slice (incl. padding)
+  int recs_per_step;    // real records per step
+  int src_slice_base;   // real record index of the slice the next staged chunk belongs to
+  int src_off;          // virtual record offset of that chunk inside its slice
+  int rq;               // quad index inside the ring, 0 .. 2*chq-1
   int left;             // quads left in the current chunk
-  int wslot;            // slot the staged chunk goes to
+  int wslot;
   v4f stg[M];
 
   __device__ __forceinline__ void issue_loads() {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      int r = src_rec + m;
-      if (r >= recs_per_step) r -= recs_per_step;   // launcher guarantees recs_per_step >= CH
-      stg[m] = bld4(rw, vlane, (unsigned)r * 1024u);
+      const int r = w + m * NW;              // record inside the chunk
+      const int vo = src_off + r;            // virtual offset inside the slice
+      if (r < ch && vo < qps4) stg[m] = bld4(rw, vlane, (unsigned)(src_slice_base + vo) * 1024u);
     }
-    src_rec += CH;
-    if (src_rec >= recs_per_step) src_rec -= recs_per_step;
+    src_off += ch;
+    if (src_off == vslice4) {
+      src_off = 0;
+      src_slice_base += qps4;
+      if (src_slice_base == recs_per_step) src_slice_base = 0;
+    }
   }
   __device__ __forceinline__ void commit_and_barrier() {
 #pragma unroll
     for (int m = 0; m < M; ++m)
-      *reinterpret_cast<v4f*>(lds_wr + wslot * (CH * 1024) + m * 1024) = stg[m];
+      if (w + m * NW < ch) *reinterpret_cast<v4f*>(lds_wr + wslot * (ch * 1024) + m * (NW * 1024)) = stg[m];
     wslot ^= 1;
     // my ring writes have landed and my reads of the previous chunk have returned
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  __device__ __forceinline__ void init(const float* wp, int lane, int w, int rps, char* smem) {
+  __device__ __forceinline__ void init(const float* wp, int lane, int w_, int qps, int nslices, int chq_, int pad,
+                                       char* smem) {
     rw = make_rsrc(wp);
     vlane = lane * 16;
+    w = w_;
     lds_rd = smem + lane * 16;
-    lds_wr = smem + (w * M) * 1024 + lane * 16;
-    recs_per_step = rps;
-    src_rec = w * M;        // < CH <= recs_per_step
+    lds_wr = smem + w_ * 1024 + lane * 16;
+    chq = chq_;
+    ch = chq_ * 4;
+    qps4 = qps * 4;
+    vslice4 = (qps + pad) * 4;
+    recs_per_step = nslices * qps * 4;
+    src_slice_base = 0;
+    src_off = 0;
     rq = 0;
-    left = CHQ;
+    left = chq_;
     wslot = 0;
     issue_loads();          // chunk 0
     commit_and_barrier();   // chunk 0 visible
@@ -189,16 +210,16 @@ struct WStream<NW, M, 1> {
     return *reinterpret_cast<const v4f*>(lds_rd + rq * 4096 + j * 1024);
   }
   __device__ __forceinline__ void next_quad() {
-    rq = (rq + 1 == 2 * CHQ) ? 0 : rq + 1;
+    rq = (rq + 1 == 2 * chq) ? 0 : rq + 1;
     if (--left == 0) {
-      left = CHQ;
+      left = chq;
       commit_and_barrier();   // publish the next chunk (loaded one period ago)
       issue_loads();          // and start fetching the one after it
     }
   }
 };
 
-template <int H, int NW, int M, int WMODE, bool HAS1>
+template <int H, int NW, int M, int WMODE, bool HAS1, bool HAS2>
 __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   constexpr int NS = H / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,20 +238,20 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   unsigned vo0 = 0, vo1 = 0, vo2 = 0, voo = 0;
   const rsrc_t rx0 = split_addr(p.src0.p, qo * p.src0.so + qi * p.src0.si, 4 * g, vo0);
   const rsrc_t rx1 = HAS1 ? split_addr(p.src1.p, qo * p.src1.so + qi * p.src1.si, 4 * g, vo1) : rx0;
-  const rsrc_t rx2 = p.c2 ? split_addr(p.src2.p, qo * p.src2.so + qi * p.src2.si, 0, vo2) : rx0;
+  const rsrc_t rx2 = HAS2 ? split_addr(p.src2.p, qo * p.src2.so + qi * p.src2.si, 0, vo2) : rx0;
   const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
   const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
                               ((size_t)blockIdx.x * NW + w) * (NS * 1024));
   const unsigned st0 = (unsigned)(p.src0.st * 4), st1 = (unsigned)(p.src1.st * 4);
-  const unsigned st2 = (unsigned)(p.src2.st * 4), sto = (unsigned)(p.out_st * 4);
+  const unsigned st2 = HAS2 ? (unsigned)(p.src2.st * 4) : 0u, sto = (unsigned)(p.out_st * 4);
   const unsigned vlane = lane * 16;
 
   const int nv0 = p.c0 >> 4, ns0 = (p.c0 & 15) >> 2;
-  const int nv2 = p.c2 >> 4, ns2 = (p.c2 & 15) >> 2;
+  const int nv2 = HAS2 ? p.c2 >> 4 : 0, ns2 = HAS2 ? (p.c2 & 15) >> 2 : 0;
   const bool rev = dir == 1;
 
   WStream<NW, M, WMODE> ws;
-  ws.init(p.wpack[dir], lane, w, NS * p.quads_per_slice * 4, smem);
+  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, NS, p.chq, p.pad, smem);
 
   v4f hold[NS];
 #pragma unroll
@@ -241,7 +262,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   // 16-channel blocks this wave will consume (summed only at consumption, so the
   // loads stay in flight behind >= 2 quads of MFMAs); the pipeline runs across
   // slice and step boundaries.
-  v4f pa0 = zero4, pb0 = zero4, pa1 = zero4, pb1 = zero4;
+  v4f pa0 = zero4, pb0 = zero4, pa1 = zero4, pb1 = zero4;   // raw blocks 0, 1 of the next slice
+  v4f pc0 = zero4, pd0 = zero4, pc1 = zero4, pd1 = zero4;   // raw blocks 2, 3 of the next slice
   {
     const unsigned tt0 = rev ? p.nsteps - 1 : 0;
     if (nv0 > 0) {
@@ -251,6 +273,14 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
     if (nv0 > 1) {
       pa1 = bld4(rx0, vo0, tt0 * st0 + 64);
       if (HAS1) pb1 = bld4(rx1, vo1, tt0 * st1 + 64);
+    }
+    if (nv0 > 2) {
+      pc0 = bld4(rx0, vo0, tt0 * st0 + 128);
+      if (HAS1) pd0 = bld4(rx1, vo1, tt0 * st1 + 128);
+    }
+    if (nv0 > 3) {
+      pc1 = bld4(rx0, vo0, tt0 * st0 + 192);
+      if (HAS1) pd1 = bld4(rx1, vo1, tt0 * st1 + 192);
     }
   }
 
@@ -266,7 +296,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       xs0 = bld1(rx0, vo0 - 12 * g, o0 + 64 * nv0);
       if (HAS1) xs0 += bld1(rx1, vo1 - 12 * g, o1 + 64 * nv0);
     }
-    if (ns2 > 0) xs2 = bld1(rx2, vo2 + 4 * g, o2 + 64 * nv2);
+    if (HAS2 && ns2 > 0) xs2 = bld1(rx2, vo2 + 4 * g, o2 + 64 * nv2);
     if (step > 0) {
       // h_{t-1}: each lane re-reads exactly the float4s it stored one step ago
       const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
@@ -279,14 +309,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       if (step > 0) cprev = bld4(rc, vlane, s * 1024);
       v4f xc0 = HAS1 ? pa0 + pb0 : pa0;   // blocks 0, 1: issued during the previous slice
       v4f xc1 = HAS1 ? pa1 + pb1 : pa1;
-      if (nv0 > 2) {
-        pa0 = bld4(rx0, vo0, o0 + 128);
-        if (HAS1) pb0 = bld4(rx1, vo1, o1 + 128);
-      }
-      if (nv0 > 3) {
-        pa1 = bld4(rx0, vo0, o0 + 192);
-        if (HAS1) pb1 = bld4(rx1, vo1, o1 + 192);
-      }
+      pa0 = pc0;                           // blocks 2, 3: issued before the previous cell update,
+      pb0 = pd0;                           // i.e. ahead of its stores in the in-order vmcnt queue
+      pa1 = pc1;
+      pb1 = pd1;
 
       v4f acc[4];
       acc[0] = ws.record(0);
@@ -376,6 +402,19 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         MFMA4(acc, a3, hold[sp].w);
         ws.next_quad();
       }
+      for (int u = 0; u < p.pad; ++u) ws.next_quad();   // ring padding: chunk ends == slice ends
+      {
+        const unsigned n0 = (s + 1 < NS ? tt : ttn) * st0;
+        const unsigned n1 = (s + 1 < NS ? tt : ttn) * st1;
+        if (nv0 > 2) {
+          pc0 = bld4(rx0, vo0, n0 + 128);
+          if (HAS1) pd0 = bld4(rx1, vo1, n1 + 128);
+        }
+        if (nv0 > 3) {
+          pc1 = bld4(rx0, vo0, n0 + 192);
+          if (HAS1) pd1 = bld4(rx1, vo1, n1 + 192);
+        }
+      }
       // ---- cell update (PyTorch gate order i, f, g, o) ----------------------
       const v4f ig = sigmoid4(acc[0]);
       const v4f fg = sigmoid4(acc[1]);
@@ -390,61 +429,100 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
 }
 
 // ---- launcher ----------------------------------------------------------------
-struct Variant {
-  int H, NW, M, WMODE;
-};
-
-template <int H, int NW, int M, int WMODE>
-int launch_t(const LstmParams& p, bool has1, int nwg, hipStream_t st) {
-  const size_t lds = WMODE ? (size_t)2 * NW * M * 1024 : 0;
-  if (has1) {
-    auto k = lstm_rec_kernel<H, NW, M, WMODE, true>;
-    if (lds > 48 * 1024) FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);
-  } else {
-    auto k = lstm_rec_kernel<H, NW, M, WMODE, false>;
-    if (lds > 48 * 1024) FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);
-  }
+template <int H, int NW, int M, int WMODE, bool HAS1, bool HAS2>
+int launch_k(const LstmParams& p, int nwg, hipStream_t st) {
+  const size_t lds = WMODE ? (size_t)2 * p.chq * 4096 : 0;
+  auto k = lstm_rec_kernel<H, NW, M, WMODE, HAS1, HAS2>;
+  if (lds > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);
   FNSSL_CHECK_LAUNCH("lstm_rec_kernel");
   return FNSSL_OK;
 }
 
-// variant id -> (NW, M, WMODE); id 0 is resolved per H by default_variant().
-//   1: NW=4  direct      2: NW=4  ring M=1     3: NW=8 ring M=2
-//   4: NW=12 ring M=2    5: NW=16 ring M=1     6: NW=8 direct     7: NW=12 ring M=1
+template <int H, int NW, int M, int WMODE>
+int launch_t(const LstmParams& p, bool has1, int nwg, hipStream_t st) {
+  const bool has2 = p.c2 > 0;
+  if (has1) return has2 ? launch_k<H, NW, M, WMODE, true, true>(p, nwg, st) : launch_k<H, NW, M, WMODE, true, false>(p, nwg, st);
+  return has2 ? launch_k<H, NW, M, WMODE, false, true>(p, nwg, st) : launch_k<H, NW, M, WMODE, false, false>(p, nwg, st);
+}
+
+// Launch geometries.  NW = waves per workgroup (all share one weight stream),
+// M = ring records staged per wave per chunk (chunk <= NW*M records), ring 0 = the
+// weight stream is read straight from L1/L2.
+struct Variant {
+  int NW, M, ring;
+};
+constexpr int kNumVariants = 8;
+const Variant kVariants[kNumVariants + 1] = {
+    {0, 0, 0},
+    {4, 1, 0},    // 1
+    {4, 4, 1},    // 2
+    {8, 4, 1},    // 3
+    {12, 4, 1},   // 4
+    {16, 2, 1},   // 5
+    {8, 1, 0},    // 6
+    {12, 2, 1},   // 7
+    {16, 4, 1},   // 8
+};
+
+int env_int(const char* name, int lo, int hi) {
+  if (const char* e = getenv(name)) {
+    const int v = atoi(e);
+    if (v >= lo && v <= hi) return v;
+  }
+  return 0;
+}
+
 int default_variant(int H) {
   // tuning override for experiments: FNSSL_LSTM_VARIANT_H256=3 etc.
   char name[40];
   snprintf(name, sizeof(name), "FNSSL_LSTM_VARIANT_H%d", H);
-  if (const char* e = getenv(name)) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 7) return v;
-  }
+  if (const int v = env_int(name, 1, kNumVariants)) return v;
   if (H == 256) return 4;
   if (H == 128) return 5;
   return 2;
 }
 
+// Ring chunk: the largest chq <= NW*M/4 with (qps + pad) % chq == 0 for a padding
+// pad <= 3 quads (chunk boundaries then coincide with slice ends).
+void choose_chunk(int qps, const Variant& v, int& chq, int& pad) {
+  const int cap = v.NW * v.M / 4;
+  int best_c = 1, best_p = 0;
+  for (int p = 0; p <= 3; ++p)
+    for (int c = cap; c >= 1; --c)
+      if ((qps + p) % c == 0) {
+        // prefer fewer commits per slice; break ties towards less padding
+        if (c > best_c) {
+          best_c = c;
+          best_p = p;
+        }
+        break;
+      }
+  chq = best_c;
+  pad = best_p;
+  if (const int f = env_int("FNSSL_LSTM_CHQ", 1, cap)) {   // experiments: force a chunk size
+    chq = f;
+    pad = (f - qps % f) % f;
+  }
+}
+
 template <int H>
-int launch_h(int variant, const LstmParams& p, bool has1, int nwg_of[8], hipStream_t st) {
+int launch_h(int variant, const LstmParams& p, bool has1, int nwg, hipStream_t st) {
   switch (variant) {
-    case 1: return launch_t<H, 4, 1, 0>(p, has1, nwg_of[1], st);
-    case 2: return launch_t<H, 4, 1, 1>(p, has1, nwg_of[2], st);
-    case 3: return launch_t<H, 8, 2, 1>(p, has1, nwg_of[3], st);
-    case 4: return launch_t<H, 12, 2, 1>(p, has1, nwg_of[4], st);
-    case 5: return launch_t<H, 16, 1, 1>(p, has1, nwg_of[5], st);
-    case 6: return launch_t<H, 8, 1, 0>(p, has1, nwg_of[6], st);
-    case 7: return launch_t<H, 12, 1, 1>(p, has1, nwg_of[7], st);
+    case 1: return launch_t<H, 4, 1, 0>(p, has1, nwg, st);
+    case 2: return launch_t<H, 4, 4, 1>(p, has1, nwg, st);
+    case 3: return launch_t<H, 8, 4, 1>(p, has1, nwg, st);
+    case 4: return launch_t<H, 12, 4, 1>(p, has1, nwg, st);
+    case 5: return launch_t<H, 16, 2, 1>(p, has1, nwg, st);
+    case 6: return launch_t<H, 8, 1, 0>(p, has1, nwg, st);
+    case 7: return launch_t<H, 12, 2, 1>(p, has1, nwg, st);
+    case 8: return launch_t<H, 16, 4, 1>(p, has1, nwg, st);
   }
   fnssl::set_error("lstm: unknown variant %d", variant);
   return FNSSL_E_INVALID;
 }
-
-const int kVariantNW[8] = {0, 4, 4, 8, 12, 16, 8, 12};
-const int kVariantCH[8] = {0, 0, 4, 16, 24, 16, 0, 12};   // ring chunk (records); 0 = no ring
 
 }  // namespace
 
@@ -550,10 +628,9 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     fnssl::set_error("lstm_forward: workspace %zu < %zu bytes", d->workspace_bytes, need);
     return FNSSL_E_WORKSPACE;
   }
-  int variant = d->variant ? d->variant : default_variant(H);
-  FNSSL_REQUIRE(variant >= 1 && variant <= 7, "lstm_forward: unknown variant %d", variant);
-  // the ring wraps the stream at most once per chunk: tiny nets use the 4-record chunk
-  if (kVariantCH[variant] > (H / 16) * quads_per_slice(d->c0, d->c2, H) * 4) variant = 2;
+  const int variant = d->variant ? d->variant : default_variant(H);
+  FNSSL_REQUIRE(variant >= 1 && variant <= kNumVariants, "lstm_forward: unknown variant %d", variant);
+  const Variant& vr = kVariants[variant];
 
   LstmParams p;
   p.src0 = View{d->src0.p, d->src0.so, d->src0.si, d->src0.st};
@@ -573,10 +650,12 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.nsteps = d->nsteps;
   p.ndir = d->ndir;
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
+  p.chq = 0;
+  p.pad = 0;
+  if (vr.ring) choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
   const int tasks = (d->nseq + 15) / 16;
-  int nwg_of[8];
-  for (int v = 1; v < 8; ++v) nwg_of[v] = (tasks + kVariantNW[v] - 1) / kVariantNW[v] * d->ndir;
-  p.wgs_per_dir = nwg_of[variant] / d->ndir;
+  p.wgs_per_dir = (tasks + vr.NW - 1) / vr.NW;
+  const int nwg = p.wgs_per_dir * d->ndir;
   const bool has1 = d->src1.p != nullptr && d->c0 > 0;
 
   const double flops = 2.0 * 4 * H * (double)(d->c0 + d->c2 + H) * d->nseq * (double)d->nsteps * d->ndir;
@@ -585,11 +664,11 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   fnssl::TimedLaunch tl(names[hi], fnssl::as_stream(stream), flops);
   hipStream_t st = fnssl::as_stream(stream);
   switch (H) {
-    case 16: return launch_h<16>(variant, p, has1, nwg_of, st);
-    case 32: return launch_h<32>(variant, p, has1, nwg_of, st);
-    case 64: return launch_h<64>(variant, p, has1, nwg_of, st);
-    case 128: return launch_h<128>(variant, p, has1, nwg_of, st);
-    default: return launch_h<256>(variant, p, has1, nwg_of, st);
+    case 16: return launch_h<16>(variant, p, has1, nwg, st);
+    case 32: return launch_h<32>(variant, p, has1, nwg, st);
+    case 64: return launch_h<64>(variant, p, has1, nwg, st);
+    case 128: return launch_h<128>(variant, p, has1, nwg, st);
+    default: return launch_h<256>(variant, p, has1, nwg, st);
   }
 }
 

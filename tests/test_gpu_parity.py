@@ -177,7 +177,7 @@ def test_lstm_kernel_variants_are_bit_identical(dev, H, c0):
     base, want = run_layer(dev, c0, 0, H, True if H == 128 else False, "narrow", 2, 6, 23, variant=1, seed=5,
                            with_skip=c0 > 4)
     assert_close(base, want, RTOL, ATOL, "variant 1")
-    for v in range(2, 8):
+    for v in range(2, 9):
         got, _ = run_layer(dev, c0, 0, H, True if H == 128 else False, "narrow", 2, 6, 23, variant=v, seed=5,
                            with_skip=c0 > 4)
         np.testing.assert_array_equal(got, base, err_msg="variant %d differs from variant 1" % v)

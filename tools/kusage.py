@@ -24,9 +24,9 @@ for line in sys.stdin:
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
 for r in rows:
     name = r["name"]
-    m = re.search(r"lstm_rec_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)", name)
+    m = re.search(r"lstm_rec_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)", name)
     if m:
-        name = "lstm H=%s NW=%s M=%s WMODE=%s HAS1=%s" % m.groups()
+        name = "lstm H=%s NW=%s M=%s WMODE=%s HAS1=%s HAS2=%s" % m.groups()
     if filt and not re.search(filt, name):
         continue
     print("%-46s vgpr %3d agpr %3d sgpr %3d scratch %3d spill %3d occ %d lds %d" % (

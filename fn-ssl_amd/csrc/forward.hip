@@ -1,10 +1,12 @@
 // FN_SSL.forward on device (reference FN-SSL/Model.py:72-90 and FNblock.forward
 // :31-50): three full-band / narrow-band blocks and the DP-IPD head, with every
-// permute / reshape / cat / residual add of the reference folded into the strided
-// operand views of the LSTM kernels (nothing but LSTM outputs is ever
-// materialised).  Full-band outputs live in [pairs, nt, nf, 256], narrow-band
-// outputs in [pairs, nf, nt, 256] — each kernel writes the layout in which the
-// NEXT kernel's 16 sequences per wave are adjacent.
+// permute / reshape / cat of the reference folded into the strided operand views
+// of the LSTM kernels, and every residual add (x + fb_skip, x + nb_skip,
+// Model.py:36-37,44-45) folded into the PRODUCING kernel's epilogue: each LSTM
+// kernel stores its raw output h and, next to it, h + skip = the next layer's
+// input, so every layer streams ONE input tensor.  Full-band tensors live in
+// [pairs, nt, nf, 256], narrow-band tensors in [pairs, nf, nt, 256] — the layout
+// in which the writing kernel's 16 sequences per wave are adjacent.
 #include <algorithm>
 
 #include "common.h"
@@ -30,7 +32,7 @@ Plan make_plan(int nb, int nf, int nt, int is_online, int chunk_pairs) {
                                    : fnssl_lstm_workspace_bytes(p.chunk * nf, 128, 2);
   p.lstm_ws = align_up(std::max(ws_full, ws_narr), 256);
   p.head_floats = (size_t)p.chunk * (nt / FNSSL_SEG_FRAMES) * 2 * nf;
-  p.total = 4 * align_up(p.act_floats * 4, 256) + p.lstm_ws + align_up(p.head_floats * 4, 256) + 256;
+  p.total = 6 * align_up(p.act_floats * 4, 256) + p.lstm_ws + align_up(p.head_floats * 4, 256) + 256;
   return p;
 }
 
@@ -62,14 +64,29 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
   const size_t act_bytes = align_up(pl.act_floats * 4, 256);
   float* F[2] = {reinterpret_cast<float*>(wsb), reinterpret_cast<float*>(wsb + act_bytes)};
   float* N[2] = {reinterpret_cast<float*>(wsb + 2 * act_bytes), reinterpret_cast<float*>(wsb + 3 * act_bytes)};
-  float* lws = reinterpret_cast<float*>(wsb + 4 * act_bytes);
-  float* head_tmp = reinterpret_cast<float*>(wsb + 4 * act_bytes + pl.lstm_ws);
+  float* Sf = reinterpret_cast<float*>(wsb + 4 * act_bytes);   // f_k + n_{k-1}: narrow-band input, full layout
+  float* Sn = reinterpret_cast<float*>(wsb + 5 * act_bytes);   // n_k + f_k    : full-band input, narrow layout
+  float* lws = reinterpret_cast<float*>(wsb + 6 * act_bytes);
+  float* head_tmp = reinterpret_cast<float*>(wsb + 6 * act_bytes + pl.lstm_ws);
 
   const int cin = net->input_size;
   const int nt2 = nt / FNSSL_SEG_FRAMES;
   const int narr_h = net->is_online ? 256 : 128;
   const int narr_dirs = net->is_online ? 1 : 2;
   const long long C = 256;
+  // strides of the two activation layouts, as (sequence-outer, sequence-inner, step)
+  const long long PS = (long long)nt * nf * C;                         // one pair
+  // full layout [pair, t, f, C]  : seen by the full-band kernel (seq = (pair, t), step = f) ...
+  const fnssl_view fl_by_full = {nullptr, PS, (long long)nf * C, C};
+  // ... and by the narrow-band kernel (seq = (pair, f), step = t)
+  const fnssl_view fl_by_narr = {nullptr, PS, C, (long long)nf * C};
+  // narrow layout [pair, f, t, C]
+  const fnssl_view nl_by_full = {nullptr, PS, C, (long long)nt * C};
+  const fnssl_view nl_by_narr = {nullptr, PS, (long long)nt * C, C};
+  auto with = [](fnssl_view v, const float* p) {
+    v.p = p;
+    return v;
+  };
 
   for (int p0 = 0; p0 < nb; p0 += pl.chunk) {
     const int G = std::min(pl.chunk, nb - p0);
@@ -77,8 +94,7 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
     for (int blk = 0; blk < 3; ++blk) {
       float* Fo = F[blk & 1];
       float* No = N[blk & 1];
-      const float* Fp = F[(blk + 1) & 1];   // previous block's full-band output
-      const float* Np = N[(blk + 1) & 1];   // previous block's narrow-band output
+      const float* Np = N[(blk + 1) & 1];   // previous block's narrow-band output (raw)
       // ---- full-band BiLSTM over frequency, one sequence per (pair, frame) ----
       fnssl_lstm_desc d = {};
       d.hidden = 128;
@@ -90,14 +106,17 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
         d.src0 = fnssl_view{xc, (long long)nt * nf * cin, (long long)nf * cin, cin};
         d.c0 = cin;
       } else {
-        d.src0 = fnssl_view{Np, (long long)nf * nt * C, C, (long long)nt * C};            // x   (Model.py:35)
-        d.src1 = fnssl_view{Fp, (long long)nt * nf * C, (long long)nf * C, C};            // + fb_skip (:36-37)
+        d.src0 = with(nl_by_full, Sn);      // x + fb_skip (Model.py:35-37), summed by the previous narrow kernel
         d.c0 = 256;
       }
       d.out = Fo;
-      d.out_so = (long long)nt * nf * C;
-      d.out_si = (long long)nf * C;
-      d.out_st = C;
+      d.out_so = fl_by_full.so;
+      d.out_si = fl_by_full.si;
+      d.out_st = fl_by_full.st;
+      if (blk > 0) {                        // dropout(f) + nb_skip (Model.py:44-45) for this block's narrow LSTM
+        d.skip = with(nl_by_full, Np);
+        d.out_sum = Sf;
+      }
       d.wpack[0] = net->wpack[blk][0][0];
       d.wpack[1] = net->wpack[blk][0][1];
       d.workspace = lws;
@@ -111,18 +130,22 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
       e.nseq = G * nf;
       e.q_inner = nf;
       e.nsteps = nt;
-      e.src0 = fnssl_view{Fo, (long long)nt * nf * C, C, (long long)nf * C};              // dropout(f) (:40-41)
       e.c0 = 256;
       if (blk == 0) {
-        e.src2 = fnssl_view{xc, (long long)nt * nf * cin, cin, (long long)nf * cin};      // cat nb_skip (:42-43)
+        e.src0 = with(fl_by_narr, Fo);                                                     // dropout(f) (:40-41)
+        e.src2 = fnssl_view{xc, (long long)nt * nf * cin, cin, (long long)nf * cin};       // cat nb_skip (:42-43)
         e.c2 = cin;
       } else {
-        e.src1 = fnssl_view{Np, (long long)nf * nt * C, (long long)nt * C, C};            // + nb_skip (:44-45)
+        e.src0 = with(fl_by_narr, Sf);
       }
       e.out = No;
-      e.out_so = (long long)nf * nt * C;
-      e.out_si = (long long)nt * C;
-      e.out_st = C;
+      e.out_so = nl_by_narr.so;
+      e.out_si = nl_by_narr.si;
+      e.out_st = nl_by_narr.st;
+      if (blk < 2) {                        // next block's full-band input: n + f  (x + fb_skip)
+        e.skip = with(fl_by_narr, Fo);
+        e.out_sum = Sn;
+      }
       e.wpack[0] = net->wpack[blk][1][0];
       e.wpack[1] = net->wpack[blk][1][1];
       e.workspace = lws;

@@ -1,0 +1,6 @@
+// LSTM recurrence kernels for hidden size 256 (explicit instantiation; see lstm_kernel.h).
+#include "lstm_kernel.h"
+
+namespace fnssl_lstm {
+template int launch_h<256>(int, const LstmParams&, int, int, hipStream_t);
+}  // namespace fnssl_lstm

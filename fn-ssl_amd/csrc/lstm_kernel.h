@@ -1,0 +1,564 @@
+// Device code and launch templates of the LSTM recurrence kernel (see lstm.hip for
+// the formulation).  Included by lstm.hip (host entry points) and by the per-hidden-
+// size translation units lstm_h*.hip, which instantiate launch_h<H> so the ~50
+// kernel instantiations per H compile in parallel.
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "common.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace fnssl_lstm {
+
+struct View {
+  const float* p;
+  long long so, si, st;
+};
+
+struct LstmParams {
+  View src0, src1, src2, skip;
+  float* out;
+  float* out_sum;   // optional second output: h + skip (same strides as out)
+  long long out_so, out_si, out_st;
+  const float* wpack[2];
+  float* cscratch;
+  int c0, c2;
+  int nseq, q_inner, nsteps, ndir;
+  int wgs_per_dir;
+  int quads_per_slice;
+  int chq, pad;   // ring chunk (quads) and per-slice padding (quads); 0 for direct variants
+};
+
+// kernel MODE bits
+constexpr int kHas1 = 1;   // input segment 0 is src0 + src1
+constexpr int kHas2 = 2;   // concatenated segment src2 present
+constexpr int kSum = 4;    // epilogue also writes out_sum = h + skip
+
+// ---- stream geometry (shared by packer and kernel) -------------------------
+// per hidden slice (16 units):  quad 0           : 4 bias records (acc init, gate q)
+//                               seg0 vec quads    : c0/16 quads, record j <-> k = 16v + 4g + j
+//                               seg0 scalar quads : (c0%16)/4 quads, record 0 <-> k = base + g
+//                               seg2 vec / scalar : same for the concatenated input
+//                               h quads           : H/16 quads, record j <-> k = 16s' + 4g + j
+__host__ __device__ inline int quads_per_slice(int c0, int c2, int H) {
+  return 1 + (c0 >> 4) + ((c0 & 15) >> 2) + (c2 >> 4) + ((c2 & 15) >> 2) + (H >> 4);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float tanh_f(float x) {
+  // 1 - 2/(e^{2x}+1): saturates cleanly at +-1, abs error ~1e-7
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ v4f sigmoid4(v4f a) {
+  return v4f{sigmoid_f(a.x), sigmoid_f(a.y), sigmoid_f(a.z), sigmoid_f(a.w)};
+}
+__device__ __forceinline__ v4f tanh4(v4f a) {
+  return v4f{tanh_f(a.x), tanh_f(a.y), tanh_f(a.z), tanh_f(a.w)};
+}
+
+#define MFMA4(ACC, AV, BV)                                                          \
+  do {                                                                              \
+    ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).x, (BV), ACC[0], 0, 0, 0);   \
+    ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).y, (BV), ACC[1], 0, 0, 0);   \
+    ACC[2] = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).z, (BV), ACC[2], 0, 0, 0);   \
+    ACC[3] = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).w, (BV), ACC[3], 0, 0, 0);   \
+  } while (0)
+
+// ---- addressing ------------------------------------------------------------
+// Every global access is a raw buffer op: 64-bit wave-uniform base in an SGPR
+// descriptor, one 32-bit per-lane byte offset VGPR per tensor, and the moving
+// part (step, block, record) in the scalar offset.  The host checks that the
+// per-descriptor extents fit in 32 bits.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ v4f bld4(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float bld1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst4(v4f d, rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, d), r, voff, soff, 0);
+}
+
+// Split a per-lane address  base + off_floats (+ extra floats)  into a descriptor
+// whose base is the wave's minimum and a per-lane byte offset >= 0.
+__device__ __forceinline__ rsrc_t split_addr(const float* base, long long off_floats, int extra_floats,
+                                             unsigned& voff) {
+  long long mn = off_floats;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long o = __shfl_xor(mn, d, 64);
+    mn = o < mn ? o : mn;
+  }
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(mn & 0xffffffffll));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)mn >> 32));
+  const long long mnu = (long long)(((unsigned long long)hi << 32) | lo);
+  voff = (unsigned)((off_floats - mnu) * 4) + (unsigned)(extra_floats * 4);
+  return make_rsrc(base + mnu);
+}
+
+// Weight-stream reader.  record(j) reads record j of the current quad,
+// peek_next() the first two records of the following quad (the A operands are
+// software-pipelined one half-quad ahead so that a wave running alone on its SIMD
+// still issues MFMAs back to back), advance() moves on and reports whether a ring
+// commit (barrier) happened — after which the peeked records must be re-read.
+// WMODE 0: straight from global.  WMODE 1: 2-slot LDS ring.
+template <int NW, int M, int WMODE>
+struct WStream;
+
+template <int NW, int M>
+struct WStream<NW, M, 0> {
+  rsrc_t rw;
+  unsigned vlane;
+  unsigned cur;   // byte offset of the current quad in the stream
+  unsigned bytes_per_step;
+  __device__ __forceinline__ void init(const float* wp, int lane, int /*w*/, int qps, int nslices, int /*chq*/,
+                                       int /*pad*/, char* /*smem*/) {
+    rw = make_rsrc(wp);
+    vlane = lane * 16;
+    cur = 0;
+    bytes_per_step = (unsigned)(qps * nslices) * 4096u;
+  }
+  __device__ __forceinline__ v4f record(int j) const { return bld4(rw, vlane, cur + j * 1024); }
+  __device__ __forceinline__ void peek_next(v4f& n0, v4f& n1) const {
+    unsigned nx = cur + 4096;
+    if (nx == bytes_per_step) nx = 0;
+    n0 = bld4(rw, vlane, nx);
+    n1 = bld4(rw, vlane, nx + 1024);
+  }
+  __device__ __forceinline__ bool advance() {
+    cur += 4096;
+    if (cur == bytes_per_step) cur = 0;
+    return false;
+  }
+};
+
+// LDS ring, 2 slots of `chq` quads.  The host picks chq and a per-slice padding so
+// that (quads_per_slice + pad) % chq == 0: chunk boundaries then coincide with slice
+// ends.  Record r of a chunk is staged by wave r % NW (its (r / NW)-th register, < M).
+template <int NW, int M>
+struct WStream<NW, M, 1> {
+  rsrc_t rw;
+  unsigned vlane;
+  char* lds_rd;         // smem + lane*16
+  char* lds_wr;         // smem + w*1024 + lane*16
+  int w;
+  int chq;              // quads per chunk
+  int ch;               // records per chunk
+  int qps4;             // real records per slice
+  int vslice4;          // virtual records per slice (incl. padding)
+  int recs_per_step;    // real records per step
+  int src_slice_base;   // real record index of the slice the next staged chunk belongs to
+  int src_off;          // virtual record offset of that chunk inside its slice
+  int rq;               // quad index inside the ring, 0 .. 2*chq-1
+  int left;             // quads left in the current chunk
+  int wslot;
+  v4f stg[M];
+
+  __device__ __forceinline__ void issue_loads() {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int r = w + m * NW;              // record inside the chunk
+      const int vo = src_off + r;            // virtual offset inside the slice
+      if (r < ch && vo < qps4) stg[m] = bld4(rw, vlane, (unsigned)(src_slice_base + vo) * 1024u);
+    }
+    src_off += ch;
+    if (src_off == vslice4) {
+      src_off = 0;
+      src_slice_base += qps4;
+      if (src_slice_base == recs_per_step) src_slice_base = 0;
+    }
+  }
+  __device__ __forceinline__ void commit_and_barrier() {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      if (w + m * NW < ch) *reinterpret_cast<v4f*>(lds_wr + wslot * (ch * 1024) + m * (NW * 1024)) = stg[m];
+    wslot ^= 1;
+    // my ring writes have landed and my reads of the previous chunk have returned
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  __device__ __forceinline__ void init(const float* wp, int lane, int w_, int qps, int nslices, int chq_, int pad,
+                                       char* smem) {
+    rw = make_rsrc(wp);
+    vlane = lane * 16;
+    w = w_;
+    lds_rd = smem + lane * 16;
+    lds_wr = smem + w_ * 1024 + lane * 16;
+    chq = chq_;
+    ch = chq_ * 4;
+    qps4 = qps * 4;
+    vslice4 = (qps + pad) * 4;
+    recs_per_step = nslices * qps * 4;
+    src_slice_base = 0;
+    src_off = 0;
+    rq = 0;
+    left = chq_;
+    wslot = 0;
+    issue_loads();          // chunk 0
+    commit_and_barrier();   // chunk 0 visible
+    issue_loads();          // chunk 1 in flight
+  }
+  __device__ __forceinline__ v4f record(int j) const {
+    return *reinterpret_cast<const v4f*>(lds_rd + rq * 4096 + j * 1024);
+  }
+  __device__ __forceinline__ void peek_next(v4f& n0, v4f& n1) const {
+    // may run ahead of the publishing barrier at a chunk end: the caller re-reads then
+    const int nq = (rq + 1 == 2 * chq) ? 0 : rq + 1;
+    n0 = *reinterpret_cast<const v4f*>(lds_rd + nq * 4096);
+    n1 = *reinterpret_cast<const v4f*>(lds_rd + nq * 4096 + 1024);
+  }
+  __device__ __forceinline__ bool advance() {
+    rq = (rq + 1 == 2 * chq) ? 0 : rq + 1;
+    if (--left == 0) {
+      left = chq;
+      commit_and_barrier();   // publish the next chunk (loaded one period ago)
+      issue_loads();          // and start fetching the one after it
+      return true;
+    }
+    return false;
+  }
+};
+
+template <int H, int NW, int M, int WMODE, int MODE>
+__global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
+  constexpr int NS = H / 16;
+  constexpr bool HAS1 = (MODE & kHas1) != 0, HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int dir = blockIdx.x / p.wgs_per_dir;
+  const int wg = blockIdx.x - dir * p.wgs_per_dir;
+  const int task = wg * NW + w;
+  int q = task * 16 + n;
+  const bool valid = q < p.nseq;
+  if (!valid) q = p.nseq - 1;
+  const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
+
+  unsigned vo0 = 0, vo1 = 0, vo2 = 0, voo = 0, vok = 0;
+  const rsrc_t rx0 = split_addr(p.src0.p, qo * p.src0.so + qi * p.src0.si, 4 * g, vo0);
+  const rsrc_t rx1 = HAS1 ? split_addr(p.src1.p, qo * p.src1.so + qi * p.src1.si, 4 * g, vo1) : rx0;
+  const rsrc_t rx2 = HAS2 ? split_addr(p.src2.p, qo * p.src2.so + qi * p.src2.si, 0, vo2) : rx0;
+  const rsrc_t rsk = SUM ? split_addr(p.skip.p, qo * p.skip.so + qi * p.skip.si, dir * H + 4 * g, vok) : rx0;
+  const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
+  unsigned voo2 = 0;
+  const rsrc_t ro2 = SUM ? split_addr(p.out_sum, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo2) : ro;
+  const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
+                              ((size_t)blockIdx.x * NW + w) * (NS * 1024));
+  const unsigned st0 = (unsigned)(p.src0.st * 4), st1 = HAS1 ? (unsigned)(p.src1.st * 4) : 0u;
+  const unsigned st2 = HAS2 ? (unsigned)(p.src2.st * 4) : 0u, sto = (unsigned)(p.out_st * 4);
+  const unsigned stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
+  const unsigned vlane = lane * 16;
+
+  const int nv0 = p.c0 >> 4, ns0 = (p.c0 & 15) >> 2;
+  const int nv2 = HAS2 ? p.c2 >> 4 : 0, ns2 = HAS2 ? (p.c2 & 15) >> 2 : 0;
+  const bool rev = dir == 1;
+
+  WStream<NW, M, WMODE> ws;
+  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, NS, p.chq, p.pad, smem);
+  v4f a0 = ws.record(0), a1 = ws.record(1);   // A operands of the current quad's first half
+
+  v4f hold[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) hold[s] = v4f{0.f, 0.f, 0.f, 0.f};
+  const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+  v4f acc[4];
+
+// one full quad: 4 records x 4 gates = 16 MFMAs; the next quad's first two records
+// are requested between the two halves
+#define QUAD(B0, B1, B2, B3)                          \
+  do {                                                \
+    const v4f a2_ = ws.record(2), a3_ = ws.record(3); \
+    __builtin_amdgcn_sched_barrier(0);                \
+    MFMA4(acc, a0, B0);                               \
+    MFMA4(acc, a1, B1);                               \
+    ws.peek_next(a0, a1);                             \
+    __builtin_amdgcn_sched_barrier(0);                \
+    MFMA4(acc, a2_, B2);                              \
+    MFMA4(acc, a3_, B3);                              \
+    if (ws.advance()) {                               \
+      a0 = ws.record(0);                              \
+      a1 = ws.record(1);                              \
+    }                                                 \
+  } while (0)
+// a remainder quad: only record 0 is real
+#define QUAD1(B0)               \
+  do {                          \
+    MFMA4(acc, a0, B0);         \
+    ws.peek_next(a0, a1);       \
+    if (ws.advance()) {         \
+      a0 = ws.record(0);        \
+      a1 = ws.record(1);        \
+    }                           \
+  } while (0)
+
+  // x-operand prefetch registers: RAW loads of the next blocks this wave will consume
+  // (summed only at consumption, so the loads stay in flight behind >= 2 quads of
+  // MFMAs); the pipeline runs across slice and step boundaries.
+  v4f pa0 = zero4, pb0 = zero4, pa1 = zero4, pb1 = zero4;   // blocks 0, 1 of the next slice
+  v4f pc0 = zero4, pd0 = zero4, pc1 = zero4, pd1 = zero4;   // blocks 2, 3 of the next slice
+  {
+    const unsigned tt0 = rev ? p.nsteps - 1 : 0;
+    if (nv0 > 0) {
+      pa0 = bld4(rx0, vo0, tt0 * st0);
+      if (HAS1) pb0 = bld4(rx1, vo1, tt0 * st1);
+    }
+    if (nv0 > 1) {
+      pa1 = bld4(rx0, vo0, tt0 * st0 + 64);
+      if (HAS1) pb1 = bld4(rx1, vo1, tt0 * st1 + 64);
+    }
+    if (nv0 > 2) {
+      pc0 = bld4(rx0, vo0, tt0 * st0 + 128);
+      if (HAS1) pd0 = bld4(rx1, vo1, tt0 * st1 + 128);
+    }
+    if (nv0 > 3) {
+      pc1 = bld4(rx0, vo0, tt0 * st0 + 192);
+      if (HAS1) pd1 = bld4(rx1, vo1, tt0 * st1 + 192);
+    }
+  }
+
+  for (int step = 0; step < p.nsteps; ++step) {
+    const unsigned tt = rev ? p.nsteps - 1 - step : step;
+    const unsigned ttn = step + 1 < p.nsteps ? (rev ? tt - 1 : tt + 1) : tt;   // prefetch target
+    const unsigned o0 = tt * st0, o1 = tt * st1, o2 = tt * st2, oo = tt * sto, ok = tt * stk;
+
+    // the first 4-channel remainder block of each segment is the same for every
+    // slice of the step: keep it in a register  (vo0 carries +4g floats: undo 3g)
+    float xs0 = 0.f, xs2 = 0.f;
+    if (ns0 > 0) {
+      xs0 = bld1(rx0, vo0 - 12 * g, o0 + 64 * nv0);
+      if (HAS1) xs0 += bld1(rx1, vo1 - 12 * g, o1 + 64 * nv0);
+    }
+    if (HAS2 && ns2 > 0) xs2 = bld1(rx2, vo2 + 4 * g, o2 + 64 * nv2);
+    if (step > 0) {
+      // h_{t-1}: each lane re-reads exactly the float4s it stored one step ago
+      const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) hold[s] = bld4(ro, voo, op + 64 * s);
+    }
+
+    for (int s = 0; s < NS; ++s) {
+      v4f cprev = zero4, skipv = zero4;
+      if (step > 0) cprev = bld4(rc, vlane, s * 1024);
+      if (SUM) skipv = bld4(rsk, vok, ok + 64 * s);
+      v4f xc0 = HAS1 ? pa0 + pb0 : pa0;   // blocks 0, 1: issued during the previous slice
+      v4f xc1 = HAS1 ? pa1 + pb1 : pa1;
+      pa0 = pc0;                           // blocks 2, 3: issued before the previous cell update,
+      pa1 = pc1;                           // i.e. ahead of its stores in the in-order vmcnt queue
+      if (HAS1) {
+        pb0 = pd0;
+        pb1 = pd1;
+      }
+
+      // ---- bias quad: accumulator init ------------------------------------
+      acc[0] = a0;
+      acc[1] = a1;
+      acc[2] = ws.record(2);
+      acc[3] = ws.record(3);
+      ws.peek_next(a0, a1);
+      if (ws.advance()) {
+        a0 = ws.record(0);
+        a1 = ws.record(1);
+      }
+
+      // ---- summed input segment, 16 channels per quad -------------------
+      for (int v = 0; v < nv0; v += 2) {
+        QUAD(xc0.x, xc0.y, xc0.z, xc0.w);
+        if (v + 1 < nv0) QUAD(xc1.x, xc1.y, xc1.z, xc1.w);
+        if (v + 2 < nv0) {
+          xc0 = HAS1 ? pa0 + pb0 : pa0;
+          xc1 = HAS1 ? pa1 + pb1 : pa1;
+          if (v + 4 < nv0) {
+            pa0 = bld4(rx0, vo0, o0 + 64 * (v + 4));
+            if (HAS1) pb0 = bld4(rx1, vo1, o1 + 64 * (v + 4));
+          }
+          if (v + 5 < nv0) {
+            pa1 = bld4(rx0, vo0, o0 + 64 * (v + 5));
+            if (HAS1) pb1 = bld4(rx1, vo1, o1 + 64 * (v + 5));
+          }
+        }
+      }
+      const unsigned n0 = (s + 1 < NS ? tt : ttn) * st0;
+      const unsigned n1 = (s + 1 < NS ? tt : ttn) * st1;
+      {
+        // blocks 0, 1 of the next slice (same x_t) or of the next step
+        if (nv0 > 0) {
+          pa0 = bld4(rx0, vo0, n0);
+          if (HAS1) pb0 = bld4(rx1, vo1, n1);
+        }
+        if (nv0 > 1) {
+          pa1 = bld4(rx0, vo0, n0 + 64);
+          if (HAS1) pb1 = bld4(rx1, vo1, n1 + 64);
+        }
+      }
+      for (int u = 0; u < ns0; ++u) {
+        float xs = xs0;
+        if (u > 0) {   // rare: more than one remainder block, fetched in place
+          xs = bld1(rx0, vo0 - 12 * g, o0 + 64 * nv0 + 16 * u);
+          if (HAS1) xs += bld1(rx1, vo1 - 12 * g, o1 + 64 * nv0 + 16 * u);
+        }
+        QUAD1(xs);
+      }
+      // ---- concatenated input segment -------------------------------------
+      for (int v = 0; v < nv2; ++v) {
+        const v4f xv = bld4(rx2, vo2 + 16 * g, o2 + 64 * v);
+        QUAD(xv.x, xv.y, xv.z, xv.w);
+      }
+      for (int u = 0; u < ns2; ++u) {
+        float xs = xs2;
+        if (u > 0) xs = bld1(rx2, vo2 + 4 * g, o2 + 64 * nv2 + 16 * u);
+        QUAD1(xs);
+      }
+      // ---- recurrent part: B operands are last step's D registers ---------
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) QUAD(hold[sp].x, hold[sp].y, hold[sp].z, hold[sp].w);
+      for (int u = 0; u < p.pad; ++u) {   // ring padding: chunk ends == slice ends
+        ws.peek_next(a0, a1);
+        if (ws.advance()) {
+          a0 = ws.record(0);
+          a1 = ws.record(1);
+        }
+      }
+      // blocks 2, 3 of the next slice: requested before this slice's stores
+      if (nv0 > 2) {
+        pc0 = bld4(rx0, vo0, n0 + 128);
+        if (HAS1) pd0 = bld4(rx1, vo1, n1 + 128);
+      }
+      if (nv0 > 3) {
+        pc1 = bld4(rx0, vo0, n0 + 192);
+        if (HAS1) pd1 = bld4(rx1, vo1, n1 + 192);
+      }
+      // ---- cell update (PyTorch gate order i, f, g, o) ----------------------
+      const v4f ig = sigmoid4(acc[0]);
+      const v4f fg = sigmoid4(acc[1]);
+      const v4f gg = tanh4(acc[2]);
+      const v4f og = sigmoid4(acc[3]);
+      const v4f cn = fg * cprev + ig * gg;
+      const v4f hn = og * tanh4(cn);
+      bst4(cn, rc, vlane, s * 1024);
+      if (valid) {
+        bst4(hn, ro, voo, oo + 64 * s);
+        if (SUM) bst4(hn + skipv, ro2, voo2, oo + 64 * s);
+      }
+    }
+  }
+#undef QUAD
+#undef QUAD1
+}
+
+// ---- launcher ----------------------------------------------------------------
+template <int H, int NW, int M, int WMODE, int MODE>
+int launch_k(const LstmParams& p, int nwg, hipStream_t st) {
+  const size_t lds = WMODE ? (size_t)2 * p.chq * 4096 : 0;
+  auto k = lstm_rec_kernel<H, NW, M, WMODE, MODE>;
+  if (lds > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);
+  FNSSL_CHECK_LAUNCH("lstm_rec_kernel");
+  return FNSSL_OK;
+}
+
+template <int H, int NW, int M, int WMODE>
+int launch_t(const LstmParams& p, int mode, int nwg, hipStream_t st) {
+  switch (mode) {
+    case 0: return launch_k<H, NW, M, WMODE, 0>(p, nwg, st);
+    case kHas1: return launch_k<H, NW, M, WMODE, kHas1>(p, nwg, st);
+    case kHas2: return launch_k<H, NW, M, WMODE, kHas2>(p, nwg, st);
+    case kSum: return launch_k<H, NW, M, WMODE, kSum>(p, nwg, st);
+    case kHas2 | kSum: return launch_k<H, NW, M, WMODE, kHas2 | kSum>(p, nwg, st);
+    case kHas1 | kHas2: return launch_k<H, NW, M, WMODE, kHas1 | kHas2>(p, nwg, st);
+  }
+  fnssl::set_error("lstm: input combination %d not built (src1 together with out_sum)", mode);
+  return FNSSL_E_INVALID;
+}
+
+// Launch geometries.  NW = waves per workgroup (all share one weight stream),
+// M = ring records staged per wave per chunk (chunk <= NW*M records), ring 0 = the
+// weight stream is read straight from L1/L2.
+struct Variant {
+  int NW, M, ring;
+};
+constexpr int kNumVariants = 8;
+constexpr Variant kVariants[kNumVariants + 1] = {
+    {0, 0, 0},
+    {4, 1, 0},    // 1
+    {4, 4, 1},    // 2
+    {8, 4, 1},    // 3
+    {12, 4, 1},   // 4
+    {16, 2, 1},   // 5
+    {8, 1, 0},    // 6
+    {12, 2, 1},   // 7
+    {16, 4, 1},   // 8
+};
+
+inline int env_int(const char* name, int lo, int hi) {
+  if (const char* e = getenv(name)) {
+    const int v = atoi(e);
+    if (v >= lo && v <= hi) return v;
+  }
+  return 0;
+}
+
+inline int default_variant(int H) {
+  // tuning override for experiments: FNSSL_LSTM_VARIANT_H256=3 etc.
+  char name[40];
+  snprintf(name, sizeof(name), "FNSSL_LSTM_VARIANT_H%d", H);
+  if (const int v = env_int(name, 1, kNumVariants)) return v;
+  if (H == 256) return 4;
+  if (H == 128) return 5;
+  return 2;
+}
+
+// Ring chunk: the largest chq <= NW*M/4 with (qps + pad) % chq == 0 for a padding
+// pad <= 3 quads (chunk boundaries then coincide with slice ends).
+inline void choose_chunk(int qps, const Variant& v, int& chq, int& pad) {
+  const int cap = v.NW * v.M / 4;
+  int best_c = 1, best_p = 0;
+  for (int p = 0; p <= 3; ++p)
+    for (int c = cap; c >= 1; --c)
+      if ((qps + p) % c == 0) {
+        // prefer fewer commits per slice; break ties towards less padding
+        if (c > best_c) {
+          best_c = c;
+          best_p = p;
+        }
+        break;
+      }
+  chq = best_c;
+  pad = best_p;
+  if (const int f = env_int("FNSSL_LSTM_CHQ", 1, cap)) {   // experiments: force a chunk size
+    chq = f;
+    pad = (f - qps % f) % f;
+  }
+}
+
+template <int H>
+int launch_h(int variant, const LstmParams& p, int mode, int nwg, hipStream_t st) {
+  switch (variant) {
+    case 1: return launch_t<H, 4, 1, 0>(p, mode, nwg, st);
+    case 2: return launch_t<H, 4, 4, 1>(p, mode, nwg, st);
+    case 3: return launch_t<H, 8, 4, 1>(p, mode, nwg, st);
+    case 4: return launch_t<H, 12, 4, 1>(p, mode, nwg, st);
+    case 5: return launch_t<H, 16, 2, 1>(p, mode, nwg, st);
+    case 6: return launch_t<H, 8, 1, 0>(p, mode, nwg, st);
+    case 7: return launch_t<H, 12, 2, 1>(p, mode, nwg, st);
+    case 8: return launch_t<H, 16, 4, 1>(p, mode, nwg, st);
+  }
+  fnssl::set_error("lstm: unknown variant %d", variant);
+  return FNSSL_E_INVALID;
+}
+
+
+}  // namespace fnssl_lstm

@@ -41,6 +41,7 @@ class LstmDesc(C.Structure):
         ("c0", C.c_int), ("c2", C.c_int),
         ("out", C.c_void_p),
         ("out_so", C.c_longlong), ("out_si", C.c_longlong), ("out_st", C.c_longlong),
+        ("skip", View), ("out_sum", C.c_void_p),
         ("hidden", C.c_int), ("ndir", C.c_int), ("nseq", C.c_int), ("q_inner", C.c_int), ("nsteps", C.c_int),
         ("wpack", C.c_void_p * 2),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),

@@ -177,15 +177,17 @@ def release_workspaces():
     _ws_cache.clear()
 
 
-def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0):
+def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None):
     """One (bi)LSTM layer over strided views.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
     x0 (+ x1) is the summed input, x2 the concatenated one (either may be None); all are logical
     [nb, nt, nf, C] tensors with arbitrary strides.  ``packed`` is a list of 1 or 2 device weight
     streams; ``out`` a logical [nb, nt, nf, ndir*hidden] tensor (any strides) that is written in place.
+    With ``skip``/``out_sum`` (both logical [nb, nt, nf, ndir*hidden]; out_sum with out's strides) the
+    kernel also stores out_sum = h + skip, i.e. the next layer's residual input.
     """
-    _need_dev(x0, x1, x2, out, *packed)
+    _need_dev(x0, x1, x2, out, skip, out_sum, *packed)
     if mode not in ("full", "narrow"):
         raise RuntimeError("fnssl.lstm_layer: mode must be 'full' or 'narrow'")
     ref = x0 if x0 is not None else x2
@@ -209,6 +211,14 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
         d.c2 = x2.shape[3]
     ov = _view(out, mode)
     d.out, d.out_so, d.out_si, d.out_st = ov.p, ov.so, ov.si, ov.st
+    if (skip is None) != (out_sum is None):
+        raise RuntimeError("fnssl.lstm_layer: skip and out_sum go together")
+    if out_sum is not None:
+        if out_sum.shape != out.shape or out_sum.stride() != out.stride() or skip.shape != out.shape:
+            raise RuntimeError("fnssl.lstm_layer: out_sum must have out's shape and strides, skip out's shape")
+        skip = _conform(skip)
+        d.skip = _view(skip, mode)
+        d.out_sum = out_sum.data_ptr()
     d.hidden, d.ndir = hidden, ndir
     d.nseq = nb * (nt if mode == "full" else nf)
     d.q_inner = nt if mode == "full" else nf

@@ -118,6 +118,11 @@ typedef struct {
   /* output h, written at channel offset dir * hidden (bi-dir: [fwd || bwd]) */
   float* out;
   long long out_so, out_si, out_st;
+  /* optional fused residual for the NEXT layer: out_sum = h + skip, same strides as
+   * out; skip is read at the output's channels (Model.py:36-37,44-45 done one kernel
+   * early).  Both NULL to disable; not combinable with src1.                      */
+  fnssl_view skip;
+  float* out_sum;
   int hidden;          /* H: 16, 32, 64, 128 or 256                           */
   int ndir;            /* 1 = forward only, 2 = bidirectional                 */
   int nseq;            /* number of sequences                                 */

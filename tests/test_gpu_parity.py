@@ -198,6 +198,26 @@ def test_lstm_strided_views_and_ragged_tail(dev):
     assert_close(buf.cpu().numpy(), want, RTOL, ATOL, "narrow layout output")
 
 
+def test_lstm_fused_residual_output(dev):
+    """out_sum = h + skip (the next layer's residual input) is exactly the separate add."""
+    from fnssl import ops
+    for mode, H, bidir in (("narrow", 256, False), ("full", 128, True), ("narrow", 32, True)):
+        nb, nt, nf = 2, 7, 19
+        c0 = 256 if H > 32 else 32
+        sd = lstm_state(c0, H, bidir, 91)
+        w = packed_dirs(sd, c0, 0, bidir, dev)
+        x = to_dev(rs_randn(92, (nb, nt, nf, c0)), dev)
+        ndir = 2 if bidir else 1
+        skip = to_dev(rs_randn(93, (nb, nt, nf, ndir * H)), dev)
+        plain = torch.empty((nb, nt, nf, ndir * H), device=dev)
+        ops.lstm_layer(mode, x, None, None, w, H, plain)
+        out = torch.full_like(plain, float("nan"))
+        osum = torch.full_like(plain, float("nan"))
+        ops.lstm_layer(mode, x, None, None, w, H, out, skip=skip, out_sum=osum)
+        assert torch.equal(out, plain)
+        assert torch.equal(osum, plain + skip)
+
+
 def test_lstm_rejects_bad_descriptors(dev):
     from fnssl import ops
     sd = lstm_state(16, 32, False, 5)

@@ -166,6 +166,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
   p.chq = 0;
   p.pad = 0;
+  p.ablate = env_int("FNSSL_ABLATE", 1, 63);
   if (vr.ring) choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
   const int tasks = (d->nseq + 15) / 16;
   p.wgs_per_dir = (tasks + vr.NW - 1) / vr.NW;

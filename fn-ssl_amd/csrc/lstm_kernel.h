@@ -30,6 +30,7 @@ struct LstmParams {
   int wgs_per_dir;
   int quads_per_slice;
   int chq, pad;   // ring chunk (quads) and per-slice padding (quads); 0 for direct variants
+  int ablate;     // timing experiments only (env FNSSL_ABLATE): bit flags, see lstm_rec_kernel
 };
 
 // kernel MODE bits
@@ -59,6 +60,11 @@ __device__ __forceinline__ v4f sigmoid4(v4f a) {
 }
 __device__ __forceinline__ v4f tanh4(v4f a) {
   return v4f{tanh_f(a.x), tanh_f(a.y), tanh_f(a.z), tanh_f(a.w)};
+}
+
+// h + skip with the reference's rounding (the rounded h is what gets added): no fma contraction
+__device__ __forceinline__ v4f add_rn4(v4f a, v4f b) {
+  return v4f{__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w)};
 }
 
 #define MFMA4(ACC, AV, BV)                                                          \
@@ -122,6 +128,7 @@ struct WStream<NW, M, 0> {
   unsigned vlane;
   unsigned cur;   // byte offset of the current quad in the stream
   unsigned bytes_per_step;
+  bool nobar;
   __device__ __forceinline__ void init(const float* wp, int lane, int /*w*/, int qps, int nslices, int /*chq*/,
                                        int /*pad*/, char* /*smem*/) {
     rw = make_rsrc(wp);
@@ -163,6 +170,7 @@ struct WStream<NW, M, 1> {
   int rq;               // quad index inside the ring, 0 .. 2*chq-1
   int left;             // quads left in the current chunk
   int wslot;
+  bool nobar;
   v4f stg[M];
 
   __device__ __forceinline__ void issue_loads() {
@@ -185,7 +193,10 @@ struct WStream<NW, M, 1> {
       if (w + m * NW < ch) *reinterpret_cast<v4f*>(lds_wr + wslot * (ch * 1024) + m * (NW * 1024)) = stg[m];
     wslot ^= 1;
     // my ring writes have landed and my reads of the previous chunk have returned
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nobar)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   __device__ __forceinline__ void init(const float* wp, int lane, int w_, int qps, int nslices, int chq_, int pad,
                                        char* smem) {
@@ -229,7 +240,10 @@ struct WStream<NW, M, 1> {
   }
 };
 
-template <int H, int NW, int M, int WMODE, int MODE>
+// ABL = true builds the timing-ablation twin (FNSSL_ABLATE bits: 1 no x loads, 2 no gate
+// transcendentals, 4 no c/h stores, 8 no ring barrier, 16 no c load, 32 no h reload); its
+// results are wrong by construction and it is never used unless the env var is set.
+template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false>
 __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   constexpr int NS = H / 16;
   constexpr bool HAS1 = (MODE & kHas1) != 0, HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
@@ -265,7 +279,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   const int nv2 = HAS2 ? p.c2 >> 4 : 0, ns2 = HAS2 ? (p.c2 & 15) >> 2 : 0;
   const bool rev = dir == 1;
 
+  const int abl = ABL ? p.ablate : 0;
   WStream<NW, M, WMODE> ws;
+  ws.nobar = ABL && (abl & 8);
   ws.init(p.wpack[dir], lane, w, p.quads_per_slice, NS, p.chq, p.pad, smem);
   v4f a0 = ws.record(0), a1 = ws.record(1);   // A operands of the current quad's first half
 
@@ -341,7 +357,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       if (HAS1) xs0 += bld1(rx1, vo1 - 12 * g, o1 + 64 * nv0);
     }
     if (HAS2 && ns2 > 0) xs2 = bld1(rx2, vo2 + 4 * g, o2 + 64 * nv2);
-    if (step > 0) {
+    if (step > 0 && !(abl & 32)) {
       // h_{t-1}: each lane re-reads exactly the float4s it stored one step ago
       const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
 #pragma unroll
@@ -350,7 +366,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
 
     for (int s = 0; s < NS; ++s) {
       v4f cprev = zero4, skipv = zero4;
-      if (step > 0) cprev = bld4(rc, vlane, s * 1024);
+      if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
       if (SUM) skipv = bld4(rsk, vok, ok + 64 * s);
       v4f xc0 = HAS1 ? pa0 + pb0 : pa0;   // blocks 0, 1: issued during the previous slice
       v4f xc1 = HAS1 ? pa1 + pb1 : pa1;
@@ -379,11 +395,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         if (v + 2 < nv0) {
           xc0 = HAS1 ? pa0 + pb0 : pa0;
           xc1 = HAS1 ? pa1 + pb1 : pa1;
-          if (v + 4 < nv0) {
+          if (v + 4 < nv0 && !(abl & 1)) {
             pa0 = bld4(rx0, vo0, o0 + 64 * (v + 4));
             if (HAS1) pb0 = bld4(rx1, vo1, o1 + 64 * (v + 4));
           }
-          if (v + 5 < nv0) {
+          if (v + 5 < nv0 && !(abl & 1)) {
             pa1 = bld4(rx0, vo0, o0 + 64 * (v + 5));
             if (HAS1) pb1 = bld4(rx1, vo1, o1 + 64 * (v + 5));
           }
@@ -393,11 +409,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       const unsigned n1 = (s + 1 < NS ? tt : ttn) * st1;
       {
         // blocks 0, 1 of the next slice (same x_t) or of the next step
-        if (nv0 > 0) {
+        if (nv0 > 0 && !(abl & 1)) {
           pa0 = bld4(rx0, vo0, n0);
           if (HAS1) pb0 = bld4(rx1, vo1, n1);
         }
-        if (nv0 > 1) {
+        if (nv0 > 1 && !(abl & 1)) {
           pa1 = bld4(rx0, vo0, n0 + 64);
           if (HAS1) pb1 = bld4(rx1, vo1, n1 + 64);
         }
@@ -431,25 +447,35 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         }
       }
       // blocks 2, 3 of the next slice: requested before this slice's stores
-      if (nv0 > 2) {
+      if (nv0 > 2 && !(abl & 1)) {
         pc0 = bld4(rx0, vo0, n0 + 128);
         if (HAS1) pd0 = bld4(rx1, vo1, n1 + 128);
       }
-      if (nv0 > 3) {
+      if (nv0 > 3 && !(abl & 1)) {
         pc1 = bld4(rx0, vo0, n0 + 192);
         if (HAS1) pd1 = bld4(rx1, vo1, n1 + 192);
       }
       // ---- cell update (PyTorch gate order i, f, g, o) ----------------------
-      const v4f ig = sigmoid4(acc[0]);
-      const v4f fg = sigmoid4(acc[1]);
-      const v4f gg = tanh4(acc[2]);
-      const v4f og = sigmoid4(acc[3]);
-      const v4f cn = fg * cprev + ig * gg;
-      const v4f hn = og * tanh4(cn);
-      bst4(cn, rc, vlane, s * 1024);
-      if (valid) {
-        bst4(hn, ro, voo, oo + 64 * s);
-        if (SUM) bst4(hn + skipv, ro2, voo2, oo + 64 * s);
+      v4f cn, hn;
+      if (ABL && (abl & 2)) {
+        cn = acc[1] + cprev + acc[0];
+        hn = acc[3] + acc[2];
+      } else {
+        const v4f ig = sigmoid4(acc[0]);
+        const v4f fg = sigmoid4(acc[1]);
+        const v4f gg = tanh4(acc[2]);
+        const v4f og = sigmoid4(acc[3]);
+        cn = fg * cprev + ig * gg;
+        hn = og * tanh4(cn);
+      }
+      if (!(abl & 4)) {
+        bst4(cn, rc, vlane, s * 1024);
+        if (valid) {
+          bst4(hn, ro, voo, oo + 64 * s);
+          if (SUM) bst4(add_rn4(hn, skipv), ro2, voo2, oo + 64 * s);
+        }
+      } else {
+        asm volatile("" ::"v"(cn), "v"(hn));
       }
     }
   }
@@ -458,10 +484,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
 }
 
 // ---- launcher ----------------------------------------------------------------
-template <int H, int NW, int M, int WMODE, int MODE>
+template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false>
 int launch_k(const LstmParams& p, int nwg, hipStream_t st) {
   const size_t lds = WMODE ? (size_t)2 * p.chq * 4096 : 0;
-  auto k = lstm_rec_kernel<H, NW, M, WMODE, MODE>;
+  auto k = lstm_rec_kernel<H, NW, M, WMODE, MODE, ABL>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -476,7 +502,11 @@ int launch_t(const LstmParams& p, int mode, int nwg, hipStream_t st) {
     case 0: return launch_k<H, NW, M, WMODE, 0>(p, nwg, st);
     case kHas1: return launch_k<H, NW, M, WMODE, kHas1>(p, nwg, st);
     case kHas2: return launch_k<H, NW, M, WMODE, kHas2>(p, nwg, st);
-    case kSum: return launch_k<H, NW, M, WMODE, kSum>(p, nwg, st);
+    case kSum:
+      if constexpr (H >= 128 && WMODE == 1 && ((NW == 12 && M == 4) || (NW == 16 && M == 2))) {
+        if (p.ablate) return launch_k<H, NW, M, WMODE, kSum, true>(p, nwg, st);
+      }
+      return launch_k<H, NW, M, WMODE, kSum>(p, nwg, st);
     case kHas2 | kSum: return launch_k<H, NW, M, WMODE, kHas2 | kSum>(p, nwg, st);
     case kHas1 | kHas2: return launch_k<H, NW, M, WMODE, kHas1 | kHas2>(p, nwg, st);
   }

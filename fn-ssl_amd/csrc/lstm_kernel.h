@@ -48,12 +48,14 @@ __host__ __device__ inline int quads_per_slice(int c0, int c2, int H) {
   return 1 + (c0 >> 4) + ((c0 & 15) >> 2) + (c2 >> 4) + ((c2 & 15) >> 2) + (H >> 4);
 }
 
+// Gate math with every rounding spelled out (no compiler-chosen fma contraction), so that all
+// kernel instantiations produce bit-identical results.
 __device__ __forceinline__ float sigmoid_f(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+  return __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-x)));
 }
 __device__ __forceinline__ float tanh_f(float x) {
   // 1 - 2/(e^{2x}+1): saturates cleanly at +-1, abs error ~1e-7
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+  return __fmaf_rn(-2.0f, __builtin_amdgcn_rcpf(__fadd_rn(__expf(2.0f * x), 1.0f)), 1.0f);
 }
 __device__ __forceinline__ v4f sigmoid4(v4f a) {
   return v4f{sigmoid_f(a.x), sigmoid_f(a.y), sigmoid_f(a.z), sigmoid_f(a.w)};
@@ -62,6 +64,13 @@ __device__ __forceinline__ v4f tanh4(v4f a) {
   return v4f{tanh_f(a.x), tanh_f(a.y), tanh_f(a.z), tanh_f(a.w)};
 }
 
+__device__ __forceinline__ v4f cell4(v4f f, v4f c, v4f i, v4f g) {   // f*c + i*g, i*g rounded first
+  return v4f{__fmaf_rn(f.x, c.x, __fmul_rn(i.x, g.x)), __fmaf_rn(f.y, c.y, __fmul_rn(i.y, g.y)),
+             __fmaf_rn(f.z, c.z, __fmul_rn(i.z, g.z)), __fmaf_rn(f.w, c.w, __fmul_rn(i.w, g.w))};
+}
+__device__ __forceinline__ v4f mul_rn4(v4f a, v4f b) {
+  return v4f{__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z), __fmul_rn(a.w, b.w)};
+}
 // h + skip with the reference's rounding (the rounded h is what gets added): no fma contraction
 __device__ __forceinline__ v4f add_rn4(v4f a, v4f b) {
   return v4f{__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w)};
@@ -368,8 +377,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       v4f cprev = zero4, skipv = zero4;
       if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
       if (SUM) skipv = bld4(rsk, vok, ok + 64 * s);
-      v4f xc0 = HAS1 ? pa0 + pb0 : pa0;   // blocks 0, 1: issued during the previous slice
-      v4f xc1 = HAS1 ? pa1 + pb1 : pa1;
+      v4f xc0 = HAS1 ? add_rn4(pa0, pb0) : pa0;   // blocks 0, 1: issued during the previous slice
+      v4f xc1 = HAS1 ? add_rn4(pa1, pb1) : pa1;
       pa0 = pc0;                           // blocks 2, 3: issued before the previous cell update,
       pa1 = pc1;                           // i.e. ahead of its stores in the in-order vmcnt queue
       if (HAS1) {
@@ -393,8 +402,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         QUAD(xc0.x, xc0.y, xc0.z, xc0.w);
         if (v + 1 < nv0) QUAD(xc1.x, xc1.y, xc1.z, xc1.w);
         if (v + 2 < nv0) {
-          xc0 = HAS1 ? pa0 + pb0 : pa0;
-          xc1 = HAS1 ? pa1 + pb1 : pa1;
+          xc0 = HAS1 ? add_rn4(pa0, pb0) : pa0;
+          xc1 = HAS1 ? add_rn4(pa1, pb1) : pa1;
           if (v + 4 < nv0 && !(abl & 1)) {
             pa0 = bld4(rx0, vo0, o0 + 64 * (v + 4));
             if (HAS1) pb0 = bld4(rx1, vo1, o1 + 64 * (v + 4));
@@ -465,8 +474,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         const v4f fg = sigmoid4(acc[1]);
         const v4f gg = tanh4(acc[2]);
         const v4f og = sigmoid4(acc[3]);
-        cn = fg * cprev + ig * gg;
-        hn = og * tanh4(cn);
+        cn = cell4(fg, cprev, ig, gg);
+        hn = mul_rn4(og, tanh4(cn));
       }
       if (!(abl & 4)) {
         bst4(cn, rc, vlane, s * 1024);

@@ -214,8 +214,8 @@ def test_lstm_fused_residual_output(dev):
         out = torch.full_like(plain, float("nan"))
         osum = torch.full_like(plain, float("nan"))
         ops.lstm_layer(mode, x, None, None, w, H, out, skip=skip, out_sum=osum)
-        assert torch.equal(out, plain)
-        assert torch.equal(osum, plain + skip)
+        assert torch.equal(out, plain), "raw output changed: max diff %g" % float((out - plain).abs().max())
+        assert torch.equal(osum, plain + skip), "sum output: max diff %g" % float((osum - plain - skip).abs().max())
 
 
 def test_lstm_rejects_bad_descriptors(dev):
@@ -290,7 +290,7 @@ def test_fnssl_block_by_block_equals_fused(dev):
     y, fb, nbs = net.block_2(y, fb_skip=fb, nb_skip=nbs)
     y, fb, nbs = net.block_3(y, fb_skip=fb, nb_skip=nbs)
     out = ops.head(y.permute(0, 2, 1, 3), net.emb2ipd.weight.detach(), net.emb2ipd.bias.detach())
-    assert torch.equal(out, fused)
+    assert torch.equal(out, fused), "max diff %g" % float((out - fused).abs().max())
 
 
 def test_fnssl_requires_eval_and_device(dev):

@@ -9,6 +9,11 @@
 
 #include "common.h"
 
+// HIP's __fadd_rn/__fmul_rn inline to plain fadd/fmul, which clang would still contract into
+// fma; every fused multiply-add in this file is written explicitly (__fmaf_rn), so turn the
+// implicit contraction off for the whole translation unit.
+#pragma clang fp contract(off)
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace fnssl_lstm {
@@ -476,6 +481,9 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         const v4f og = sigmoid4(acc[3]);
         cn = cell4(fg, cprev, ig, gg);
         hn = mul_rn4(og, tanh4(cn));
+        // make the rounded h opaque: h + skip below must add the ROUNDED h (what the reference
+        // adds), not become fma(o, tanh c, skip)
+        asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));
       }
       if (!(abl & 4)) {
         bst4(cn, rc, vlane, s * 1024);

@@ -22,7 +22,7 @@
 
 #include "common.h"
 
-#include "lstm_kernel.h"
+#include "lstm_static.h"
 
 using namespace fnssl_lstm;
 
@@ -140,10 +140,6 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     fnssl::set_error("lstm_forward: workspace %zu < %zu bytes", d->workspace_bytes, need);
     return FNSSL_E_WORKSPACE;
   }
-  const int variant = d->variant ? d->variant : default_variant(H);
-  FNSSL_REQUIRE(variant >= 1 && variant <= kNumVariants, "lstm_forward: unknown variant %d", variant);
-  const Variant& vr = kVariants[variant];
-
   LstmParams p;
   p.src0 = View{d->src0.p, d->src0.so, d->src0.si, d->src0.st};
   p.src1 = View{d->src1.p, d->src1.so, d->src1.si, d->src1.st};
@@ -164,13 +160,8 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.nsteps = d->nsteps;
   p.ndir = d->ndir;
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
-  p.chq = 0;
-  p.pad = 0;
   p.ablate = env_int("FNSSL_ABLATE", 1, 63);
-  if (vr.ring) choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
   const int tasks = (d->nseq + 15) / 16;
-  p.wgs_per_dir = (tasks + vr.NW - 1) / vr.NW;
-  const int nwg = p.wgs_per_dir * d->ndir;
   const int mode = ((d->src1.p != nullptr && d->c0 > 0) ? kHas1 : 0) | (d->c2 > 0 ? kHas2 : 0) |
                    (d->out_sum ? kSum : 0);
 
@@ -179,13 +170,79 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   const int hi = H == 16 ? 0 : H == 32 ? 1 : H == 64 ? 2 : H == 128 ? 3 : 4;
   fnssl::TimedLaunch tl(names[hi], fnssl::as_stream(stream), flops);
   hipStream_t st = fnssl::as_stream(stream);
-  switch (H) {
-    case 16: return launch_h<16>(variant, p, mode, nwg, st);
-    case 32: return launch_h<32>(variant, p, mode, nwg, st);
-    case 64: return launch_h<64>(variant, p, mode, nwg, st);
-    case 128: return launch_h<128>(variant, p, mode, nwg, st);
-    default: return launch_h<256>(variant, p, mode, nwg, st);
+
+  // one launch of `nw` waves per workgroup over the 16-sequence groups [t0, t1) of every direction
+  auto launch_range = [&](int variant, int t0, int t1) -> int {
+    const Variant& vr = kVariants[variant];
+    p.task0 = t0;
+    p.task1 = t1;
+    p.wgs_per_dir = (t1 - t0 + vr.NW - 1) / vr.NW;
+    const int nwg = p.wgs_per_dir * d->ndir;
+    if (d->variant == 0 && !p.ablate && !env_int("FNSSL_LSTM_NO_STATIC", 1, 1)) {
+      int rc = kNoStatic;
+      if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
+      if (H == 256) rc = launch_static_h256(p, mode, vr.NW, nwg, st);
+      if (rc != kNoStatic) return rc;
+    }
+    p.chq = 0;
+    p.pad = 0;
+    if (vr.ring) choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
+    switch (H) {
+      case 16: return launch_h<16>(variant, p, mode, nwg, st);
+      case 32: return launch_h<32>(variant, p, mode, nwg, st);
+      case 64: return launch_h<64>(variant, p, mode, nwg, st);
+      case 128: return launch_h<128>(variant, p, mode, nwg, st);
+      default: return launch_h<256>(variant, p, mode, nwg, st);
+    }
+  };
+
+  if (d->variant != 0 || H < 128) {
+    const int variant = d->variant ? d->variant : default_variant(H);
+    FNSSL_REQUIRE(variant >= 1 && variant <= kNumVariants, "lstm_forward: unknown variant %d", variant);
+    return launch_range(variant, 0, tasks);
   }
+  if (const int forced = default_variant_override(H)) return launch_range(forced, 0, tasks);
+
+  // ---- launch planner ---------------------------------------------------------------
+  // Every wave does the same work, so a launch runs at the pace of its fullest CU.  Split the
+  // per-CU wave count W = ceil(total groups / CUs) into the fewest rounds of <= wmax waves and
+  // make the rounds as even as possible (config 2, full-band: 7200 groups -> 29 waves per CU ->
+  // rounds of 15 + 14 instead of 16 + 16).  Supported wave counts: the ring variants below.
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  struct Sup {
+    int nw, variant;
+  };
+  static const Sup sup128[] = {{4, 2}, {8, 3}, {12, 4}, {13, 9}, {14, 10}, {15, 11}, {16, 5}};
+  static const Sup sup256[] = {{4, 2}, {8, 3}, {12, 4}};
+  const Sup* sup = H == 128 ? sup128 : sup256;
+  const int nsup = H == 128 ? 7 : 3;
+  const int wmax = sup[nsup - 1].nw;
+  auto pick = [&](int want) {   // smallest supported wave count >= want
+    for (int i = 0; i < nsup; ++i)
+      if (sup[i].nw >= want) return sup[i];
+    return sup[nsup - 1];
+  };
+  const long long total = (long long)tasks * d->ndir;
+  const int W = (int)((total + ncu - 1) / ncu);            // waves per CU if spread evenly
+  const int rounds = (W + wmax - 1) / wmax;
+  const int wgs_per_dir_round = ncu / d->ndir > 0 ? ncu / d->ndir : 1;
+  int t0 = 0;
+  for (int r = 0; r < rounds && t0 < tasks; ++r) {
+    const int left_rounds = rounds - r;
+    const long long left_total = (long long)(tasks - t0) * d->ndir;
+    const int want = (int)(((left_total + ncu - 1) / ncu + left_rounds - 1) / left_rounds);
+    const Sup s = pick(want);
+    int t1 = r + 1 == rounds ? tasks : t0 + wgs_per_dir_round * s.nw;
+    if (t1 > tasks) t1 = tasks;
+    const int rc = launch_range(s.variant, t0, t1);
+    if (rc != FNSSL_OK) return rc;
+    t0 = t1;
+  }
+  return FNSSL_OK;
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -33,6 +34,7 @@ struct LstmParams {
   int c0, c2;
   int nseq, q_inner, nsteps, ndir;
   int wgs_per_dir;
+  int task0, task1;   // this launch covers 16-sequence groups [task0, task1) of every direction
   int quads_per_slice;
   int chq, pad;   // ring chunk (quads) and per-slice padding (quads); 0 for direct variants
   int ablate;     // timing experiments only (env FNSSL_ABLATE): bit flags, see lstm_rec_kernel
@@ -268,10 +270,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int dir = blockIdx.x / p.wgs_per_dir;
   const int wg = blockIdx.x - dir * p.wgs_per_dir;
-  const int task = wg * NW + w;
+  const int task = p.task0 + wg * NW + w;
   int q = task * 16 + n;
-  const bool valid = q < p.nseq;
-  if (!valid) q = p.nseq - 1;
+  const bool valid = q < p.nseq && task < p.task1;
+  if (q >= p.nseq) q = p.nseq - 1;
   const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
 
   unsigned vo0 = 0, vo1 = 0, vo2 = 0, voo = 0, vok = 0;
@@ -537,7 +539,7 @@ int launch_t(const LstmParams& p, int mode, int nwg, hipStream_t st) {
 struct Variant {
   int NW, M, ring;
 };
-constexpr int kNumVariants = 8;
+constexpr int kNumVariants = 11;
 constexpr Variant kVariants[kNumVariants + 1] = {
     {0, 0, 0},
     {4, 1, 0},    // 1
@@ -548,6 +550,9 @@ constexpr Variant kVariants[kNumVariants + 1] = {
     {8, 1, 0},    // 6
     {12, 2, 1},   // 7
     {16, 4, 1},   // 8
+    {13, 2, 1},   // 9   (odd sizes: per-round wave counts of the launch planner)
+    {14, 2, 1},   // 10
+    {15, 2, 1},   // 11
 };
 
 inline int env_int(const char* name, int lo, int hi) {
@@ -558,11 +563,15 @@ inline int env_int(const char* name, int lo, int hi) {
   return 0;
 }
 
-inline int default_variant(int H) {
-  // tuning override for experiments: FNSSL_LSTM_VARIANT_H256=3 etc.
+// tuning override for experiments: FNSSL_LSTM_VARIANT_H256=3 etc. (0 = none)
+inline int default_variant_override(int H) {
   char name[40];
   snprintf(name, sizeof(name), "FNSSL_LSTM_VARIANT_H%d", H);
-  if (const int v = env_int(name, 1, kNumVariants)) return v;
+  return env_int(name, 1, kNumVariants);
+}
+
+inline int default_variant(int H) {
+  if (const int v = default_variant_override(H)) return v;
   if (H == 256) return 4;
   if (H == 128) return 5;
   return 2;
@@ -602,6 +611,9 @@ int launch_h(int variant, const LstmParams& p, int mode, int nwg, hipStream_t st
     case 6: return launch_t<H, 8, 1, 0>(p, mode, nwg, st);
     case 7: return launch_t<H, 12, 2, 1>(p, mode, nwg, st);
     case 8: return launch_t<H, 16, 4, 1>(p, mode, nwg, st);
+    case 9: return launch_t<H, 13, 2, 1>(p, mode, nwg, st);
+    case 10: return launch_t<H, 14, 2, 1>(p, mode, nwg, st);
+    case 11: return launch_t<H, 15, 2, 1>(p, mode, nwg, st);
   }
   fnssl::set_error("lstm: unknown variant %d", variant);
   return FNSSL_E_INVALID;

@@ -1,0 +1,29 @@
+// Shape-specialised LSTM kernels, hidden size 128 (full-band BiLSTM of every block and the
+// offline narrow-band BiLSTM).  See lstm_static.h.
+#include "lstm_static.h"
+
+namespace fnssl_lstm {
+
+#define TRY(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_)                                              \
+  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                  \
+    return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_>(p, nwg, st);
+
+int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st) {
+  // block 1 full-band: 4 input channels, 10 quads per slice
+  TRY(16, 2, 0, 1, 0, 5, 0, 0)
+  TRY(15, 2, 0, 1, 0, 5, 0, 0)
+  TRY(14, 2, 0, 1, 0, 5, 0, 0)
+  TRY(13, 2, 0, 1, 0, 5, 0, 0)
+  // blocks 2/3 full-band (and offline narrow-band 2/3): 256 channels, 25 quads (+3 pad = 4 x 7)
+  TRY(16, 2, 16, 0, 0, 7, 3, kSum)
+  TRY(15, 2, 16, 0, 0, 7, 3, kSum)
+  TRY(14, 2, 16, 0, 0, 7, 3, kSum)
+  TRY(16, 2, 16, 0, 0, 7, 3, 0)
+  TRY(15, 2, 16, 0, 0, 7, 3, 0)
+  TRY(14, 2, 16, 0, 0, 7, 3, 0)
+  // offline narrow-band block 1: 256 + 4 channels, 26 quads (+2 pad = 4 x 7)
+  TRY(16, 2, 16, 0, 1, 7, 2, kHas2 | kSum)
+  return kNoStatic;
+}
+
+}  // namespace fnssl_lstm

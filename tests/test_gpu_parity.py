@@ -218,6 +218,37 @@ def test_lstm_fused_residual_output(dev):
         assert torch.equal(osum, plain + skip), "sum output: max diff %g" % float((osum - plain - skip).abs().max())
 
 
+def test_launch_planner_and_static_kernels_match_generic(dev):
+    """variant 0 = launch planner (uneven multi-round wave counts) + shape-specialised kernels;
+    it must be bit-identical to an explicit generic variant."""
+    from fnssl import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    # (mode, H, bidir, c0, c2, nb, nt, nf, with residual output)
+    cases = [("full", 128, True, 256, 0, 1, 33000, 3, True),     # 2063 groups x 2 dirs -> 17 waves/CU -> rounds 9(12) + ...
+             ("full", 128, True, 4, 0, 1, 40000, 3, False),
+             ("narrow", 256, False, 256, 0, 3, 5, 1000, True),
+             ("narrow", 256, False, 256, 4, 3, 5, 1000, True),
+             ("narrow", 128, True, 256, 4, 1, 4, 700, True)]
+    for mode, H, bidir, c0, c2, nb, nt, nf, with_sum in cases:
+        sd = lstm_state(c0 + c2, H, bidir, 300 + c0 + c2 + H)
+        w = packed_dirs(sd, c0, c2, bidir, dev)
+        ndir = 2 if bidir else 1
+        x0 = torch.randn((nb, nt, nf, c0), generator=g, device=dev)
+        x2 = torch.randn((nb, nt, nf, c2), generator=g, device=dev) if c2 else None
+        skip = torch.randn((nb, nt, nf, ndir * H), generator=g, device=dev) if with_sum else None
+        outs = []
+        for variant in (0, 5 if H == 128 else 4):
+            out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+            osum = torch.full_like(out, float("nan")) if with_sum else None
+            ops.lstm_layer(mode, x0, None, x2, w, H, out, variant, skip=skip, out_sum=osum)
+            outs.append((out, osum))
+        assert not torch.isnan(outs[0][0]).any(), (mode, H, c0, c2)
+        assert torch.equal(outs[0][0], outs[1][0]), (mode, H, c0, c2)
+        if with_sum:
+            assert torch.equal(outs[0][1], outs[1][1]), (mode, H, c0, c2)
+
+
 def test_lstm_rejects_bad_descriptors(dev):
     from fnssl import ops
     sd = lstm_state(16, 32, False, 5)

@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=192)
     ap.add_argument("--nt", type=int, default=300)
     ap.add_argument("--nf", type=int, default=256)
-    ap.add_argument("--variants", default="1,2,3,4,5,6,7,8")
+    ap.add_argument("--variants", default="0,4,5,8")
     ap.add_argument("--layers", default="narrow256s,full128s,narrow256_first,full128_first,narrow256,full128")
     ap.add_argument("--reps", type=int, default=2)
     args = ap.parse_args()

@@ -134,12 +134,17 @@ def main():
 
     # ---- roofline of the dominant kernel (narrow-band LSTM, H = 256) ------------------
     roof = None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_lstm_h256.json")
+    if os.path.exists(tpath):       # PMC passes cannot run inside the timed region: measured by rocprofv3, committed
+        with open(tpath) as f:
+            traffic = json.load(f).get("bytes_per_launch")
     dom = kern.get("lstm_h256")
     if dom and dom["ms"] > 0:
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "lstm_rec_kernel<H=256> (narrow-band LSTM)",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "launches": dom["count"], "avg_ms": round(dom["ms"] / max(1, dom["count"]), 3),
                 "flop_per_launch": dom["flops"] / max(1, dom["count"])}
     breakdown = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["count"] / args.steps,

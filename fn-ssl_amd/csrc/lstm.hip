@@ -178,7 +178,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     p.task1 = t1;
     p.wgs_per_dir = (t1 - t0 + vr.NW - 1) / vr.NW;
     const int nwg = p.wgs_per_dir * d->ndir;
-    if (d->variant == 0 && !p.ablate && !env_int("FNSSL_LSTM_NO_STATIC", 1, 1)) {
+    if (d->variant == 0 && !env_int("FNSSL_LSTM_NO_STATIC", 1, 1)) {
       int rc = kNoStatic;
       if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
       if (H == 256) rc = launch_static_h256(p, mode, vr.NW, nwg, st);

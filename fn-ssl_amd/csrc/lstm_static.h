@@ -30,7 +30,8 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE>
+// ABL = true: timing-ablation twin driven by FNSSL_ABLATE (bits as in lstm_rec_kernel); wrong results.
+template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false>
 __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p) {
   constexpr int NS = H / 16;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   const unsigned sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
   const unsigned vlane = lane * 16;
   const bool rev = dir == 1;
+  const int abl = ABL ? p.ablate : 0;
   if (NS0) vo0 -= 12 * g;   // remainder-only input: lane (n, g) reads channel g, not 4g..4g+3
 
   // ---- weight ring ---------------------------------------------------------------
@@ -93,15 +95,25 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       if (src_rec == NS * QPS * 4) src_rec = 0;
     }
   };
-  auto commit = [&]() {
+  // The staged chunk goes to the slot that was read during the PREVIOUS chunk period, which is
+  // free for the whole current period, so the wait-for-data + ds_write sits in the middle of the
+  // chunk (where waves are not lined up at a barrier and the in-order vmcnt wait costs least)
+  // and the chunk end is only `lgkmcnt(0); s_barrier`.
+  auto stage_write = [&]() {
 #pragma unroll
     for (int m = 0; m < M; ++m)
       if (w + m * NW < CH) *reinterpret_cast<v4f*>(lds_wr + wslot * (CH * 1024) + m * (NW * 1024)) = stg[m];
     wslot ^= 1;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  auto sync = [&]() {
+    if (ABL && (abl & 8))
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   issue_loads();
-  commit();
+  stage_write();
+  sync();
   issue_loads();
   const char* cb = lds_rd;                      // base of the chunk being read
   auto rec = [&](auto ql, int j) {              // record j of quad ql (compile time) of the current chunk
@@ -126,8 +138,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   };
   auto ring_end = [&](auto qi_c) {
     constexpr int QL = decltype(qi_c)::value % CHQ;
+    if constexpr (QL + 1 == (CHQ + 1) / 2 && CHQ > 1) stage_write();
     if constexpr (QL + 1 == CHQ) {
-      commit();
+      if constexpr (CHQ == 1) stage_write();
+      sync();
       issue_loads();
       rslot ^= 1;
       cb = lds_rd + rslot * (CH * 1024);
@@ -168,7 +182,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
     float xs0 = 0.f, xs2 = 0.f;
     if (NS0) xs0 = bld1(rx0, vo0, o0 + 64 * NV0);
     if (NS2) xs2 = bld1(rx2, vo2, o2);
-    if (step > 0) {
+    if (step > 0 && !(abl & 32)) {
       const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
 #pragma unroll
       for (int s = 0; s < NS; ++s) hold[s] = bld4(ro, voo, op + 64 * s);
@@ -176,8 +190,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
 
     for (int s = 0; s < NS; ++s) {
       v4f cprev = zero4, skipv = zero4;
-      if (step > 0) cprev = bld4(rc, vlane, s * 1024);
-      if (SUM) skipv = bld4(rsk, vok, ok + 64 * s);
+      if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
+      if (SUM && !(abl & 16)) skipv = bld4(rsk, vok, ok + 64 * s);
       const unsigned nx = (s + 1 < NS ? tt : ttn) * st0;   // x of the next slice / next step
 
       // quad 0: bias -> accumulators
@@ -192,10 +206,12 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
         constexpr int V = decltype(v)::value;
         const v4f xb = xr[V % 4];
         SQUAD(1 + V, xb.x, xb.y, xb.z, xb.w);
-        if constexpr (V + 4 < NV0)
-          xr[V % 4] = bld4(rx0, vo0, o0 + 64 * (V + 4));
-        else
-          xr[V % 4] = bld4(rx0, vo0, nx + 64 * (V + 4 - NV0));   // wraps into the next slice
+        if (!(abl & 1)) {
+          if constexpr (V + 4 < NV0)
+            xr[V % 4] = bld4(rx0, vo0, o0 + 64 * (V + 4));
+          else
+            xr[V % 4] = bld4(rx0, vo0, nx + 64 * (V + 4 - NV0));   // wraps into the next slice
+        }
       });
       if constexpr (NS0 > 0) SQUAD1(1 + NV0, xs0);
       if constexpr (NS2 > 0) SQUAD1(1 + NV0 + NS0, xs2);
@@ -210,17 +226,27 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
         ring_end(ic<QPS + decltype(u)::value>{});
       });
       // cell update
-      const v4f ig = sigmoid4(acc[0]);
-      const v4f fg = sigmoid4(acc[1]);
-      const v4f gg = tanh4(acc[2]);
-      const v4f og = sigmoid4(acc[3]);
-      const v4f cn = cell4(fg, cprev, ig, gg);
-      v4f hn = mul_rn4(og, tanh4(cn));
+      v4f cn, hn;
+      if (ABL && (abl & 2)) {
+        cn = acc[1] + cprev + acc[0];
+        hn = acc[3] + acc[2];
+      } else {
+        const v4f ig = sigmoid4(acc[0]);
+        const v4f fg = sigmoid4(acc[1]);
+        const v4f gg = tanh4(acc[2]);
+        const v4f og = sigmoid4(acc[3]);
+        cn = cell4(fg, cprev, ig, gg);
+        hn = mul_rn4(og, tanh4(cn));
+      }
       asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
-      bst4(cn, rc, vlane, s * 1024);
-      if (valid) {
-        bst4(hn, ro, voo, oo + 64 * s);
-        if (SUM) bst4(add_rn4(hn, skipv), ro2, voo2, oo + 64 * s);
+      if (!(abl & 4)) {
+        bst4(cn, rc, vlane, s * 1024);
+        if (valid) {
+          bst4(hn, ro, voo, oo + 64 * s);
+          if (SUM) bst4(add_rn4(hn, skipv), ro2, voo2, oo + 64 * s);
+        }
+      } else {
+        asm volatile("" ::"v"(cn), "v"(hn));
       }
     }
   }
@@ -228,10 +254,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
 #undef SQUAD1
 }
 
-template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE>
+template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false>
 int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
   const size_t lds = (size_t)2 * CHQ * 4096;
-  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE>;
+  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));

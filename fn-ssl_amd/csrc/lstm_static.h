@@ -31,7 +31,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // ABL = true: timing-ablation twin driven by FNSSL_ABLATE (bits as in lstm_rec_kernel); wrong results.
-template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false>
+// STAG = true: the waves of a workgroup form two groups that run ONE CHUNK apart on a 3-slot ring,
+// so the slice-end work of one group (cell update, stores, accumulator re-init, first x loads)
+// overlaps with the other group's MFMAs instead of idling the matrix pipe for everybody at once.
+template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
+          bool STAG = false>
 __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p) {
   constexpr int NS = H / 16;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
@@ -42,7 +46,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   static_assert(VQ % CHQ == 0, "chunks must tile the (padded) slice");
   constexpr int CH = 4 * CHQ;                           // records per chunk
   static_assert(CH <= NW * M, "chunk does not fit the staging registers");
-  static_assert(NV0 == 0 || NV0 % 4 == 0, "x ring is 4 blocks deep");
+  static_assert(NV0 == 0 || NV0 % XD == 0, "the x ring depth must divide the block count");
   static_assert(!(NS0 && NV0), "remainder-only or block-only summed input");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -76,6 +80,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   // ---- weight ring ---------------------------------------------------------------
   char* const lds_rd = smem + lane * 16;
   char* const lds_wr = smem + w * 1024 + lane * 16;
+  constexpr int NSLOT = STAG ? 3 : 2;
+  const bool late = STAG && ((w >> 2) & 1);   // group 1 runs one chunk behind group 0
   int wslot = 0;          // slot the staged chunk is committed to
   int rslot = 0;          // slot being read
   int src_rec = 0;        // real record index of the next chunk to stage
@@ -103,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
 #pragma unroll
     for (int m = 0; m < M; ++m)
       if (w + m * NW < CH) *reinterpret_cast<v4f*>(lds_wr + wslot * (CH * 1024) + m * (NW * 1024)) = stg[m];
-    wslot ^= 1;
+    wslot = (wslot + 1 == NSLOT) ? 0 : wslot + 1;
   };
   auto sync = [&]() {
     if (ABL && (abl & 8))
@@ -115,6 +121,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   stage_write();
   sync();
   issue_loads();
+  if (late) {   // idle period: keep the ring protocol going while group 0 works on chunk 0
+    stage_write();
+    sync();
+    issue_loads();
+  }
   const char* cb = lds_rd;                      // base of the chunk being read
   auto rec = [&](auto ql, int j) {              // record j of quad ql (compile time) of the current chunk
     return *reinterpret_cast<const v4f*>(cb + decltype(ql)::value * 4096 + j * 1024);
@@ -143,7 +154,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       if constexpr (CHQ == 1) stage_write();
       sync();
       issue_loads();
-      rslot ^= 1;
+      rslot = (rslot + 1 == NSLOT) ? 0 : rslot + 1;
       cb = lds_rd + rslot * (CH * 1024);
       a0 = rec(ic<0>{}, 0);
       a1 = rec(ic<0>{}, 1);
@@ -168,11 +179,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
     ring_end(ic<(QI)>{});      \
   } while (0)
 
-  // ---- x operand ring: block v lives in xr[v % 4], requested 3 quads before its use --
-  v4f xr[4] = {zero4, zero4, zero4, zero4};
+  // ---- x operand ring: block v lives in xr[v % XD], requested XD-1 quads before its use --
+  v4f xr[XD];
+#pragma unroll
+  for (int i = 0; i < XD; ++i) xr[i] = zero4;
   {
     const unsigned tt0 = rev ? p.nsteps - 1 : 0;
-    static_for<(NV0 < 4 ? NV0 : 4)>([&](auto v) { xr[v.value] = bld4(rx0, vo0, tt0 * st0 + 64 * v.value); });
+    static_for<(NV0 < XD ? NV0 : XD)>([&](auto v) { xr[v.value] = bld4(rx0, vo0, tt0 * st0 + 64 * v.value); });
   }
 
   for (int step = 0; step < p.nsteps; ++step) {
@@ -190,8 +203,6 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
 
     for (int s = 0; s < NS; ++s) {
       v4f cprev = zero4, skipv = zero4;
-      if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
-      if (SUM && !(abl & 16)) skipv = bld4(rsk, vok, ok + 64 * s);
       const unsigned nx = (s + 1 < NS ? tt : ttn) * st0;   // x of the next slice / next step
 
       // quad 0: bias -> accumulators
@@ -204,15 +215,19 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       // summed input, 16 channels per quad
       static_for<NV0>([&](auto v) {
         constexpr int V = decltype(v)::value;
-        const v4f xb = xr[V % 4];
+        const v4f xb = xr[V % XD];
         SQUAD(1 + V, xb.x, xb.y, xb.z, xb.w);
         if (!(abl & 1)) {
-          if constexpr (V + 4 < NV0)
-            xr[V % 4] = bld4(rx0, vo0, o0 + 64 * (V + 4));
+          if constexpr (V + XD < NV0)
+            xr[V % XD] = bld4(rx0, vo0, o0 + 64 * (V + XD));
           else
-            xr[V % 4] = bld4(rx0, vo0, nx + 64 * (V + 4 - NV0));   // wraps into the next slice
+            xr[V % XD] = bld4(rx0, vo0, nx + 64 * (V + XD - NV0));   // wraps into the next slice
         }
       });
+      // cell state and residual operand of this slice: requested after the x part (whose ring
+      // registers they reuse), still a whole recurrent part ahead of their use
+      if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
+      if (SUM && !(abl & 16)) skipv = bld4(rsk, vok, ok + 64 * s);
       if constexpr (NS0 > 0) SQUAD1(1 + NV0, xs0);
       if constexpr (NS2 > 0) SQUAD1(1 + NV0 + NS0, xs2);
       // recurrent part
@@ -250,14 +265,20 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       }
     }
   }
+  if (STAG && !late) {   // group 0 finishes one period early: stay in the protocol
+    stage_write();
+    sync();
+  }
 #undef SQUAD
 #undef SQUAD1
 }
 
-template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false>
+template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
+          bool STAG = false>
 int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
-  const size_t lds = (size_t)2 * CHQ * 4096;
-  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL>;
+  const size_t lds = (size_t)(STAG ? 3 : 2) * CHQ * 4096;
+  static_assert((STAG ? 3 : 2) * CHQ * 4096 <= 160 * 1024, "ring does not fit the LDS");
+  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL, XD, STAG>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));

@@ -8,7 +8,19 @@ namespace fnssl_lstm {
   if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                  \
     return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_>(p, nwg, st);
 
+#define TRYS(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_)                                             \
+  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                \
+    return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, 4, true>(p, nwg, st);
+
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st) {
+  if (!p.ablate && env_int("FNSSL_STATIC_STAG", 1, 1)) {   // experiment (no gain, r01): two wave groups one chunk apart
+    TRYS(16, 2, 16, 0, 0, 7, 3, kSum)
+    TRYS(15, 2, 16, 0, 0, 7, 3, kSum)
+    TRYS(14, 2, 16, 0, 0, 7, 3, kSum)
+    TRYS(16, 2, 0, 1, 0, 5, 0, 0)
+    TRYS(15, 2, 0, 1, 0, 5, 0, 0)
+    TRYS(14, 2, 0, 1, 0, 5, 0, 0)
+  }
   // block 1 full-band: 4 input channels, 10 quads per slice
   if (!env_int("FNSSL_STATIC_SMALLCHUNK", 1, 1)) {
     TRY(16, 4, 0, 1, 0, 10, 0, 0)

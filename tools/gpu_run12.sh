@@ -1,0 +1,7 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests -m gpu -q --timeout 240 -p no:cacheprovider 2>&1 | tail -5 > $O/pytest.log
+echo "== XD=8" > $O/lstm_bench.log
+timeout 300 python tools/lstm_bench.py --layers narrow256s,narrow256_first,full128s --variants 0 --reps 3 >> $O/lstm_bench.log 2>&1
+echo "== XD=4" >> $O/lstm_bench.log
+FNSSL_STATIC_XD4=1 timeout 300 python tools/lstm_bench.py --layers narrow256s --variants 0 --reps 3 >> $O/lstm_bench.log 2>&1
+tail -3 $O/pytest.log; grep -v amdgpu.ids $O/lstm_bench.log

@@ -1,16 +1,19 @@
 """Drop-ins for the hot-path classes of the reference's ``Module.py``
 (FN-SSL/Module.py:28-68 STFT, :376-404 AddChToBatch, :406-421 RemoveChFromBatch).
 
-Only the signal front end lives here; the IPD->DOA back end, metrics and
-plotting of the reference's Module.py are out of scope.  The
+The signal front end and — as the first "next" row of SURVEY.md §8f — the IPD->DOA back end
+(DPIPD templates :424-519, SourceDetectLocalize 'IDL' :516-577, PredDOA.predgt2DOA :690-727)
+live here; metrics and plotting of the reference's Module.py are out of scope.  The
 fused front end used by ``predict_step`` is ``fnssl.ops.preprocess`` (one STFT
 kernel + one scan + one pack kernel); the classes below exist so code written
 against the reference's per-stage API keeps working, with the same shapes and
 dtypes.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
+from fnssl import doa as fdoa
 from fnssl import ops
 
 
@@ -66,3 +69,89 @@ class RemoveChFromBatch(nn.Module):
     def forward(self, data, nb):
         nmic = int(data.shape[0] / nb)
         return data.reshape((nb, nmic) + tuple(data.shape[1:])).contiguous()
+
+
+class DPIPD(nn.Module):
+    """DP-IPD template bank exp(-j 2 pi f tau) for a grid of candidate directions (host, numpy;
+    built once per array geometry).  ``forward()`` returns (template, None, doa_candidate) like the
+    reference with ``source_doa=None``; generating ground-truth targets is outside the path."""
+
+    def __init__(self, ndoa_candidate, mic_location, nf=257, fre_max=8000, ch_mode='M', speed=343.0):
+        super(DPIPD, self).__init__()
+        self.ndoa_candidate = ndoa_candidate
+        self.mic_location = mic_location
+        self.nf, self.fre_max, self.speed, self.ch_mode = nf, fre_max, speed, ch_mode
+        self.dpipd_template, self.doa_candidate = fdoa.dpipd_templates(
+            mic_location, ndoa_candidate[0], ndoa_candidate[1], nf, fre_max, ch_mode, speed)
+
+    def forward(self, source_doa=None):
+        if source_doa is not None:
+            raise NotImplementedError("ground-truth DP-IPD targets (training) are outside the forward path")
+        return self.dpipd_template, None, self.doa_candidate
+
+
+class SourceDetectLocalize(nn.Module):
+    """Iterative localisation and voice-activity detection ('IDL') on device."""
+
+    def __init__(self, max_num_sources, source_num_mode='kNum', meth_mode='IDL'):
+        super(SourceDetectLocalize, self).__init__()
+        if meth_mode != 'IDL':
+            raise NotImplementedError("only the iterative 'IDL' method is part of the path")
+        self.max_num_sources = max_num_sources
+        self.source_num_mode = source_num_mode
+        self.meth_mode = meth_mode
+
+    def forward(self, pred_ipd, dpipd_template, doa_candidate):
+        """pred_ipd [nb, nt, 2nf, np], dpipd_template [nele, nazi, 2nf, np] ->
+        (DOAs [nb, nt, 2, ns], VADs [nb, nt, ns], spatial spectrum [nb, nt, nele, nazi])"""
+        nb = pred_ipd.shape[0]
+        nele, nazi = dpipd_template.shape[:2]
+        idx, vads, ss = fdoa.localize(pred_ipd.detach(), dpipd_template.to(pred_ipd.device), nb,
+                                      self.max_num_sources, self.source_num_mode)
+        ele = torch.as_tensor(np.asarray(doa_candidate[0])).to(pred_ipd.device, torch.float32)
+        azi = torch.as_tensor(np.asarray(doa_candidate[1])).to(pred_ipd.device, torch.float32)
+        idx = idx.long()
+        doas = torch.stack((ele[idx // nazi], azi[idx % nazi]), dim=2)       # [nb, nt, 2, ns]
+        return doas, vads, ss
+
+
+class PredDOA(nn.Module):
+    """DP-IPD predictions -> DOA tracks (prediction half of the reference's PredDOA, Module.py:650-727).
+    ``mic_location`` defaults to the reference's hard-coded two-microphone array."""
+
+    def __init__(self, method_mode='IDL', source_num_mode='kNum', cuda_activated=True, max_num_sources=1,
+                 res_the=37, res_phi=73, fs=16000, nfft=512, ch_mode='MM', device="cuda", mic_location=None):
+        super(PredDOA, self).__init__()
+        self.nfft = nfft
+        self.fre_max = fs / 2
+        self.ch_mode = ch_mode
+        self.dev = device
+        if mic_location is None:
+            mic_location = np.array(((-0.04, 0.0, 0.0), (0.04, 0.0, 0.0)))
+        self.removebatch = RemoveChFromBatch(ch_mode=self.ch_mode)
+        self.gerdpipd = DPIPD(ndoa_candidate=[res_the, res_phi], mic_location=mic_location,
+                              nf=int(self.nfft / 2) + 1, fre_max=self.fre_max, ch_mode=self.ch_mode, speed=340)
+        self.sourcelocalize = SourceDetectLocalize(max_num_sources=int(max_num_sources),
+                                                   source_num_mode=source_num_mode, meth_mode=method_mode)
+        bank, self.doa_candidate = fdoa.template_bank(self.gerdpipd.dpipd_template)
+        self.register_buffer("bank", torch.from_numpy(bank), persistent=False)
+
+    def predgt2DOA(self, pred_batch=None, gt_batch=None, time_pool_size=None):
+        if time_pool_size is not None:
+            raise NotImplementedError("time pooling of non-network IPDs is outside the path")
+        if pred_batch is not None:
+            pred_ipd = pred_batch.detach()
+            npair = self.bank.shape[-1]
+            nb = pred_ipd.shape[0] // npair
+            idx, vads, ss = fdoa.localize(pred_ipd, self.bank.to(pred_ipd.device), nb,
+                                          self.sourcelocalize.max_num_sources, self.sourcelocalize.source_num_mode)
+            nazi = self.bank.shape[1]
+            ele = torch.as_tensor(self.doa_candidate[0]).to(pred_ipd.device, torch.float32)
+            azi = torch.as_tensor(self.doa_candidate[1]).to(pred_ipd.device, torch.float32)
+            idx = idx.long()
+            pred_batch = {'doa': torch.stack((ele[idx // nazi], azi[idx % nazi]), dim=2),
+                          'vad_sources': vads, 'spatial_spectrum': ss}
+        if gt_batch is not None:
+            for key in gt_batch.keys():
+                gt_batch[key] = gt_batch[key].detach()
+        return pred_batch, gt_batch

@@ -168,6 +168,26 @@ int fnssl_linear(const float* x, int m, int k, const float* wt, const float* b, 
                  float* y, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* IPD -> DOA back end (next row after the forward path)      */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Replaces SourceDetectLocalize.forward, meth_mode 'IDL'
+ * (FN-SSL/Lightning/Module.py:525-577): spatial spectrum against a DP-IPD template
+ * bank, then per source: first-argmax, projection ratio, subtraction.
+ *   pred  element (utterance b, pair p, segment t, k) at pred[b*sb + p*sp + t*st + k*sk]:
+ *         the network output [nb*np, nt, nf2] (sb = np*nt*nf2, sp = nt*nf2, st = nf2, sk = 1,
+ *         nf2 = 2*nf = [cos | sin]) or the reference's re-batched [nb, nt, nf2, np] view
+ *   bank  [ncand, nf2, np]   template bank (host: fnssl.doa.template_bank)
+ *   ss    [nb, nt, ncand]    spatial spectrum before any subtraction
+ *   idx   [nb, nt, nsrc]     winning candidate per source (int32)
+ *   vad   [nb, nt, nsrc]     1 ('kNum') or the projection ratio ('unkNum', unk_num = 1)
+ */
+int fnssl_ipd2doa(const float* pred, long long sb, long long sp, long long st, long long sk,
+                  const float* bank, int nb, int np, int nt, int nf2,
+                  int ncand, int nsrc, int unk_num, float* ss, int* idx, float* vad, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Whole network (replaces FN_SSL.forward, FN-SSL/Model.py:72-90)             */
 /* ------------------------------------------------------------------------- */
 

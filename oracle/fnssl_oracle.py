@@ -278,3 +278,84 @@ def flops_per_tf_point(is_online: bool = True, input_size: int = 4) -> int:
     total = l(input_size, 128, 2) + l(256 + input_size, hn, nd)
     total += 2 * (l(256, 128, 2) + l(256, hn, nd))
     return total
+
+
+# --------------------------------------------------------------------------- #
+# IPD -> DOA back end (next row after the forward path)
+# --------------------------------------------------------------------------- #
+def dpipd_templates(mic_location: np.ndarray, nele: int = 37, nazi: int = 73, nf: int = 257,
+                    fre_max: float = 8000.0, ch_mode: str = "MM", speed: float = 340.0):
+    """DPIPD.__init__ + data_adjust, FN-SSL/Lightning/Module.py:429-463,505-519.
+
+    Returns (template complex64 [nele, nazi, nf, np], [ele_candidate, azi_candidate]).
+    """
+    mic_location = np.asarray(mic_location, dtype=np.float64)
+    nmic = mic_location.shape[-2]
+    ele = np.linspace(0, np.pi, nele)
+    azi = np.linspace(-np.pi, np.pi, nazi)
+    fre = np.linspace(0.0, fre_max, nf)
+    r = np.stack([np.outer(np.sin(ele), np.cos(azi)), np.outer(np.sin(ele), np.sin(azi)),
+                  np.tile(np.cos(ele), [nazi, 1]).transpose()], axis=2)            # [nele, nazi, 3]
+    ipd = np.empty((nele, nazi, nf, nmic, nmic))
+    for m1 in range(nmic):
+        for m2 in range(nmic):
+            itd = np.dot(r, mic_location[m2, :] - mic_location[m1, :]) / speed     # :450
+            ipd[:, :, :, m1, m2] = -2 * np.pi * fre[None, None, :] * itd[:, :, None]
+    tmpl = np.exp(1j * ipd)
+    pairs = pair_list(nmic, ch_mode)
+    out = np.empty((nele, nazi, nf, len(pairs)), dtype=np.complex64)
+    for p, (i, j) in enumerate(pairs):
+        out[..., p] = tmpl[..., i, j]
+    return out, [ele, azi]
+
+
+def template_bank(template: np.ndarray, doa_candidate):
+    """The candidate bank PredDOA.predgt2DOA actually searches, Module.py:702-716: real|imag of
+    bins 1..256 concatenated along frequency, elevation fixed to the middle row, azimuth the upper
+    half of the grid; candidates replaced by ele = pi/2, azi = linspace(0, pi, 37)."""
+    nele, nazi = template.shape[:2]
+    t = np.concatenate((template.real[:, :, 1:NBIN, :], template.imag[:, :, 1:NBIN, :]), axis=2).astype(F32)
+    t = t[int((nele - 1) / 2):int((nele - 1) / 2) + 1, int((nazi - 1) / 2):nazi, :, :]
+    cand = [np.linspace(np.pi / 2, np.pi / 2, 1), np.linspace(0, np.pi, 37)]
+    return np.ascontiguousarray(t), cand
+
+
+def source_detect_localize(pred_ipd: np.ndarray, bank: np.ndarray, cand, max_num_sources: int = 1,
+                           source_num_mode: str = "kNum"):
+    """SourceDetectLocalize.forward, meth_mode 'IDL', Module.py:525-577.
+
+    pred_ipd [nb, nt, 2nf, np] (= RemoveChFromBatch(pred).permute(0, 2, 3, 1)), bank [nele, nazi, 2nf, np]
+    -> (doa [nb, nt, 2, ns], vad [nb, nt, ns], ss [nb, nt, nele, nazi])
+    """
+    pred = np.array(pred_ipd, dtype=F32, copy=True)
+    nb, nt, nf2, npair = pred.shape
+    nele, nazi = bank.shape[:2]
+    flat = bank.reshape(nele * nazi, nf2 * npair).astype(F32)                      # [ncand, 2nf*np]
+    norm = F32(npair * nf2 / 2)
+    doas = np.zeros((nb, nt, 2, max_num_sources), dtype=F32)
+    vads = np.zeros((nb, nt, max_num_sources), dtype=F32)
+    ss0 = None
+    for s in range(max_num_sources):
+        m = (pred.reshape(nb, nt, -1) @ flat.T / norm).astype(F32)                 # [nb, nt, ncand]
+        if ss0 is None:
+            ss0 = m.reshape(nb, nt, nele, nazi).copy()
+        idx = m.argmax(axis=2)
+        ei, ai = np.unravel_index(idx, (nele, nazi))
+        doas[:, :, 0, s] = cand[0][ei]
+        doas[:, :, 1, s] = cand[1][ai]
+        tm = flat[idx].reshape(nb, nt, nf2, npair)                                 # chosen templates
+        ratio = (tm * pred).sum(axis=(2, 3), dtype=F32) / (tm * tm).sum(axis=(2, 3), dtype=F32)
+        vads[:, :, s] = 1 if source_num_mode == "kNum" else ratio
+        pred = (pred - ratio[:, :, None, None] * tm).astype(F32)
+    return doas, vads, ss0
+
+
+def pred_to_doa(pred: np.ndarray, nb: int, mic_location, ch_mode: str = "MM", max_num_sources: int = 1,
+                source_num_mode: str = "kNum", speed: float = 340.0):
+    """PredDOA.predgt2DOA (prediction half), Module.py:690-727: network output
+    [nb*np, nt, 2nf] -> dict(doa, vad_sources, spatial_spectrum)."""
+    tmpl, cand = dpipd_templates(mic_location, 37, 73, NBIN, 8000.0, ch_mode, speed)
+    bank, cand = template_bank(tmpl, cand)
+    rebatch = np.transpose(remove_ch_from_batch(pred, nb), (0, 2, 3, 1))           # [nb, nt, 2nf, np]
+    doa, vad, ss = source_detect_localize(rebatch, bank, cand, max_num_sources, source_num_mode)
+    return {"doa": doa, "vad_sources": vad, "spatial_spectrum": ss}

@@ -169,5 +169,46 @@ def main():
          out=out.numpy(), x_sub=x.numpy()[:, :, ::32, ::8])
 
 
+
+
+@torch.no_grad()
+def golden_doa():
+    """G12: IPD -> DOA back end (PredDOA.predgt2DOA / SourceDetectLocalize / DPIPD)."""
+    arrs = {}
+    # the reference's own 2-mic geometry, one and two sources, both source-number modes
+    for ci, (ns, mode) in enumerate([(1, "kNum"), (2, "unkNum")]):
+        pd = ref_module.PredDOA(method_mode="IDL", source_num_mode=mode, max_num_sources=ns, ch_mode="MM",
+                                device="cpu")
+        pred = np.tanh(rs_randn(1200 + ci, (3, 5, 512)))            # [nb*np (np = 1), nt, 2nf]
+        out, _ = pd.predgt2DOA(pred_batch=torch.from_numpy(pred), gt_batch=None)
+        arrs["c%d_cfg" % ci] = np.array([1200 + ci, 3, 5, ns, int(mode == "kNum")])
+        arrs["c%d_doa" % ci] = out["doa"].numpy()
+        arrs["c%d_vad" % ci] = out["vad_sources"].numpy()
+        arrs["c%d_ss" % ci] = out["spatial_spectrum"].numpy()
+    # template generator on a 4-mic geometry, 'MM' and 'M' (sub-sampled grid to stay small)
+    mics = np.array(((-0.04, 0.0, 0.0), (0.04, 0.0, 0.0), (0.0, 0.05, 0.01), (0.02, -0.03, 0.0)))
+    for mode in ("MM", "M"):
+        g = ref_module.DPIPD(ndoa_candidate=[5, 9], mic_location=mics, nf=257, fre_max=8000, ch_mode=mode, speed=340)
+        t, _, cand = g()
+        arrs["tmpl_" + mode] = t[:, :, ::16, :].astype(np.complex64)
+    arrs["tmpl_mics"] = mics
+    # a 4-mic localisation through SourceDetectLocalize with a bank built by the reference DPIPD
+    g = ref_module.DPIPD(ndoa_candidate=[37, 73], mic_location=mics, nf=257, fre_max=8000, ch_mode="MM", speed=340)
+    t, _, _ = g()
+    bank = np.concatenate((t.real[:, :, 1:257, :], t.imag[:, :, 1:257, :]), axis=2).astype(np.float32)
+    bank = bank[18:19, 36:73]
+    cand = [np.linspace(np.pi / 2, np.pi / 2, 1), np.linspace(0, np.pi, 37)]
+    sdl = ref_module.SourceDetectLocalize(max_num_sources=2, source_num_mode="unkNum", meth_mode="IDL")
+    pred4 = np.tanh(rs_randn(1210, (2, 4, 512, 6)))                # [nb, nt, 2nf, np]
+    doa, vad, ss = sdl(pred_ipd=torch.from_numpy(pred4), dpipd_template=torch.from_numpy(bank), doa_candidate=cand)
+    arrs["m4_seed"] = np.array([1210])
+    arrs["m4_doa"], arrs["m4_vad"], arrs["m4_ss"] = doa.numpy(), vad.numpy(), ss.numpy()
+    save("g12_doa", **arrs)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "doa":
+        golden_doa()
+    else:
+        main()
+        golden_doa()

@@ -382,3 +382,50 @@ def test_full_size_frame_slice_against_oracle(dev):
     want = O.predict_step(sd, batch, "MM", True)
     assert out.shape == want.shape == (1, 25, 512)
     assert_close(out, want, RTOL, ATOL, "257 x 300 utterance")
+
+
+# --------------------------------------------------------------------------- IPD -> DOA back end (next row)
+def test_doa_backend_golden(dev):
+    """PredDOA / SourceDetectLocalize / DPIPD drop-ins against the reference's outputs: candidate
+    choices exact, spectra and ratios within fp32 tolerance."""
+    import Module as at_module
+    g = load_golden("g12_doa")
+    for ci in range(2):
+        seed, nbp, nt, ns, knum = [int(v) for v in g["c%d_cfg" % ci]]
+        pd = at_module.PredDOA(method_mode="IDL", source_num_mode="kNum" if knum else "unkNum",
+                               max_num_sources=ns, ch_mode="MM", device=str(dev)).to(dev)
+        pred = to_dev(np.tanh(rs_randn(seed, (nbp, nt, 512))), dev)
+        out, _ = pd.predgt2DOA(pred_batch=pred, gt_batch=None)
+        np.testing.assert_array_equal(out["doa"].cpu().numpy(), g["c%d_doa" % ci])
+        assert_close(out["vad_sources"].cpu().numpy(), g["c%d_vad" % ci], 1e-4, 1e-6, "vad")
+        assert_close(out["spatial_spectrum"].cpu().numpy(), g["c%d_ss" % ci], 1e-5, 1e-6, "spatial spectrum")
+    mics4 = g["tmpl_mics"]
+    for mode in ("MM", "M"):
+        t, _, cand = at_module.DPIPD([5, 9], mics4, nf=257, fre_max=8000, ch_mode=mode, speed=340)()
+        assert_close(t[:, :, ::16, :], g["tmpl_" + mode], 1e-5, 1e-5, "template " + mode)
+    from fnssl import doa as fdoa
+    t, cand = fdoa.dpipd_templates(mics4, 37, 73, 257, 8000, "MM", 340)
+    bank, cand = fdoa.template_bank(t)
+    sdl = at_module.SourceDetectLocalize(max_num_sources=2, source_num_mode="unkNum", meth_mode="IDL")
+    pred4 = to_dev(np.tanh(rs_randn(int(g["m4_seed"][0]), (2, 4, 512, 6))), dev)
+    doa, vad, ss = sdl(pred_ipd=pred4, dpipd_template=to_dev(bank, dev), doa_candidate=cand)
+    np.testing.assert_array_equal(doa.cpu().numpy(), g["m4_doa"])
+    assert_close(vad.cpu().numpy(), g["m4_vad"], 1e-4, 1e-6, "4-mic vad")
+    assert_close(ss.cpu().numpy(), g["m4_ss"], 1e-5, 1e-6, "4-mic spatial spectrum")
+
+
+def test_waveform_to_doa_end_to_end(dev):
+    """waveform -> DP-IPD -> DOA entirely on device equals oracle forward + oracle back end."""
+    import Module as at_module
+    import predict_step as ps
+    from oracle import fnssl_oracle as O
+    net, sd = build_net(dev, 81)
+    model = ps.MyModel(device=str(dev))
+    model.arch = net
+    batch = rs_randn(82, (2, 2, 512 + 35 * 256), 0.05)
+    pred = model.predict_step(to_dev(batch, dev), 0)
+    pd = at_module.PredDOA(max_num_sources=1, device=str(dev)).to(dev)
+    out, _ = pd.predgt2DOA(pred_batch=pred)
+    want = O.pred_to_doa(O.predict_step(sd, batch, "MM", True), 2, np.array(((-0.04, 0, 0), (0.04, 0, 0))))
+    np.testing.assert_array_equal(out["doa"].cpu().numpy(), want["doa"])
+    assert_close(out["spatial_spectrum"].cpu().numpy(), want["spatial_spectrum"], 1e-4, 1e-5, "spectrum")

@@ -145,3 +145,27 @@ def test_torch_ref_features():
     sig3 = rs_randn(g["seed3"], g["shape3"])
     got = R.data_preprocess(torch.from_numpy(sig3), "MM").numpy()
     assert_close(got, g["x3"], 1e-6, 1e-6, "torch_ref features")
+
+
+# --- IPD -> DOA back end (next row after the forward path) ------------------------------------------
+def test_g12_doa_backend():
+    g = load_golden("g12_doa")
+    mics2 = np.array(((-0.04, 0.0, 0.0), (0.04, 0.0, 0.0)))
+    for ci in range(2):
+        seed, nbp, nt, ns, knum = [int(v) for v in g["c%d_cfg" % ci]]
+        pred = np.tanh(rs_randn(seed, (nbp, nt, 512)))
+        out = O.pred_to_doa(pred, nbp, mics2, "MM", ns, "kNum" if knum else "unkNum")
+        np.testing.assert_array_equal(out["doa"], g["c%d_doa" % ci])          # candidate indices: exact
+        assert_close(out["vad_sources"], g["c%d_vad" % ci], 1e-5, 1e-6, "vad %d" % ci)
+        assert_close(out["spatial_spectrum"], g["c%d_ss" % ci], 1e-5, 1e-6, "ss %d" % ci)
+    mics4 = g["tmpl_mics"]
+    for mode in ("MM", "M"):
+        t, cand = O.dpipd_templates(mics4, 5, 9, 257, 8000, mode, 340)
+        assert_close(t[:, :, ::16, :], g["tmpl_" + mode], 1e-5, 1e-5, "template " + mode)
+    t, cand = O.dpipd_templates(mics4, 37, 73, 257, 8000, "MM", 340)
+    bank, cand = O.template_bank(t, cand)
+    pred4 = np.tanh(rs_randn(int(g["m4_seed"][0]), (2, 4, 512, 6)))
+    doa, vad, ss = O.source_detect_localize(pred4, bank, cand, 2, "unkNum")
+    np.testing.assert_array_equal(doa, g["m4_doa"])
+    assert_close(vad, g["m4_vad"], 1e-4, 1e-6, "4-mic vad")
+    assert_close(ss, g["m4_ss"], 1e-5, 1e-6, "4-mic ss")

@@ -12,7 +12,16 @@ namespace fnssl_lstm {
   if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                \
     return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, 4, true>(p, nwg, st);
 
+#define TRYX(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, XD_)                                        \
+  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                \
+    return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, XD_>(p, nwg, st);
+
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st) {
+  if (!p.ablate && env_int("FNSSL_STATIC_XD8", 1, 1)) {   // experiment: 8-deep x ring
+    TRYX(16, 2, 16, 0, 0, 7, 3, kSum, 8)
+    TRYX(15, 2, 16, 0, 0, 7, 3, kSum, 8)
+    TRYX(14, 2, 16, 0, 0, 7, 3, kSum, 8)
+  }
   if (!p.ablate && env_int("FNSSL_STATIC_STAG", 1, 1)) {   // experiment (no gain, r01): two wave groups one chunk apart
     TRYS(16, 2, 16, 0, 0, 7, 3, kSum)
     TRYS(15, 2, 16, 0, 0, 7, 3, kSum)
@@ -51,6 +60,18 @@ int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream
   TRY(14, 2, 16, 0, 0, 7, 3, 0)
   // offline narrow-band block 1: 256 + 4 channels, 26 quads (+2 pad = 4 x 7)
   TRY(16, 2, 16, 0, 1, 7, 2, kHas2 | kSum)
+  // smaller launches (fewer than 14 waves per CU): 13 / 12 / 8 / 4 waves per workgroup
+  TRY(13, 4, 16, 0, 0, 13, 1, kSum)
+  TRY(13, 4, 16, 0, 0, 13, 1, 0)
+  TRY(12, 2, 16, 0, 0, 5, 0, kSum)
+  TRY(12, 2, 16, 0, 0, 5, 0, 0)
+  TRY(12, 2, 0, 1, 0, 5, 0, 0)
+  TRY(8, 4, 16, 0, 0, 7, 3, kSum)
+  TRY(8, 4, 16, 0, 0, 7, 3, 0)
+  TRY(8, 4, 0, 1, 0, 5, 0, 0)
+  TRY(4, 4, 16, 0, 0, 4, 3, kSum)
+  TRY(4, 4, 16, 0, 0, 4, 3, 0)
+  TRY(4, 4, 0, 1, 0, 4, 2, 0)
   return kNoStatic;
 }
 

@@ -32,6 +32,13 @@ int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream
     return launch_static_k<256, 12, 4, 16, 0, 0, 11, 0, kSum, true>(p, nwg, st);
   TRY(12, 4, 16, 0, 0, 11, 0, kSum)
   TRY(12, 4, 16, 0, 0, 11, 0, 0)
+  // smaller launches: 8 / 4 waves per workgroup
+  TRY(8, 4, 16, 0, 1, 7, 1, kHas2 | kSum)
+  TRY(8, 4, 16, 0, 0, 7, 2, kSum)
+  TRY(8, 4, 16, 0, 0, 7, 2, 0)
+  TRY(4, 4, 16, 0, 1, 4, 2, kHas2 | kSum)
+  TRY(4, 4, 16, 0, 0, 3, 0, kSum)
+  TRY(4, 4, 16, 0, 0, 3, 0, 0)
   return kNoStatic;
 }
 

@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense fp32
-FLOP_PER_TF_POINT = 4997120       # online FN_SSL, LSTM matmuls only
+FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only, by is_online
 
 
 def log(msg):
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--ch-mode", default="MM")
     ap.add_argument("--chunk-pairs", type=int, default=0)
+    ap.add_argument("--offline", action="store_true", help="is_online=False (bidirectional narrow-band LSTM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample")
@@ -87,8 +88,12 @@ def main():
     from fnssl import ops
     from fnssl import weights as W
 
-    sd = W.make_fnssl_state(0, is_online=True)
+    online = not args.offline
+    sd = W.make_fnssl_state(0, is_online=online)
     model = ps.MyModel(ch_mode=args.ch_mode, device=str(dev))
+    if not online:
+        import Model as at_model
+        model.arch = at_model.FN_SSL(is_online=False)
     model.arch.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.arch.chunk_pairs = args.chunk_pairs
     model = model.to(dev).eval()
@@ -130,7 +135,7 @@ def main():
 
     utt_frames = args.nb * nt * args.steps * world
     value = utt_frames / dt
-    flop_per_utt_frame = FLOP_PER_TF_POINT * 256 * n_pairs
+    flop_per_utt_frame = FLOP_PER_TF_POINT[online] * 256 * n_pairs
 
     # ---- roofline of the dominant kernel (narrow-band LSTM, H = 256) ------------------
     roof = None
@@ -139,7 +144,7 @@ def main():
     if os.path.exists(tpath):       # PMC passes cannot run inside the timed region: measured by rocprofv3, committed
         with open(tpath) as f:
             traffic = json.load(f).get("bytes_per_launch")
-    dom = kern.get("lstm_h256")
+    dom = kern.get("lstm_h256") if online else None
     if dom and dom["ms"] > 0:
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "lstm_rec_kernel<H=256> (narrow-band LSTM)",
@@ -158,7 +163,7 @@ def main():
         from oracle import torch_ref as R
         cores = usable_cores()
         torch.set_num_threads(cores)
-        net = R.build(sd, True)
+        net = R.build(sd, online)
         sample = batch[:args.cpu_utts].cpu()
         R.predict_step(net, sample[:, :, :512 + 11 * 256], args.ch_mode)       # warm-up (12 frames)
         # probe on 24 frames, then size the timed sample to ~args.cpu_seconds of CPU work
@@ -191,7 +196,7 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: FN-SSL (online) DP-IPD forward, waveform->STFT->features->"
+            "config": {"workload": "BASELINE configs[1]: FN-SSL (%s) DP-IPD forward," % ("online" if online else "offline") + " waveform->STFT->features->"
                                    "3x(full-band BiLSTM + narrow-band LSTM)->head; %d utterances/GPU x %d mics "
                                    "('%s' = %d pairs) x 257 bins x %d frames, fp32; frame = one STFT frame of one "
                                    "utterance" % (args.nb, args.nch, args.ch_mode, n_pairs, nt),

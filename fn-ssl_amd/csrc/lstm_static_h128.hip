@@ -60,6 +60,8 @@ int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream
   TRY(14, 2, 16, 0, 0, 7, 3, 0)
   // offline narrow-band block 1: 256 + 4 channels, 26 quads (+2 pad = 4 x 7)
   TRY(16, 2, 16, 0, 1, 7, 2, kHas2 | kSum)
+  TRY(12, 4, 16, 0, 1, 9, 1, kHas2 | kSum)
+  TRY(8, 4, 16, 0, 1, 7, 2, kHas2 | kSum)
   // smaller launches (fewer than 14 waves per CU): 13 / 12 / 8 / 4 waves per workgroup
   TRY(13, 4, 16, 0, 0, 13, 1, kSum)
   TRY(13, 4, 16, 0, 0, 13, 1, 0)

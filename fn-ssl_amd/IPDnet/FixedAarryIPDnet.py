@@ -1,0 +1,218 @@
+"""Drop-in for the reference's ``IPDnet/FixedAarryIPDnet.py`` (fixed-array IPDnet): same classes,
+constructor arguments, ``forward`` signatures, return shapes and ``state_dict`` key names, with every
+``forward`` running the HIP kernels of libfnssl_hip.so on an MI355X.
+
+    FNblock(input_size, hidden_size=128, dropout=0.2, add_skip_dim=4, is_online=False, is_first=False)
+        .forward(x, fb_skip, nb_skip) -> x                              FixedAarryIPDnet.py:11,29-40
+    CausCnnBlock(inp_dim, out_dim, cnn_hidden_dim=128, ...)
+        .forward(x[nb, C, nf, nt]) -> [nb, out_dim, nf, nt//12]         FixedAarryIPDnet.py:47,61-73
+    IPDnet(input_size=4, hidden_size=128, max_track=2, is_online=True, n_seg=312)
+        .forward(x[nb, 2*nch, nf, nt], offline_inference=False)
+            -> [nb, nt//12, 2*nf, nch-1, max_track]                     FixedAarryIPDnet.py:80,91-120
+
+Against the reference's dataflow nothing is concatenated or permuted in memory: the concat skips
+(:34, :38) are a second operand segment of the consuming LSTM / conv kernel, the permutes are strides.
+``nn.LSTM`` / ``nn.Conv2d`` sub-modules only hold parameters.  Forward-only (``eval()``), ROCm tensors
+only, fp32.
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from fnssl import ops                                               # noqa: E402
+from Model import _lstm_streams, _param_key, _require_eval          # noqa: E402
+
+
+def _split16(c):
+    """Channels of a skip/input tensor as (vector channels, remainder channels) of the LSTM kernel."""
+    return (c, 0) if c % 16 == 0 else (0, c)
+
+
+class FNblock(nn.Module):
+    """Full-band BiLSTM over frequency and narrow-band LSTM over time with concatenated input skips."""
+
+    def __init__(self, input_size, hidden_size=128, dropout=0.2, add_skip_dim=4, is_online=False, is_first=False):
+        super(FNblock, self).__init__()
+        self.input_size = input_size
+        self.full_hidden_size = hidden_size // 2
+        self.is_first = is_first
+        self.is_online = is_online
+        self.add_skip_dim = add_skip_dim
+        if self.is_online:
+            self.narr_hidden_size = hidden_size
+        else:
+            self.narr_hidden_size = hidden_size // 2
+        self.dropout = dropout
+        self.dropout_full = nn.Dropout(p=self.dropout)
+        self.dropout_narr = nn.Dropout(p=self.dropout)
+        if is_first:
+            self.fullLstm = nn.LSTM(input_size=self.input_size, hidden_size=self.full_hidden_size,
+                                    batch_first=True, bidirectional=True)
+        else:
+            self.fullLstm = nn.LSTM(input_size=self.input_size + add_skip_dim, hidden_size=self.full_hidden_size,
+                                    batch_first=True, bidirectional=True)
+        self.narrLstm = nn.LSTM(input_size=2 * self.full_hidden_size + add_skip_dim,
+                                hidden_size=self.narr_hidden_size, batch_first=True,
+                                bidirectional=not self.is_online)
+        self._packed = None
+        self._packed_key = None
+
+    def _streams(self, device):
+        key = (_param_key(self), str(device))
+        if self._packed is None or self._packed_key != key:
+            if self.is_first:
+                c0, c2 = _split16(self.input_size)
+            else:
+                c0, c2 = self.input_size, self.add_skip_dim
+            full = _lstm_streams(self.fullLstm, c0, c2, device)
+            narr = _lstm_streams(self.narrLstm, 2 * self.full_hidden_size, self.add_skip_dim, device)
+            self._packed, self._packed_key = (full, narr), key
+        return self._packed
+
+    def run(self, x_main, x_skip, x_in=None):
+        """Full-band input = [x_main | x_in] (first block: x_in alone), narrow-band input = [full out | x_skip];
+        x_in defaults to x_skip (IPDnet.forward feeds the network input to both).  All operands are logical
+        [nb, nt, nf, C] tensors with any strides.  Returns the narrow-band output, logical
+        [nb, nt, nf, Hn] stored [nb, nf, nt, Hn]; its concatenation with the skip is left to the consumer."""
+        _require_eval(self)
+        if x_in is None:
+            x_in = x_skip
+        nb, nt, nf, _ = x_skip.shape
+        full_w, narr_w = self._streams(x_skip.device)
+        f = torch.empty((nb, nt, nf, 2 * self.full_hidden_size), dtype=torch.float32, device=x_skip.device)
+        if self.is_first:
+            if _split16(self.input_size)[0]:
+                ops.lstm_layer("full", x_in, None, None, full_w, self.full_hidden_size, f)
+            else:
+                ops.lstm_layer("full", None, None, x_in, full_w, self.full_hidden_size, f)
+        else:
+            ops.lstm_layer("full", x_main, None, x_in, full_w, self.full_hidden_size, f)      # cat :38 of the
+        nh = self.narr_hidden_size * (1 if self.is_online else 2)                              # block before
+        n = torch.empty((nb, nf, nt, nh), dtype=torch.float32, device=x_skip.device)
+        ops.lstm_layer("narrow", f, None, x_skip, narr_w, self.narr_hidden_size, n.permute(0, 2, 1, 3))   # cat :34
+        return n.permute(0, 2, 1, 3)
+
+    def forward(self, x, fb_skip, nb_skip):
+        """Reference signature: x [nb, nt, nf, C], fb_skip [nb*nt, nf, Cs], nb_skip [nb*nf, nt, Cs]
+        -> [nb, nt, nf, Hn + Cs] (the concatenation is materialised only here, for API compatibility)."""
+        nb, nt, nf, nc = x.shape
+        skip = fb_skip.reshape(nb, nt, nf, -1)
+        if self.is_first:
+            n = self.run(None, skip, x)
+        else:
+            if nc != self.input_size + self.add_skip_dim:
+                raise RuntimeError("FNblock: %d input channels, expected %d" % (nc, self.input_size + self.add_skip_dim))
+            n = self.run(x[..., :self.input_size], skip, x[..., self.input_size:])
+        nbs = nb_skip.reshape(nb, nf, nt, -1).permute(0, 2, 1, 3)
+        return torch.cat((n, nbs), dim=-1)
+
+
+class CausCnnBlock(nn.Module):
+    """conv3x3 -> ReLU -> pool 3 -> conv3x3 -> ReLU -> pool 4 -> conv3x3 -> tanh, causal in time."""
+
+    def __init__(self, inp_dim, out_dim, cnn_hidden_dim=128, kernel=(3, 3), stride=(1, 1), padding=(1, 2)):
+        super(CausCnnBlock, self).__init__()
+        if tuple(kernel) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 2):
+            raise ValueError("CausCnnBlock: the MI355X path is built for kernel (3,3), stride (1,1), padding (1,2)")
+        self.inp_dim, self.out_dim, self.cnn_hidden_dim = inp_dim, out_dim, cnn_hidden_dim
+        self.conv1 = nn.Conv2d(inp_dim, cnn_hidden_dim, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+        self.conv2 = nn.Conv2d(cnn_hidden_dim, cnn_hidden_dim, kernel_size=kernel, stride=stride, padding=padding,
+                               bias=False)
+        self.conv3 = nn.Conv2d(cnn_hidden_dim, out_dim, kernel_size=kernel, stride=stride, padding=padding, bias=False)
+        self.pooling1 = nn.AvgPool2d(kernel_size=(1, 3))
+        self.pooling2 = nn.AvgPool2d(kernel_size=(1, 4))
+        self.pad = padding
+        self.relu = nn.ReLU(inplace=True)
+        self.tanh = nn.Tanh()
+        self._packed = None
+        self._packed_key = None
+
+    def _streams(self, device, ca, cb):
+        key = (_param_key(self), str(device), ca, cb)
+        if self._packed is None or self._packed_key != key:
+            h = self.cnn_hidden_dim
+            if h % 16:
+                raise RuntimeError("CausCnnBlock: cnn_hidden_dim must be a multiple of 16")
+            self._packed = (ops.pack_conv3x3(self.conv1.weight, ca, cb, device),
+                            ops.pack_conv3x3(self.conv2.weight, h, 0, device),
+                            ops.pack_conv3x3(self.conv3.weight, h, 0, device))
+            self._packed_key = key
+        return self._packed
+
+    def run(self, xa, xb):
+        """Channel concatenation [xa | xb] of logical [nb, nf, nt, C] tensors -> [nb, nf, nt//12, ceil4(out_dim)]."""
+        _require_eval(self)
+        ca = xa.shape[3]
+        cb = 0 if xb is None else xb.shape[3]
+        if ca + cb != self.inp_dim:
+            raise RuntimeError("CausCnnBlock: %d + %d input channels, expected %d" % (ca, cb, self.inp_dim))
+        w1, w2, w3 = self._streams(xa.device, ca, cb)
+        y = ops.conv3x3_causal(xa, xb, w1, self.cnn_hidden_dim, "relu")
+        y = ops.avgpool_time(y, 3)
+        y = ops.conv3x3_causal(y, None, w2, self.cnn_hidden_dim, "relu")
+        y = ops.avgpool_time(y, 4)
+        return ops.conv3x3_causal(y, None, w3, self.out_dim, "tanh")
+
+    def forward(self, x):
+        """Reference signature: x [nb, inp_dim, nf, nt] -> [nb, out_dim, nf, nt // 12]."""
+        c = x.shape[1]
+        ca = c - c % 16
+        xl = x.permute(0, 2, 3, 1).contiguous()                      # channels-last (plumbing)
+        if ca == 0:
+            raise RuntimeError("CausCnnBlock: needs at least 16 input channels")
+        xa = xl[..., :ca]
+        xb = xl[..., ca:] if ca < c else None
+        y = self.run(xa, xb)
+        return y[..., :self.out_dim].permute(0, 3, 1, 2)
+
+
+class IPDnet(nn.Module):
+    """Fixed-array IPDnet: two FN blocks with input concat-skips and the causal conv head."""
+
+    def __init__(self, input_size=4, hidden_size=128, max_track=2, is_online=True, n_seg=312):
+        super(IPDnet, self).__init__()
+        self.is_online = is_online
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.block_1 = FNblock(input_size=self.input_size, hidden_size=self.hidden_size,
+                               add_skip_dim=self.input_size, is_online=self.is_online, is_first=True)
+        self.block_2 = FNblock(input_size=self.hidden_size, hidden_size=self.hidden_size,
+                               add_skip_dim=self.input_size, is_online=self.is_online, is_first=False)
+        self.cnn_out_dim = 2 * ((input_size // 2) - 1) * max_track
+        self.cnn_inp_dim = hidden_size + input_size
+        self.conv = CausCnnBlock(inp_dim=self.cnn_inp_dim, out_dim=self.cnn_out_dim)
+        self.n = n_seg
+
+    def forward(self, x, offline_inference=False):
+        _require_eval(self)
+        nb, nc, nf, nt = x.shape
+        if nc != self.input_size:
+            raise RuntimeError("IPDnet: %d input channels, expected %d" % (nc, self.input_size))
+        ou_frame = nt // 12
+        nseg = 1
+        if not self.is_online and offline_inference:
+            # chunk-wise offline inference (:96-100): zero-pad the time axis to a multiple of n and
+            # fold the segments into the batch
+            pad = (self.n - nt % self.n) % self.n
+            if pad:
+                x = torch.cat((x, x.new_zeros((nb, nc, nf, pad))), dim=3)
+            nseg = (nt + pad) // self.n
+            x = x.reshape(nb, nc, nf, nseg, self.n).permute(0, 3, 1, 2, 4).reshape(nb * nseg, nc, nf, self.n)
+            nb, nt = nb * nseg, self.n
+        xs = ops.nchw_to_seq(x)                                     # [nb, nt, nf, C]  (:93)
+        y = self.block_1.run(None, xs)
+        y = self.block_2.run(y, xs)                                 # logical [nb, nt, nf, Hn], stored [nb, nf, nt, Hn]
+        c = self.conv.run(y.permute(0, 2, 1, 3), xs.permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
+        nt2 = nt // 12
+        c = c[..., :self.cnn_out_dim].permute(0, 2, 1, 3)           # = conv(x).permute(0,3,2,1)  (:113)
+        c = c.reshape(nb, nt2, nf, 2, -1).permute(0, 1, 3, 2, 4)
+        if nseg > 1 or (not self.is_online and offline_inference):
+            c = c.reshape(nb // nseg, nt2 * nseg, 2, nf * 2, -1).permute(0, 1, 3, 4, 2)
+            return c[:, :ou_frame, :, :, :]
+        return c.reshape(nb, nt2, 2, nf * 2, -1).permute(0, 1, 3, 4, 2)

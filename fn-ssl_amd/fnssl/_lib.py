@@ -27,7 +27,8 @@ SYMBOLS = [
     "fnssl_abi_version", "fnssl_last_error", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
-    "fnssl_ipd2doa",
+    "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
+    "fnssl_avgpool_time",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
 ]
 
@@ -105,6 +106,11 @@ def load():
     lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
     lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
     lib.fnssl_ipd2doa.argtypes = [vp, ll, ll, ll, ll, vp, i, i, i, i, i, i, i, vp, vp, vp, vp]
+    lib.fnssl_conv3x3_packed_floats.argtypes = [i, i, i]
+    lib.fnssl_conv3x3_packed_floats.restype = sz
+    lib.fnssl_conv3x3_pack.argtypes = [vp, i, i, i, vp]
+    lib.fnssl_conv3x3_causal.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
+    lib.fnssl_avgpool_time.argtypes = [vp, i, i, i, i, vp, vp]
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz
     lib.fnssl_forward.argtypes = [C.POINTER(Net), vp, i, i, i, vp, vp, sz, i, vp]

@@ -235,6 +235,64 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
 
 
 # --------------------------------------------------------------------------- #
+# causal 3x3 conv + time pooling (IPDnet head)
+# --------------------------------------------------------------------------- #
+def pack_conv3x3(weight, ca: int, cb: int, device) -> torch.Tensor:
+    """Pack a Conv2d weight [cout, ca + cb, 3, 3] into the conv kernel's weight stream."""
+    w = np.ascontiguousarray(weight.detach().cpu().numpy() if isinstance(weight, torch.Tensor) else weight,
+                             dtype=np.float32)
+    cout = w.shape[0]
+    if w.shape != (cout, ca + cb, 3, 3):
+        raise RuntimeError("fnssl.pack_conv3x3: weight shape %s does not match [cout, %d + %d, 3, 3]"
+                           % (w.shape, ca, cb))
+    lib = _lib.load()
+    n = lib.fnssl_conv3x3_packed_floats(cout, ca, cb)
+    if n == 0:
+        raise RuntimeError("fnssl.pack_conv3x3: unsupported sizes cout=%d ca=%d cb=%d" % (cout, ca, cb))
+    out = np.empty(n, dtype=np.float32)
+    check(lib.fnssl_conv3x3_pack(w.ctypes.data_as(C.c_void_p), cout, ca, cb, out.ctypes.data_as(C.c_void_p)),
+          "conv3x3_pack")
+    return torch.from_numpy(out).to(device)
+
+
+def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none"):
+    """Causal 3x3 conv over (bin, time) of the channel concatenation [xa | xb].
+
+    xa / xb: logical [nb, nf, nt, C] tensors with arbitrary batch / bin / time strides and a
+    contiguous channel dimension (xb may be None).  Returns [nb, nf, nt, ceil4(cout)] channels-last
+    (padding channels are 0)."""
+    _need_dev(xa, xb, packed)
+    xa, xb = _conform(xa), _conform(xb)
+    nb, nf, nt, ca = xa.shape
+    cb = 0 if xb is None else xb.shape[3]
+    if xb is not None and tuple(xb.shape[:3]) != (nb, nf, nt):
+        raise RuntimeError("fnssl.conv3x3_causal: xb must match xa's [nb, nf, nt]")
+    if xa.stride(3) != 1 or (xb is not None and xb.stride(3) != 1):
+        raise RuntimeError("fnssl.conv3x3_causal: channel dimension must be contiguous")
+    cs = (cout + 3) // 4 * 4
+    out = torch.empty((nb, nf, nt, cs), dtype=torch.float32, device=xa.device)   # pad channels come out 0
+    sa = xa.stride()
+    sb_ = xb.stride() if xb is not None else (0, 0, 0, 1)
+    code = {"none": 0, "relu": 1, "tanh": 2}[act]
+    check(_lib.load().fnssl_conv3x3_causal(_ptr(xa), sa[0], sa[1], sa[2], ca,
+                                           _ptr(xb) if xb is not None else None, sb_[0], sb_[1], sb_[2], cb,
+                                           _ptr(packed), cout, nb, nf, nt, code, _ptr(out), cs, _stream()),
+          "conv3x3_causal")
+    return out
+
+
+def avgpool_time(x, k: int):
+    """[nb, nf, nt, C] channels-last -> [nb, nf, nt // k, C] (AvgPool2d((1, k)) of the NCHW view)."""
+    _need_dev(x)
+    x = x.contiguous()
+    nb, nf, nt, c = x.shape
+    y = torch.empty((nb, nf, nt // k, c), dtype=torch.float32, device=x.device)
+    if y.numel():
+        check(_lib.load().fnssl_avgpool_time(_ptr(x), nb * nf, nt, c, k, _ptr(y), _stream()), "avgpool_time")
+    return y
+
+
+# --------------------------------------------------------------------------- #
 # head / whole network
 # --------------------------------------------------------------------------- #
 def head(x, w, b):

@@ -93,3 +93,35 @@ def make_fnblock_state(seed: int, input_size: int, hidden_size: int = 256,
 
 def n_params(sd) -> int:
     return int(sum(v.size for v in sd.values()))
+
+
+# --------------------------------------------------------------------------- #
+# IPDnet (fixed array), reference IPDnet/FixedAarryIPDnet.py:7-90
+# --------------------------------------------------------------------------- #
+def ipdnet_param_shapes(input_size: int = 4, hidden_size: int = 128, max_track: int = 2, is_online: bool = True):
+    """(name, shape) list of IPDnet: two concat-skip FN blocks + a 3-layer causal Conv2d head."""
+    fh = hidden_size // 2
+    nh = hidden_size if is_online else hidden_size // 2
+    out = []
+    for bi, full_in in ((1, input_size), (2, hidden_size + input_size)):
+        out += [("block_%d.fullLstm.%s" % (bi, n), s) for n, s in lstm_param_shapes(full_in, fh, True)]
+        out += [("block_%d.narrLstm.%s" % (bi, n), s)
+                for n, s in lstm_param_shapes(2 * fh + input_size, nh, not is_online)]
+    cout = 2 * ((input_size // 2) - 1) * max_track
+    cin = hidden_size + input_size
+    out += [("conv.conv1.weight", (128, cin, 3, 3)), ("conv.conv2.weight", (128, 128, 3, 3)),
+            ("conv.conv3.weight", (cout, 128, 3, 3))]
+    return out
+
+
+def make_ipdnet_state(seed: int = 0, input_size: int = 4, hidden_size: int = 128, max_track: int = 2,
+                      is_online: bool = True):
+    rs = np.random.RandomState(seed)
+    sd = collections.OrderedDict()
+    for name, shape in ipdnet_param_shapes(input_size, hidden_size, max_track, is_online):
+        if "_l0" in name:
+            b = 1.0 / np.sqrt(shape[0] // GATES)
+        else:                                   # Conv2d default init: U(+-1/sqrt(fan_in))
+            b = 1.0 / np.sqrt(shape[1] * shape[2] * shape[3])
+        sd[name] = rs.uniform(-b, b, size=shape).astype(np.float32)
+    return sd

@@ -188,6 +188,33 @@ int fnssl_ipd2doa(const float* pred, long long sb, long long sp, long long st, l
                   int ncand, int nsrc, int unk_num, float* ss, int* idx, float* vad, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* IPDnet head (next row 8f-3): causal 3x3 Conv2d + time pooling              */
+/* ------------------------------------------------------------------------- */
+
+/* Floats of the packed weight stream for Conv2d(ca + cb -> cout, 3x3); 0 if unsupported
+ * (cout <= 128, ca % 16 == 0, cb % 4 == 0). */
+size_t fnssl_conv3x3_packed_floats(int cout, int ca, int cb);
+
+/* Host-only: pack a PyTorch Conv2d weight [cout, ca + cb, 3, 3] for fnssl_conv3x3_causal. */
+int fnssl_conv3x3_pack(const float* w, int cout, int ca, int cb, float* packed);
+
+/*
+ * Replaces one conv stage of CausCnnBlock.forward (IPDnet/FixedAarryIPDnet.py:61-73):
+ * Conv2d(k = 3x3, padding (1, 2), bias = False) -> activation -> crop the last 2 time steps,
+ * i.e. out[b, f, t, :] = act( sum_{df, dt, c} W[:, c, df, dt] * x[b, f+df-1, t+dt-2, c] ).
+ * The input is the channel concatenation [xa (ca channels) | xb (cb channels)] of two
+ * channels-last tensors; element (b, f, t, c) of xa lives at xa[b*a_sb + f*a_sf + t*a_st + c].
+ *   act: 0 none, 1 ReLU, 2 tanh;  out [nb, nf, nt, cout_stride] channels-last (cout valid).
+ */
+int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca,
+                         const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
+                         const float* wpack, int cout, int nb, int nf, int nt, int act,
+                         float* out, int cout_stride, void* stream);
+
+/* y[row, t2, c] = mean_{k < K} x[row, K*t2 + k, c]   (AvgPool2d((1, K)); c % 4 == 0). */
+int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Whole network (replaces FN_SSL.forward, FN-SSL/Model.py:72-90)             */
 /* ------------------------------------------------------------------------- */
 

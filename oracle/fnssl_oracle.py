@@ -359,3 +359,75 @@ def pred_to_doa(pred: np.ndarray, nb: int, mic_location, ch_mode: str = "MM", ma
     rebatch = np.transpose(remove_ch_from_batch(pred, nb), (0, 2, 3, 1))           # [nb, nt, 2nf, np]
     doa, vad, ss = source_detect_localize(rebatch, bank, cand, max_num_sources, source_num_mode)
     return {"doa": doa, "vad_sources": vad, "spatial_spectrum": ss}
+
+
+# --------------------------------------------------------------------------- #
+# IPDnet, fixed array.  Reference IPDnet/FixedAarryIPDnet.py
+# --------------------------------------------------------------------------- #
+def ipdnet_block(sd, prefix, x, skip, is_online):
+    """IPDnet FNblock.forward (eval), FixedAarryIPDnet.py:29-40.  x [nb, nt, nf, C], skip [nb, nt, nf, Cs]:
+    full-band BiLSTM, concat skip, narrow-band LSTM, concat skip -> [nb, nt, nf, Hn + Cs]."""
+    nb, nt, nf, _ = x.shape
+    f = lstm(x.reshape(nb * nt, nf, -1), sd, prefix + "fullLstm.", True)                         # :31-32
+    v = np.concatenate([f, skip.reshape(nb * nt, nf, -1)], axis=-1)                              # :34
+    v = np.transpose(v.reshape(nb, nt, nf, -1), (0, 2, 1, 3)).reshape(nb * nf, nt, -1)           # :35
+    n = lstm(v, sd, prefix + "narrLstm.", not is_online)                                         # :36
+    n = np.concatenate([n, np.transpose(skip, (0, 2, 1, 3)).reshape(nb * nf, nt, -1)], axis=-1)  # :38
+    return np.ascontiguousarray(np.transpose(n.reshape(nb, nf, nt, -1), (0, 2, 1, 3)))           # :39
+
+
+def conv3x3_pad12(x, w):
+    """nn.Conv2d(k=3x3, stride 1, padding (1, 2), bias=False) on x [nb, Cin, F, T] -> [nb, Cout, F, T + 2]."""
+    nb, cin, F, T = x.shape
+    xp = np.zeros((nb, cin, F + 2, T + 4), dtype=F32)
+    xp[:, :, 1:F + 1, 2:T + 2] = x
+    out = np.zeros((nb, w.shape[0], F, T + 2), dtype=F32)
+    for df in range(3):
+        for dt in range(3):
+            patch = xp[:, :, df:df + F, dt:dt + T + 2]                     # [nb, cin, F, T+2]
+            out += np.einsum("oc,bcft->boft", w[:, :, df, dt].astype(F32), patch, optimize=True).astype(F32)
+    return out
+
+
+def avgpool_t(x, k):
+    """nn.AvgPool2d((1, k)) on [nb, C, F, T] (floors)."""
+    nb, c, F, T = x.shape
+    t2 = T // k
+    return (x[:, :, :, :t2 * k].reshape(nb, c, F, t2, k).sum(axis=4, dtype=F32) / F32(k)).astype(F32)
+
+
+def caus_cnn_block(sd, prefix, x):
+    """CausCnnBlock.forward, FixedAarryIPDnet.py:61-73.  x [nb, Cin, F, T] -> [nb, Cout, F, T // 12]."""
+    out = np.maximum(conv3x3_pad12(x, sd[prefix + "conv1.weight"]), 0)[:, :, :, :-2]
+    out = avgpool_t(out, 3)
+    out = np.maximum(conv3x3_pad12(out, sd[prefix + "conv2.weight"]), 0)[:, :, :, :-2]
+    out = avgpool_t(out, 4)
+    out = conv3x3_pad12(out, sd[prefix + "conv3.weight"])[:, :, :, :-2]
+    return np.tanh(out, dtype=F32)
+
+
+def ipdnet_forward(sd, x, is_online=True, n_seg=0):
+    """IPDnet.forward, FixedAarryIPDnet.py:91-120.  x [nb, 2*nch, nf, nt] -> [nb, nt // 12, 2*nf, nch - 1, max_track].
+    n_seg > 0 (offline networks only) = chunk-wise inference (offline_inference=True, :96-100, :114-116):
+    the time axis is zero-padded to a multiple of n_seg and the segments are processed independently."""
+    x = np.transpose(np.asarray(x, dtype=F32), (0, 3, 2, 1))                  # [nb, nt, nf, C]
+    nb, nt, nf, _ = x.shape
+    if n_seg > 0 and not is_online:
+        ou_frame = nt // 12
+        pad = (n_seg - nt % n_seg) % n_seg                                    # utils_.pad_segments :152-159
+        xp = np.concatenate([x, np.zeros((nb, pad, nf, x.shape[3]), dtype=F32)], axis=1)
+        nseg = (nt + pad) // n_seg
+        xs = xp.reshape(nb * nseg, n_seg, nf, -1)                             # :98-99
+        ys = ipdnet_forward(sd, np.transpose(xs, (0, 3, 2, 1)), is_online)    # [nb*nseg, nt2, 2nf, P, 2]
+        nt2 = n_seg // 12
+        # undo the final permute, regroup segments along time (:115), redo it
+        c = np.transpose(ys, (0, 1, 4, 2, 3)).reshape(nb, nseg * nt2, 2, 2 * nf, -1)
+        return np.ascontiguousarray(np.transpose(c, (0, 1, 3, 4, 2))[:, :ou_frame])
+    y = ipdnet_block(sd, "block_1.", x, x, is_online)
+    y = ipdnet_block(sd, "block_2.", y, x, is_online)
+    y = np.transpose(y, (0, 3, 2, 1))                                         # [nb, C', nf, nt]
+    nt2 = nt // 12
+    c = caus_cnn_block(sd, "conv.", y)                                        # [nb, Cout, nf, nt2]
+    c = np.transpose(c, (0, 3, 2, 1)).reshape(nb, nt2, nf, 2, -1)             # :113
+    c = np.transpose(c, (0, 1, 3, 2, 4))                                      # [nb, nt2, 2, nf, K]
+    return np.ascontiguousarray(np.transpose(c.reshape(nb, nt2, 2, nf * 2, -1), (0, 1, 3, 4, 2)))   # :118

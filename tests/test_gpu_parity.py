@@ -429,3 +429,184 @@ def test_waveform_to_doa_end_to_end(dev):
     want = O.pred_to_doa(O.predict_step(sd, batch, "MM", True), 2, np.array(((-0.04, 0, 0), (0.04, 0, 0))))
     np.testing.assert_array_equal(out["doa"].cpu().numpy(), want["doa"])
     assert_close(out["spatial_spectrum"].cpu().numpy(), want["spatial_spectrum"], 1e-4, 1e-5, "spectrum")
+
+
+# --------------------------------------------------------------------------- IPDnet row (SURVEY §8f-3)
+def _ipdnet_module():
+    import importlib.util
+    import os
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(here, "fn-ssl_amd", "IPDnet", "FixedAarryIPDnet.py")
+    if "fnssl_ipdnet_dropin" in sys.modules:
+        return sys.modules["fnssl_ipdnet_dropin"]
+    spec = importlib.util.spec_from_file_location("fnssl_ipdnet_dropin", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["fnssl_ipdnet_dropin"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _oracle_conv(xa, xb, w, act):
+    """[nb, nf, nt, C] channels-last operands -> causal conv, channels-last."""
+    from oracle import fnssl_oracle as O
+    x = xa if xb is None else np.concatenate([xa, xb], axis=-1)
+    y = O.conv3x3_pad12(np.transpose(x, (0, 3, 1, 2)), w)[:, :, :, :-2]
+    if act == "relu":
+        y = np.maximum(y, 0)
+    elif act == "tanh":
+        y = np.tanh(y)
+    return np.transpose(y, (0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("cout,ca,cb,nb,nf,nt,act", [
+    (128, 16, 4, 2, 5, 23, "relu"),      # conv1 of the 2-mic network, ragged time tile
+    (128, 32, 16, 1, 3, 40, "none"),     # segment B with a full 16-channel block
+    (128, 128, 0, 1, 4, 16, "relu"),     # conv2
+    (6, 128, 0, 2, 3, 5, "tanh"),        # conv3, cout not a multiple of 4, nt < 3 taps + tile
+    (28, 128, 0, 1, 1, 33, "tanh"),      # 8-mic head, a single frequency row
+    (64, 16, 12, 1, 2, 17, "none"),      # 4-tile kernel with a 3-block remainder
+])
+def test_conv3x3_causal_matches_oracle(dev, cout, ca, cb, nb, nf, nt, act):
+    from fnssl import ops
+    w = rs_randn(2100 + cout + ca, (cout, ca + cb, 3, 3), 0.1)
+    xa = rs_randn(2200, (nb, nf, nt, ca))
+    xb = rs_randn(2201, (nb, nf, nt, cb)) if cb else None
+    packed = ops.pack_conv3x3(w, ca, cb, dev)
+    got = ops.conv3x3_causal(to_dev(xa, dev), to_dev(xb, dev) if cb else None, packed, cout, act)
+    assert got.shape == (nb, nf, nt, (cout + 3) // 4 * 4)
+    got = got.cpu().numpy()
+    assert_close(got[..., :cout], _oracle_conv(xa, xb, w, act), RTOL, ATOL, "conv3x3")
+    assert not got[..., cout:].any(), "padding channels must be zero"
+
+
+def test_conv3x3_reads_strided_operands_in_place(dev):
+    """The head reads the narrow-band output ([nb, nf, nt, C]) and the network input (stored
+    [nb, nt, nf, C]) through strides; results equal the contiguous call bit for bit."""
+    from fnssl import ops
+    nb, nf, nt, ca, cb, cout = 2, 4, 19, 32, 4, 128
+    w = rs_randn(2300, (cout, ca + cb, 3, 3), 0.1)
+    packed = ops.pack_conv3x3(w, ca, cb, dev)
+    xa = to_dev(rs_randn(2301, (nb, nf, nt, ca)), dev)
+    xb_store = to_dev(rs_randn(2302, (nb, nt, nf, cb)), dev)
+    xb = xb_store.permute(0, 2, 1, 3)
+    wide = to_dev(rs_randn(2303, (nb, nf, nt, ca + 16)), dev)
+    wide[..., :ca] = xa
+    a = ops.conv3x3_causal(xa, xb.contiguous(), packed, cout, "relu")
+    b = ops.conv3x3_causal(wide[..., :ca], xb, packed, cout, "relu")
+    assert torch.equal(a, b)
+
+
+def test_conv3x3_and_pool_reject_bad_arguments(dev):
+    from fnssl import _lib, ops
+    with pytest.raises(RuntimeError, match="unsupported sizes"):
+        ops.pack_conv3x3(np.zeros((129, 16, 3, 3), np.float32), 16, 0, dev)
+    with pytest.raises(RuntimeError, match="unsupported sizes"):
+        ops.pack_conv3x3(np.zeros((8, 20, 3, 3), np.float32), 20, 0, dev)        # ca must be a multiple of 16
+    with pytest.raises(RuntimeError, match="does not match"):
+        ops.pack_conv3x3(np.zeros((8, 20, 3, 3), np.float32), 16, 8, dev)
+    x = torch.zeros((1, 2, 8, 16), device=dev)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_causal(x.cpu(), None, x, 8)
+    lib = _lib.load()
+    assert lib.fnssl_avgpool_time(None, 1, 1, 4, 1, None, None) != 0
+    assert b"avgpool_time" in lib.fnssl_last_error()
+
+
+def test_avgpool_time_matches_oracle(dev):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    x = rs_randn(2400, (2, 3, 26, 8))
+    for k in (3, 4):
+        got = ops.avgpool_time(to_dev(x, dev), k).cpu().numpy()
+        want = np.transpose(O.avgpool_t(np.transpose(x, (0, 3, 1, 2)), k), (0, 2, 3, 1))
+        assert_close(got, want, 1e-6, 1e-7, "avgpool k=%d" % k)
+    assert ops.avgpool_time(to_dev(x[:, :, :2], dev), 3).shape == (2, 3, 0, 8)
+
+
+def test_causcnnblock_golden(dev):
+    M = _ipdnet_module()
+    g = load_golden("g10_ipdnet")
+    blk = M.CausCnnBlock(inp_dim=20, out_dim=6).eval()
+    sdc = {"conv%d.weight" % (i + 1): torch.from_numpy(rs_randn(1700 + i, s, 0.1)) for i, s in
+           enumerate([(128, 20, 3, 3), (128, 128, 3, 3), (6, 128, 3, 3)])}
+    blk.load_state_dict(sdc)
+    blk.to(dev)
+    got = blk(to_dev(rs_randn(1710, (2, 20, 7, 26)), dev))
+    assert_close(got.cpu().numpy(), g["cnn_out"], RTOL, ATOL, "CausCnnBlock vs reference golden")
+
+
+def test_ipdnet_golden(dev):
+    """IPDnet.forward against outputs of the real reference (2-mic online/offline, 8-mic hidden 256,
+    257-like wide band) and against the oracle."""
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    M = _ipdnet_module()
+    g = load_golden("g10_ipdnet")
+    ci = 0
+    while "c%d_cfg" % ci in g:
+        cfg = [int(v) for v in g["c%d_cfg" % ci]]
+        isz, hid, mt, online, wseed, xseed = cfg[:6]
+        shape = tuple(cfg[6:])
+        sd = W.make_ipdnet_state(wseed, isz, hid, mt, bool(online))
+        net = M.IPDnet(input_size=isz, hidden_size=hid, max_track=mt, is_online=bool(online)).eval()
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        net.to(dev)
+        x = rs_randn(xseed, shape)
+        got = net(to_dev(x, dev)).cpu().numpy()
+        assert_close(got, g["c%d_out" % ci], RTOL, ATOL, "IPDnet case %d vs reference golden" % ci)
+        assert_close(got, O.ipdnet_forward(sd, x, bool(online)), RTOL, ATOL, "IPDnet case %d vs oracle" % ci)
+        ci += 1
+    assert ci == 4
+
+
+def test_ipdnet_chunkwise_offline_inference_golden(dev):
+    from fnssl import weights as W
+    M = _ipdnet_module()
+    g = load_golden("g10_ipdnet")
+    sd = W.make_ipdnet_state(1520, 4, 128, 2, False)
+    net = M.IPDnet(input_size=4, hidden_size=128, max_track=2, is_online=False, n_seg=24).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev)
+    got = net(to_dev(rs_randn(1620, (2, 4, 16, 40)), dev), offline_inference=True)
+    assert_close(got.cpu().numpy(), g["seg_out"], RTOL, ATOL, "chunk-wise offline inference")
+
+
+def test_ipdnet_fnblock_reference_signature(dev):
+    """FNblock.forward(x, fb_skip, nb_skip) of the IPDnet tree returns the concatenated tensor."""
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    M = _ipdnet_module()
+    sd = W.make_ipdnet_state(2500, 4, 128, 2, True)
+    nb, nt, nf = 2, 12, 9
+    x = rs_randn(2501, (nb, nt, nf, 4))
+    b1 = M.FNblock(input_size=4, hidden_size=128, add_skip_dim=4, is_online=True, is_first=True).eval()
+    b2 = M.FNblock(input_size=128, hidden_size=128, add_skip_dim=4, is_online=True, is_first=False).eval()
+    for blk, pre in ((b1, "block_1."), (b2, "block_2.")):
+        blk.load_state_dict({k[len(pre):]: torch.from_numpy(v.copy()) for k, v in sd.items() if k.startswith(pre)})
+        blk.to(dev)
+    xd = to_dev(x, dev)
+    fb = xd.reshape(nb * nt, nf, 4)
+    nbs = xd.permute(0, 2, 1, 3).reshape(nb * nf, nt, 4)
+    y1 = b1(xd, fb, nbs)
+    y2 = b2(y1, fb, nbs)
+    w1 = O.ipdnet_block(sd, "block_1.", x, x, True)
+    w2 = O.ipdnet_block(sd, "block_2.", w1, x, True)
+    assert_close(y1.cpu().numpy(), w1, RTOL, ATOL, "block_1")
+    assert_close(y2.cpu().numpy(), w2, RTOL, ATOL, "block_2")
+
+
+def test_ipdnet_config3_shape_smoke(dev):
+    """BASELINE.json config 3 geometry at a reduced batch: 8 mics, hidden 256, 257 bins, 48 frames."""
+    from fnssl import weights as W
+    M = _ipdnet_module()
+    sd = W.make_ipdnet_state(2600, 16, 256, 2, True)
+    net = M.IPDnet(input_size=16, hidden_size=256, max_track=2, is_online=True).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev)
+    x = to_dev(rs_randn(2601, (2, 16, 257, 48)), dev)
+    y = net(x)
+    assert y.shape == (2, 4, 514, 7, 2)
+    assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
+    # utterances are independent: a batch of one gives the same rows bit for bit
+    assert torch.equal(net(x[1:2]), y[1:2])

@@ -98,3 +98,23 @@ def test_checkpoint_key_names_match_reference():
         want = dict(W.fnssl_param_shapes(is_online=online))
         assert {k: tuple(v.shape) for k, v in sd.items()} == want
     assert list(at_model.FN_lightning().state_dict())[0].startswith("arch.block_1.fullLstm.")
+
+
+def test_ipdnet_dropin_state_dict_matches_reference_names():
+    """Checkpoint compatibility of the IPDnet drop-in: parameter names and shapes are the reference's
+    (weights.ipdnet_param_shapes was checked against the real reference when g10 was generated)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from fnssl import weights as W
+    spec = importlib.util.spec_from_file_location(
+        "fnssl_ipdnet_dropin_cpu", os.path.join(ROOT, "fn-ssl_amd", "IPDnet", "FixedAarryIPDnet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for isz, hid, mt, online in [(4, 128, 2, True), (16, 256, 2, True), (8, 256, 3, False)]:
+        net = mod.IPDnet(input_size=isz, hidden_size=hid, max_track=mt, is_online=online)
+        got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        want = {k: tuple(s) for k, s in W.ipdnet_param_shapes(isz, hid, mt, online)}
+        assert got == want
+    with __import__("pytest").raises(RuntimeError, match="eval"):
+        net(__import__("torch").zeros(1, 8, 4, 12))

@@ -169,3 +169,25 @@ def test_g12_doa_backend():
     np.testing.assert_array_equal(doa, g["m4_doa"])
     assert_close(vad, g["m4_vad"], 1e-4, 1e-6, "4-mic vad")
     assert_close(ss, g["m4_ss"], 1e-5, 1e-6, "4-mic ss")
+
+
+# --- IPDnet (fixed array) ------------------------------------------------------------------------------
+def test_g10_ipdnet():
+    g = load_golden("g10_ipdnet")
+    ci = 0
+    while "c%d_cfg" % ci in g:
+        cfg = [int(v) for v in g["c%d_cfg" % ci]]
+        isz, hid, mt, online, wseed, xseed = cfg[:6]
+        shape = tuple(cfg[6:])
+        sd = W.make_ipdnet_state(wseed, isz, hid, mt, bool(online))
+        got = O.ipdnet_forward(sd, rs_randn(xseed, shape), bool(online))
+        assert got.shape == g["c%d_out" % ci].shape, ci
+        assert_close(got, g["c%d_out" % ci], 1e-4, 1e-5, "ipdnet case %d" % ci)
+        ci += 1
+    assert ci == 4
+    sd = W.make_ipdnet_state(1520, 4, 128, 2, False)
+    assert_close(O.ipdnet_forward(sd, rs_randn(1620, (2, 4, 16, 40)), False, n_seg=24), g["seg_out"], 1e-4, 1e-5,
+                 "ipdnet chunk-wise offline inference")
+    sdc = {"c.conv%d.weight" % (i + 1): rs_randn(1700 + i, s, 0.1) for i, s in
+           enumerate([(128, 20, 3, 3), (128, 128, 3, 3), (6, 128, 3, 3)])}
+    assert_close(O.caus_cnn_block(sdc, "c.", rs_randn(1710, (2, 20, 7, 26))), g["cnn_out"], 1e-4, 1e-5, "cnn block")

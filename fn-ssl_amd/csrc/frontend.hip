@@ -192,6 +192,50 @@ nchw_to_seq_kernel(const float* __restrict__ x, int c, int nf, int nt, float* __
   }
 }
 
+// ---- all-channel ("array") features of IPDnet (reference IPDnet/runIPDnetOn.py:240-254) ----------
+// mu[b, t]: the same recursion on the mean magnitude over ALL channels and the 257 bins.
+__global__ void ema_array_kernel(const float* __restrict__ magsum, const float* __restrict__ ca,
+                                 const float* __restrict__ cb, int nb, int nch, int nt, float* __restrict__ mu) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const float* s = magsum + (long long)b * nch * nt;
+  const float cnt = (float)(nch * kBins);
+  float m = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    float acc = s[t];
+    for (int c = 1; c < nch; ++c) acc = __fadd_rn(acc, s[(long long)c * nt + t]);
+    const float mean = __fdiv_rn(acc, cnt);
+    m = __fadd_rn(__fmul_rn(ca[t], m), __fmul_rn(cb[t], mean));
+    mu[(long long)b * nt + t] = m;
+  }
+}
+
+// x[b, t, f, :] = [Re ch 0..nch-1, Im ch 0..nch-1](bin f+1) / (mu + eps)
+template <int LAYOUT>
+__global__ void __launch_bounds__(256)
+pack_array_kernel(const float2* __restrict__ spec, const float* __restrict__ mu, int nch, int nt, float eps,
+                  float* __restrict__ x) {
+  const long long row = blockIdx.x;   // (b, t)
+  const int f = threadIdx.x;
+  const int t = (int)(row % nt);
+  const long long b = row / nt;
+  const float den = __fadd_rn(mu[row], eps);
+  for (int c = 0; c < nch; ++c) {
+    const float2 v = spec[((b * nch + c) * nt + t) * kBins + f + 1];
+    const float re = __fdiv_rn(v.x, den), im = __fdiv_rn(v.y, den);
+    if (LAYOUT == 0) {
+      float* o = x + (row * kNF + f) * (2 * nch);
+      o[c] = re;
+      o[nch + c] = im;
+    } else {
+      float* o = x + b * 2 * nch * (long long)kNF * nt + (long long)f * nt + t;
+      const long long cs = (long long)kNF * nt;
+      o[c * cs] = re;
+      o[(nch + c) * cs] = im;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -265,6 +309,33 @@ int fnssl_pair_features(const float* spec, const float* magsum, const float* coe
       hipLaunchKernelGGL(pack_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st,
                          reinterpret_cast<const float2*>(spec), mu, nb, nch, np, nt, ch_mode, eps, x);
     FNSSL_CHECK_LAUNCH("pack_kernel");
+  }
+  return FNSSL_OK;
+}
+
+int fnssl_array_features(const float* spec, const float* magsum, const float* coef_a, const float* coef_b,
+                         int nb, int nch, int nt, float eps, float* mu, float* x, int layout, void* stream) {
+  FNSSL_REQUIRE(spec && magsum && coef_a && coef_b && mu && x, "array_features: null pointer");
+  FNSSL_REQUIRE(layout == 0 || layout == 1, "array_features: layout %d", layout);
+  FNSSL_REQUIRE(nb > 0 && nt > 0 && nch > 0, "array_features: empty problem");
+  hipStream_t st = fnssl::as_stream(stream);
+  {
+    fnssl::TimedLaunch tl("ema", st);
+    hipLaunchKernelGGL(ema_array_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, magsum, coef_a, coef_b, nb, nch, nt,
+                       mu);
+    FNSSL_CHECK_LAUNCH("ema_array_kernel");
+  }
+  {
+    fnssl::TimedLaunch tl("pack", st);
+    const long long rows = (long long)nb * nt;
+    FNSSL_REQUIRE(rows < (1ll << 31), "array_features: too many rows");
+    if (layout == 0)
+      hipLaunchKernelGGL(pack_array_kernel<0>, dim3((unsigned)rows), dim3(256), 0, st,
+                         reinterpret_cast<const float2*>(spec), mu, nch, nt, eps, x);
+    else
+      hipLaunchKernelGGL(pack_array_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st,
+                         reinterpret_cast<const float2*>(spec), mu, nch, nt, eps, x);
+    FNSSL_CHECK_LAUNCH("pack_array_kernel");
   }
   return FNSSL_OK;
 }

@@ -182,6 +182,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
       int rc = kNoStatic;
       if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
       if (H == 256) rc = launch_static_h256(p, mode, vr.NW, nwg, st);
+      if (rc == kNoStatic && !env_int("FNSSL_NO_STATIC_IPDNET", 1, 1)) rc = launch_static_ipdnet(p, mode, H, vr.NW, nwg, st);
       if (rc != kNoStatic) return rc;
     }
     p.chq = 0;

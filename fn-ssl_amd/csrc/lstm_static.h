@@ -35,13 +35,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // so the slice-end work of one group (cell update, stores, accumulator re-init, first x loads)
 // overlaps with the other group's MFMAs instead of idling the matrix pipe for everybody at once.
 template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
-          bool STAG = false>
+          bool STAG = false, int NV2 = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p) {
   constexpr int NS = H / 16;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
   static_assert(!(MODE & kHas1), "static kernel: single summed input only");
-  static_assert(HAS2 == (NS2 > 0), "NS2 must match the mode");
-  constexpr int QPS = 1 + NV0 + NS0 + NS2 + NS;        // real quads per slice
+  static_assert(HAS2 == (NS2 + NV2 > 0), "NS2 / NV2 must match the mode");
+  constexpr int QPS = 1 + NV0 + NS0 + NV2 + NS2 + NS;  // real quads per slice
   constexpr int VQ = QPS + PAD;                         // virtual quads per slice
   static_assert(VQ % CHQ == 0, "chunks must tile the (padded) slice");
   constexpr int CH = 4 * CHQ;                           // records per chunk
@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   unsigned vo0 = 0, vo2 = 0, voo = 0, vok = 0, voo2 = 0;
   const rsrc_t rx0 = split_addr(p.src0.p, qo * p.src0.so + qi * p.src0.si, 4 * g, vo0);
   const rsrc_t rx2 = HAS2 ? split_addr(p.src2.p, qo * p.src2.so + qi * p.src2.si, g, vo2) : rx0;
+  const unsigned vo2v = vo2 + 12 * g;   // 16-channel blocks of the concatenated input: lane (n, g) reads 4g..4g+3
   const rsrc_t rsk = SUM ? split_addr(p.skip.p, qo * p.skip.so + qi * p.skip.si, dir * H + 4 * g, vok) : rx0;
   const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
   const rsrc_t ro2 = SUM ? split_addr(p.out_sum, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo2) : ro;
@@ -192,9 +193,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
     const unsigned tt = rev ? p.nsteps - 1 - step : step;
     const unsigned ttn = step + 1 < p.nsteps ? (rev ? tt - 1 : tt + 1) : tt;
     const unsigned o0 = tt * st0, o2 = tt * st2, oo = tt * sto, ok = tt * stk;
-    float xs0 = 0.f, xs2 = 0.f;
-    if (NS0) xs0 = bld1(rx0, vo0, o0 + 64 * NV0);
-    if (NS2) xs2 = bld1(rx2, vo2, o2);
+    float xs0[NS0 > 0 ? NS0 : 1], xs2[NS2 > 0 ? NS2 : 1];   // 4-channel remainder blocks: lane (n, g) holds channel 4u + g
+    static_for<NS0>([&](auto u) { xs0[u.value] = bld1(rx0, vo0, o0 + 64 * NV0 + 16 * u.value); });
+    static_for<NS2>([&](auto u) { xs2[u.value] = bld1(rx2, vo2, o2 + 64 * NV2 + 16 * u.value); });
+    v4f xv2[NV2 > 0 ? NV2 : 1];   // the concatenated input is the same for every slice: held for the whole step
+    static_for<NV2>([&](auto v) { xv2[v.value] = bld4(rx2, vo2v, o2 + 64 * v.value); });
     if (step > 0 && !(abl & 32)) {
       const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
 #pragma unroll
@@ -228,12 +231,16 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       // registers they reuse), still a whole recurrent part ahead of their use
       if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
       if (SUM && !(abl & 16)) skipv = bld4(rsk, vok, ok + 64 * s);
-      if constexpr (NS0 > 0) SQUAD1(1 + NV0, xs0);
-      if constexpr (NS2 > 0) SQUAD1(1 + NV0 + NS0, xs2);
+      static_for<NS0>([&](auto u) { SQUAD1(1 + NV0 + decltype(u)::value, xs0[decltype(u)::value]); });
+      static_for<NV2>([&](auto v) {
+        constexpr int V = decltype(v)::value;
+        SQUAD(1 + NV0 + NS0 + V, xv2[V].x, xv2[V].y, xv2[V].z, xv2[V].w);
+      });
+      static_for<NS2>([&](auto u) { SQUAD1(1 + NV0 + NS0 + NV2 + decltype(u)::value, xs2[decltype(u)::value]); });
       // recurrent part
       static_for<NS>([&](auto sp) {
         constexpr int SP = decltype(sp)::value;
-        SQUAD(1 + NV0 + NS0 + NS2 + SP, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
+        SQUAD(1 + NV0 + NS0 + NV2 + NS2 + SP, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
       });
       // ring padding
       static_for<PAD>([&](auto u) {
@@ -274,11 +281,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
 }
 
 template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
-          bool STAG = false>
+          bool STAG = false, int NV2 = 0>
 int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
   const size_t lds = (size_t)(STAG ? 3 : 2) * CHQ * 4096;
   static_assert((STAG ? 3 : 2) * CHQ * 4096 <= 160 * 1024, "ring does not fit the LDS");
-  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL, XD, STAG>;
+  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL, XD, STAG, NV2>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -291,5 +298,6 @@ int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
 constexpr int kNoStatic = -100;
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
+int launch_static_ipdnet(const LstmParams& p, int mode, int H, int NW, int nwg, hipStream_t st);
 
 }  // namespace fnssl_lstm

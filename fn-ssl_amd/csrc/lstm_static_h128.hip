@@ -5,15 +5,15 @@
 namespace fnssl_lstm {
 
 #define TRY(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_)                                              \
-  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                  \
+  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && NS2_ < 4 && mode == (MODE_))                  \
     return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_>(p, nwg, st);
 
 #define TRYS(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_)                                             \
-  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                \
+  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && NS2_ < 4 && mode == (MODE_))                \
     return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, 4, true>(p, nwg, st);
 
 #define TRYX(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, XD_)                                        \
-  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && mode == (MODE_))                \
+  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && NS2_ < 4 && mode == (MODE_))                \
     return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, XD_>(p, nwg, st);
 
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st) {

@@ -28,7 +28,7 @@ SYMBOLS = [
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
-    "fnssl_avgpool_time",
+    "fnssl_avgpool_time", "fnssl_array_features",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
 ]
 
@@ -106,6 +106,7 @@ def load():
     lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
     lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
     lib.fnssl_ipd2doa.argtypes = [vp, ll, ll, ll, ll, vp, i, i, i, i, i, i, i, vp, vp, vp, vp]
+    lib.fnssl_array_features.argtypes = [vp, vp, vp, vp, i, i, i, C.c_float, vp, vp, i, vp]
     lib.fnssl_conv3x3_packed_floats.argtypes = [i, i, i]
     lib.fnssl_conv3x3_packed_floats.restype = sz
     lib.fnssl_conv3x3_pack.argtypes = [vp, i, i, i, vp]

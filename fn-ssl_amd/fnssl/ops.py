@@ -107,6 +107,27 @@ def preprocess(sig, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int =
     return x
 
 
+def array_features(spec, magsum, eps: float = 1e-6, sample_length: int = 280, layout: int = 1):
+    """IPDnet's all-channel features (runIPDnetOn.py:246-254).  Returns (x, mu); x is
+    [nb, 2*nch, 256, nt] (layout 1, the reference's tensor) or [nb, nt, 256, 2*nch] (layout 0)."""
+    _need_dev(spec, magsum)
+    nb, nch, nt = magsum.shape
+    ca, cb = forgetting_coefs(nt, sample_length, spec.device)
+    mu = torch.empty((nb, nt), dtype=torch.float32, device=spec.device)
+    shape = (nb, nt, NF, 2 * nch) if layout == 0 else (nb, 2 * nch, NF, nt)
+    x = torch.empty(shape, dtype=torch.float32, device=spec.device)
+    check(_lib.load().fnssl_array_features(_ptr(spec), _ptr(magsum), _ptr(ca), _ptr(cb), nb, nch, nt, eps,
+                                           _ptr(mu), _ptr(x), layout, _stream()), "array_features")
+    return x, mu
+
+
+def preprocess_array(sig, eps: float = 1e-6, sample_length: int = 280, layout: int = 1):
+    """Waveforms [nb, ns, nch] -> IPDnet input features (runIPDnetOn.py:237-254)."""
+    spec, magsum = stft(sig)
+    x, _ = array_features(spec, magsum, eps, sample_length, layout)
+    return x
+
+
 def nchw_to_seq(x):
     """[n, c, nf, nt] -> [n, nt, nf, c] (Model.py:73) as a contiguous tensor."""
     _need_dev(x)

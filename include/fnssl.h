@@ -187,6 +187,19 @@ int fnssl_ipd2doa(const float* pred, long long sb, long long sp, long long st, l
                   const float* bank, int nb, int np, int nt, int nf2,
                   int ncand, int nsrc, int unk_num, float* ss, int* idx, float* vad, void* stream);
 
+/*
+ * IPDnet's all-channel features (replaces IPDnet/runIPDnetOn.py:240-254: abs, forgetting_norm over
+ * all channels with sample_length 280, real/imag normalise, cat, DC-drop).
+ *   spec, magsum  outputs of fnssl_stft;  coef_a/b  DEVICE [nt] from fnssl_forgetting_coefs
+ *   mu            [nb, nt] (written)
+ *   x             channels [Re ch 0..nch-1, Im ch 0..nch-1], bins 1..256:
+ *                 layout 0: [nb, nt, 256, 2*nch];  layout 1: [nb, 2*nch, 256, nt] (what the reference builds)
+ */
+int fnssl_array_features(const float* spec, const float* magsum,
+                         const float* coef_a, const float* coef_b,
+                         int nb, int nch, int nt, float eps,
+                         float* mu, float* x, int layout, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* IPDnet head (next row 8f-3): causal 3x3 Conv2d + time pooling              */
 /* ------------------------------------------------------------------------- */

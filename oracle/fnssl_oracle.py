@@ -158,6 +158,16 @@ def data_preprocess(mic_sig: np.ndarray, ch_mode: str = "MM", eps: float = 1e-6,
     return np.ascontiguousarray(x[:, :, 1:NBIN, :])
 
 
+def array_preprocess(mic_sig: np.ndarray, eps: float = 1e-6, sample_length: int = 280) -> np.ndarray:
+    """Input half of IPDnet's data_preprocess, IPDnet/runIPDnetOn.py:240-254: all channels are
+    normalised together.  mic_sig [nb, ns, nch] -> x [nb, 2*nch, 256, nt], channels [Re all, Im all]."""
+    spec = np.transpose(stft(mic_sig), (0, 3, 1, 2))   # [nb, nch, 257, nt]   :246
+    mu = forgetting_norm(np.abs(spec).astype(F32), sample_length)           # :248-249
+    den = (mu + F32(eps)).astype(F32)
+    x = np.concatenate([(spec.real.astype(F32) / den).astype(F32), (spec.imag.astype(F32) / den).astype(F32)], axis=1)
+    return np.ascontiguousarray(x[:, :, 1:NBIN, :])                          # fre_range_used :125
+
+
 # --------------------------------------------------------------------------- #
 # network
 # --------------------------------------------------------------------------- #

@@ -50,6 +50,16 @@ def main():
     net = ref.IPDnet(input_size=4, hidden_size=128, max_track=2, is_online=False, n_seg=24).eval()
     net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     arrs["seg_out"] = net(torch.from_numpy(rs_randn(1620, (2, 4, 16, 40))), offline_inference=True).numpy()
+    # input features: the reference's own STFT module and forgetting_norm composed exactly as
+    # runIPDnetOn.py:240-254 does (data_preprocess itself also needs a simulated acoustic scene)
+    import Module as at_module  # noqa: E402  (reference IPDnet/Module.py)
+    from utils_ import forgetting_norm  # noqa: E402  (reference)
+    sig = rs_randn(1630, (2, 256 * 14, 4), 0.1)
+    stft = at_module.STFT(win_len=512, win_shift_ratio=0.5, nfft=512)(signal=torch.from_numpy(sig))
+    reb = stft.permute(0, 3, 1, 2)
+    mean_value = forgetting_norm(torch.abs(reb), sample_length=280)
+    feat = torch.cat((torch.real(reb) / (mean_value + 1e-6), torch.imag(reb) / (mean_value + 1e-6)), dim=1)
+    arrs["feat_out"] = feat[:, :, range(1, 257), :].numpy()
     # the causal conv block alone
     blk = ref.CausCnnBlock(inp_dim=20, out_dim=6).eval()
     sdc = {"conv%d.weight" % (i + 1): rs_randn(1700 + i, s, 0.1) for i, s in

@@ -229,7 +229,12 @@ def test_launch_planner_and_static_kernels_match_generic(dev):
              ("full", 128, True, 4, 0, 1, 40000, 3, False),
              ("narrow", 256, False, 256, 0, 3, 5, 1000, True),
              ("narrow", 256, False, 256, 4, 3, 5, 1000, True),
-             ("narrow", 128, True, 256, 4, 1, 4, 700, True)]
+             ("narrow", 128, True, 256, 4, 1, 4, 700, True),
+             # IPDnet shapes (16-channel concat skip): 4 / 8 / 12 waves per CU, full-band block 2
+             ("narrow", 256, False, 256, 16, 1, 4, 16000, False),
+             ("narrow", 256, False, 256, 16, 2, 3, 16000, False),
+             ("narrow", 256, False, 256, 16, 3, 3, 16000, False),
+             ("full", 128, True, 256, 16, 1, 19200, 3, False)]
     for mode, H, bidir, c0, c2, nb, nt, nf, with_sum in cases:
         sd = lstm_state(c0 + c2, H, bidir, 300 + c0 + c2 + H)
         w = packed_dirs(sd, c0, c2, bidir, dev)
@@ -610,3 +615,35 @@ def test_ipdnet_config3_shape_smoke(dev):
     assert torch.isfinite(y).all() and float(y.abs().max()) <= 1.0
     # utterances are independent: a batch of one gives the same rows bit for bit
     assert torch.equal(net(x[1:2]), y[1:2])
+
+
+def test_ipdnet_array_features_golden(dev):
+    """STFT + all-channel recursive normalisation (runIPDnetOn.py:240-254) in both layouts."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    g = load_golden("g10_ipdnet")
+    sig = rs_randn(1630, (2, 256 * 14, 4), 0.1)
+    x1 = ops.preprocess_array(to_dev(sig, dev), layout=1)
+    x0 = ops.preprocess_array(to_dev(sig, dev), layout=0)
+    scale = np.abs(g["feat_out"]).max()
+    assert x1.shape == g["feat_out"].shape
+    assert np.abs(x1.cpu().numpy() - g["feat_out"]).max() <= 5e-6 * scale, "vs reference golden"
+    assert np.abs(x1.cpu().numpy() - O.array_preprocess(sig)).max() <= 5e-6 * scale, "vs oracle"
+    assert torch.equal(x0, x1.permute(0, 3, 2, 1).contiguous()), "layout 0 is the same numbers, channels-last"
+
+
+def test_ipdnet_waveform_to_ipd(dev):
+    """Waveforms -> features -> IPDnet, against the oracle chain (8 microphones, 16 input channels)."""
+    from fnssl import ops
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    M = _ipdnet_module()
+    sd = W.make_ipdnet_state(2700, 16, 128, 2, True)
+    net = M.IPDnet(input_size=16, hidden_size=128, max_track=2, is_online=True).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev)
+    sig = rs_randn(2701, (1, 256 * 25, 8), 0.1)
+    got = net(ops.preprocess_array(to_dev(sig, dev)))
+    want = O.ipdnet_forward(sd, O.array_preprocess(sig), True)
+    assert got.shape == want.shape == (1, 2, 512, 7, 2)
+    assert_close(got.cpu().numpy(), want, RTOL, ATOL, "waveform -> IPD")

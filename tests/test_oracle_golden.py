@@ -188,6 +188,8 @@ def test_g10_ipdnet():
     sd = W.make_ipdnet_state(1520, 4, 128, 2, False)
     assert_close(O.ipdnet_forward(sd, rs_randn(1620, (2, 4, 16, 40)), False, n_seg=24), g["seg_out"], 1e-4, 1e-5,
                  "ipdnet chunk-wise offline inference")
+    feat = O.array_preprocess(rs_randn(1630, (2, 256 * 14, 4), 0.1))
+    assert np.abs(feat - g["feat_out"]).max() <= 2e-6 * np.abs(g["feat_out"]).max(), "IPDnet input features"
     sdc = {"c.conv%d.weight" % (i + 1): rs_randn(1700 + i, s, 0.1) for i, s in
            enumerate([(128, 20, 3, 3), (128, 128, 3, 3), (6, 128, 3, 3)])}
     assert_close(O.caus_cnn_block(sdc, "c.", rs_randn(1710, (2, 20, 7, 26))), g["cnn_out"], 1e-4, 1e-5, "cnn block")

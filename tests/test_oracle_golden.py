@@ -193,3 +193,49 @@ def test_g10_ipdnet():
     sdc = {"c.conv%d.weight" % (i + 1): rs_randn(1700 + i, s, 0.1) for i, s in
            enumerate([(128, 20, 3, 3), (128, 128, 3, 3), (6, 128, 3, 3)])}
     assert_close(O.caus_cnn_block(sdc, "c.", rs_randn(1710, (2, 20, 7, 26))), g["cnn_out"], 1e-4, 1e-5, "cnn block")
+
+
+# --- training step -----------------------------------------------------------------
+def _project(name_index, a):
+    a = np.asarray(a, dtype=np.float64)
+    r = rs_randn(5000 + name_index, a.shape).astype(np.float64)
+    return np.array([np.sqrt((a * a).sum()), (a * r).sum()])
+
+
+def test_g13_training_step_oracle_matches_reference():
+    """oracle.train_ref (autograd restatement with explicit dropout masks) against the real reference's
+    loss, prediction, gradient projections and Adam update."""
+    from oracle import train_ref as T
+    g = load_golden("g13_train")
+    for ci in range(2):
+        online, nb, npair, nf, nt, seed, wseed, xseed, gseed = [int(v) for v in g["c%d_cfg" % ci]]
+        sd = W.make_fnssl_state(wseed, 4, 256, bool(online))
+        x = rs_randn(xseed, (nb * npair, 4, nf, nt))
+        gt = rs_randn(gseed, (nb, nt // 12, 2 * nf, npair), 0.5)
+        loss, grads, new_sd, _, pred = T.train_step(sd, x, gt, seed, 256, bool(online))
+        assert abs(loss - float(g["c%d_loss" % ci])) <= 1e-6 * abs(loss)
+        assert_close(pred, g["c%d_pred" % ci], 1e-5, 1e-6, "train-mode prediction")
+        names = [str(s) for s in g["c%d_names" % ci]]
+        assert names == list(grads.keys())
+        for i, k in enumerate(names):
+            want = g["c%d_gproj" % ci][i]
+            got = _project(i, grads[k])
+            assert abs(got[0] - want[0]) <= 1e-4 * want[0] + 1e-12, (k, got, want)
+            assert abs(got[1] - want[1]) <= 1e-4 * want[0] * np.sqrt(grads[k].size) * 0.05 + 1e-12, (k, got, want)
+            n = min(16, grads[k].size)
+            assert_close(grads[k].reshape(-1)[:n], g["c%d_ghead" % ci][i][:n], 1e-3, 1e-4 * want[0] / np.sqrt(grads[k].size),
+                         "grad head " + k)
+            dw = _project(100 + i, new_sd[k] - sd[k])
+            wd = g["c%d_dproj" % ci][i]
+            assert abs(dw[0] - wd[0]) <= 2e-3 * wd[0] + 1e-12, (k, dw, wd)
+
+
+def test_dropout_scale_statistics_and_determinism():
+    from oracle import train_ref as T
+    s = T.layer_seed(7, 3)
+    a = T.dropout_scale(s, (2, 5, 7, 256))
+    assert set(np.unique(a)) == {np.float32(0), np.float32(1.25)}
+    assert abs((a > 0).mean() - 0.8) < 0.01
+    # a chunk of the batch draws the same mask as the whole batch
+    assert np.array_equal(T.dropout_scale(s, (1, 5, 7, 256), b0=1), a[1:2])
+    assert not np.array_equal(T.dropout_scale(T.layer_seed(7, 4), (2, 5, 7, 256)), a)

@@ -32,6 +32,7 @@ extern template int launch_h<32>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_h<64>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_h<128>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_h<256>(int, const LstmParams&, int, int, hipStream_t);
+int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train.hip
 }  // namespace fnssl_lstm
 
 extern "C" {
@@ -153,6 +154,8 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.wpack[0] = d->wpack[0];
   p.wpack[1] = d->wpack[1];
   p.cscratch = d->workspace;
+  p.reserve = d->reserve;
+  p.ntasks = (d->nseq + 15) / 16;
   p.c0 = d->c0;
   p.c2 = d->c2;
   p.nseq = d->nseq;
@@ -170,6 +173,21 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   const int hi = H == 16 ? 0 : H == 32 ? 1 : H == 64 ? 2 : H == 128 ? 3 : 4;
   fnssl::TimedLaunch tl(names[hi], fnssl::as_stream(stream), flops);
   hipStream_t st = fnssl::as_stream(stream);
+
+  if (d->reserve) {   // training forward: also save the gate activations (lstm_train.hip)
+    FNSSL_REQUIRE((H == 128 || H == 256) && !(mode & (kHas1 | kSum)),
+                  "lstm_forward: the reserve-saving forward needs hidden 128/256 and no src1 / out_sum");
+    FNSSL_REQUIRE(d->reserve_bytes >= fnssl_lstm_reserve_bytes(d->nseq, H, d->ndir, d->nsteps) &&
+                      (reinterpret_cast<uintptr_t>(d->reserve) & 15) == 0 &&
+                      (long double)d->nsteps * (H / 16) * kReserveRecs * 1024 < 4.0e9L,
+                  "lstm_forward: reserve buffer too small or misaligned");
+    p.chq = 0;
+    p.pad = 0;
+    p.task0 = 0;
+    p.task1 = tasks;
+    p.wgs_per_dir = 0;
+    return forward_save(p, H, mode, st);
+  }
 
   // one launch of `nw` waves per workgroup over the 16-sequence groups [t0, t1) of every direction
   auto launch_range = [&](int variant, int t0, int t1) -> int {

@@ -31,6 +31,8 @@ struct LstmParams {
   long long out_so, out_si, out_st;
   const float* wpack[2];
   float* cscratch;
+  float* reserve;     // training forward (MODE bit kSave): gates + cell state per (dir, group, step, slice)
+  int ntasks;         // 16-sequence groups per direction (reserve indexing)
   int c0, c2;
   int nseq, q_inner, nsteps, ndir;
   int wgs_per_dir;
@@ -44,6 +46,11 @@ struct LstmParams {
 constexpr int kHas1 = 1;   // input segment 0 is src0 + src1
 constexpr int kHas2 = 2;   // concatenated segment src2 present
 constexpr int kSum = 4;    // epilogue also writes out_sum = h + skip
+constexpr int kSave = 8;   // training forward: the epilogue also stores i, f, g, o and c for the backward pass
+
+// Reserve layout (written by the kSave forward, read by lstm_bwd_kernel): lane-private 1 KiB records
+//   reserve[(((dir * ntasks + group) * nsteps + t) * NS + slice) * 5 + {i, f, g, o, c}][lane] (float4)
+constexpr int kReserveRecs = 5;
 
 // ---- stream geometry (shared by packer and kernel) -------------------------
 // per hidden slice (16 units):  quad 0           : 4 bias records (acc init, gate q)
@@ -263,6 +270,7 @@ template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false>
 __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   constexpr int NS = H / 16;
   constexpr bool HAS1 = (MODE & kHas1) != 0, HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
+  constexpr bool SAVE = (MODE & kSave) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -286,6 +294,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   const rsrc_t ro2 = SUM ? split_addr(p.out_sum, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo2) : ro;
   const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
                               ((size_t)blockIdx.x * NW + w) * (NS * 1024));
+  const bool tsave = SAVE && task < p.task1;
+  const rsrc_t rres = SAVE ? make_rsrc(reinterpret_cast<const char*>(p.reserve) +
+                                       ((size_t)dir * p.ntasks + (tsave ? task : 0)) * p.nsteps *
+                                           (size_t)(NS * kReserveRecs * 1024))
+                           : rc;
   const unsigned st0 = (unsigned)(p.src0.st * 4), st1 = HAS1 ? (unsigned)(p.src1.st * 4) : 0u;
   const unsigned st2 = HAS2 ? (unsigned)(p.src2.st * 4) : 0u, sto = (unsigned)(p.out_st * 4);
   const unsigned stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
@@ -486,6 +499,14 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         // make the rounded h opaque: h + skip below must add the ROUNDED h (what the reference
         // adds), not become fma(o, tanh c, skip)
         asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));
+        if (SAVE && tsave) {
+          const unsigned rb = (tt * NS + s) * (kReserveRecs * 1024);
+          bst4(ig, rres, vlane, rb);
+          bst4(fg, rres, vlane, rb + 1024);
+          bst4(gg, rres, vlane, rb + 2048);
+          bst4(og, rres, vlane, rb + 3072);
+          bst4(cn, rres, vlane, rb + 4096);
+        }
       }
       if (!(abl & 4)) {
         bst4(cn, rc, vlane, s * 1024);

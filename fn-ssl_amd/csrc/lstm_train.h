@@ -1,0 +1,224 @@
+// Training kernels of the LSTM layers: the forward that also saves the gate
+// activations, and back-propagation through time.  Host entry points: lstm_train.hip.
+//
+// Backward formulation.  With the forward's transposed product G^T = W [x | h]^T, the gradient of the
+// layer input and of the previous hidden state is again a transposed product
+//     [dx_t | dh_{t-1}]^T [(C0g + H) x 16] = [W_ih | W_hh]^T [(C0g + H) x 4H] * da_t^T [4H x 16]
+// with the SAME operand roles: A = a 16-row tile of the (transposed) weights streamed through the LDS
+// ring, B = the pre-activation gradients da_t with lane <-> sequence.  A wave owns 16 sequences, walks
+// the time axis against the forward direction and alternates two phases per step:
+//   A  (VALU)  per 16-unit hidden slice: read i, f, g, o, c_t, c_{t-1} (forward reserve), the upstream
+//              gradient and the carried dh / dc, form da_{i,f,g,o}, write them to the dA tensor (the
+//              weight-gradient GEMMs consume it afterwards) and carry dc;
+//   B  (MFMA)  stream [W_ih | W_hh]^T: for every group of 4 x 16 output channels accumulate over the 4H
+//              gate units (B operand re-read from the dA rows this wave has just written), then store
+//              dx_t (input-gradient tensor) or carry dh_{t-1} (lane-private scratch).
+// The output channels are arranged like a forward "fake LSTM" with 4 "gates" = the four quarters of the
+// padded output range, so the packed stream has the forward's record structure (bias quad = zeros) and
+// the D fragments land on the lanes that own those units in phase A of the next step.
+#pragma once
+
+#include "lstm_kernel.h"
+
+namespace fnssl_lstm {
+
+struct BwdParams {
+  const float* reserve;
+  View dh;                     // upstream gradient wrt the layer output (channel offset dir * H)
+  float* da;                   // [seq, step, ndir * 4H] view (written)
+  long long da_so, da_si, da_st;
+  float* dx;                   // [seq, step, ndir * c0g] view (written), null when c0g == 0
+  long long dx_so, dx_si, dx_st;
+  const float* wpack[2];
+  float* scratch;              // per wave 2 * NS records: carried dh, carried dc
+  int c0g, co_pad;             // input channels that need a gradient; padded output range (multiple of 64)
+  int nseq, q_inner, nsteps, ndir, ntasks;
+  int wgs_per_dir, task0, task1;
+  int quads_per_slice, chq, pad;
+};
+
+inline int bwd_co_pad(int c0g, int H) { return (c0g + H + 63) / 64 * 64; }
+inline int bwd_quads_per_slice(int H) { return 1 + (4 * H) / 16; }
+
+template <int H, int NW, int M>
+__global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
+  constexpr int NS = H / 16;
+  constexpr int NVB = 4 * H / 16;   // 16-channel blocks of one dA row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int dir = blockIdx.x / p.wgs_per_dir;
+  const int wg = blockIdx.x - dir * p.wgs_per_dir;
+  const int task = p.task0 + wg * NW + w;
+  const bool tvalid = task < p.task1;
+  int q = task * 16 + n;
+  const bool valid = q < p.nseq && tvalid;
+  if (q >= p.nseq) q = p.nseq - 1;
+  const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
+
+  unsigned vdh = 0, vda = 0, vdx = 0;
+  const rsrc_t rdh = split_addr(p.dh.p, qo * p.dh.so + qi * p.dh.si, dir * H + 4 * g, vdh);
+  const rsrc_t rda = split_addr(p.da, qo * p.da_so + qi * p.da_si, dir * 4 * H + 4 * g, vda);
+  const rsrc_t rdx = p.c0g ? split_addr(p.dx, qo * p.dx_so + qi * p.dx_si, dir * p.c0g + 4 * g, vdx) : rdh;
+  const rsrc_t rres = make_rsrc(reinterpret_cast<const char*>(p.reserve) +
+                                ((size_t)dir * p.ntasks + (tvalid ? task : 0)) * p.nsteps *
+                                    (size_t)(NS * kReserveRecs * 1024));
+  const rsrc_t rsc = make_rsrc(reinterpret_cast<const char*>(p.scratch) +
+                               ((size_t)blockIdx.x * NW + w) * (2 * NS * 1024));
+  const unsigned sdh = (unsigned)(p.dh.st * 4), sda = (unsigned)(p.da_st * 4), sdx = (unsigned)(p.dx_st * 4);
+  const unsigned vlane = lane * 16;
+  const bool rev = dir == 1;
+  const int nso = p.co_pad >> 6;      // output slices (4 x 16 channels each)
+  const int hq = p.co_pad >> 2;       // channels per output quarter
+
+  WStream<NW, M, 1> ws;
+  ws.nobar = false;
+  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, nso, p.chq, p.pad, smem);
+  v4f a0 = ws.record(0), a1 = ws.record(1);
+  const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+  v4f acc[4];
+
+#define QUAD(B0, B1, B2, B3)                          \
+  do {                                                \
+    const v4f a2_ = ws.record(2), a3_ = ws.record(3); \
+    __builtin_amdgcn_sched_barrier(0);                \
+    MFMA4(acc, a0, B0);                               \
+    MFMA4(acc, a1, B1);                               \
+    ws.peek_next(a0, a1);                             \
+    __builtin_amdgcn_sched_barrier(0);                \
+    MFMA4(acc, a2_, B2);                              \
+    MFMA4(acc, a3_, B3);                              \
+    if (ws.advance()) {                               \
+      a0 = ws.record(0);                              \
+      a1 = ws.record(1);                              \
+    }                                                 \
+  } while (0)
+
+  for (int step = 0; step < p.nsteps; ++step) {
+    // the forward direction ran t = 0 .. T-1, so its gradient flows T-1 .. 0; the reverse one the other way
+    const unsigned tt = rev ? step : p.nsteps - 1 - step;
+    const bool has_prev = step + 1 < p.nsteps;            // the forward pass had a step before tt
+    const unsigned tp = has_prev ? (rev ? tt + 1 : tt - 1) : tt;
+    const unsigned oa = tt * sda;
+
+    // ---- phase A: gate gradients of every hidden slice ---------------------------------------
+    for (int s = 0; s < NS; ++s) {
+      const unsigned rb = (tt * NS + s) * (kReserveRecs * 1024);
+      const v4f ig = bld4(rres, vlane, rb), fg = bld4(rres, vlane, rb + 1024);
+      const v4f gg = bld4(rres, vlane, rb + 2048), og = bld4(rres, vlane, rb + 3072);
+      const v4f ct = bld4(rres, vlane, rb + 4096);
+      v4f cp = zero4, dh = bld4(rdh, vdh, tt * sdh + 64 * s), dc = zero4;
+      if (has_prev) cp = bld4(rres, vlane, (tp * NS + s) * (kReserveRecs * 1024) + 4096);
+      if (step > 0) {
+        dh += bld4(rsc, vlane, s * 1024);
+        dc = bld4(rsc, vlane, (NS + s) * 1024);
+      }
+      const v4f tc = tanh4(ct);
+      const v4f one = v4f{1.f, 1.f, 1.f, 1.f};
+      dc += dh * og * (one - tc * tc);
+      const v4f dao = dh * tc * og * (one - og);
+      const v4f dai = dc * gg * ig * (one - ig);
+      const v4f daf = dc * cp * fg * (one - fg);
+      const v4f dag = dc * ig * (one - gg * gg);
+      bst4(dc * fg, rsc, vlane, (NS + s) * 1024);
+      if (valid) {
+        bst4(dai, rda, vda, oa + 64 * s);
+        bst4(daf, rda, vda, oa + 4 * H + 64 * s);
+        bst4(dag, rda, vda, oa + 8 * H + 64 * s);
+        bst4(dao, rda, vda, oa + 12 * H + 64 * s);
+      }
+    }
+    // the B operands below are this wave's own dA rows: wait until the stores have been performed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- phase B: [dx | dh_prev]^T = [W_ih | W_hh]^T da^T -------------------------------------
+    v4f x0 = bld4(rda, vda, oa), x1 = bld4(rda, vda, oa + 64), x2 = bld4(rda, vda, oa + 128),
+        x3 = bld4(rda, vda, oa + 192);
+    for (int so = 0; so < nso; ++so) {
+      acc[0] = a0;   // "bias" quad of the stream: zeros
+      acc[1] = a1;
+      acc[2] = ws.record(2);
+      acc[3] = ws.record(3);
+      ws.peek_next(a0, a1);
+      if (ws.advance()) {
+        a0 = ws.record(0);
+        a1 = ws.record(1);
+      }
+#pragma unroll 1
+      for (int v = 0; v < NVB; v += 4) {
+        // 4-deep operand ring; the blocks wrap around into the next output slice (same dA row)
+        const unsigned nx = oa + 64 * ((v + 4) & (NVB - 1));
+        QUAD(x0.x, x0.y, x0.z, x0.w);
+        x0 = bld4(rda, vda, nx);
+        QUAD(x1.x, x1.y, x1.z, x1.w);
+        x1 = bld4(rda, vda, nx + 64);
+        QUAD(x2.x, x2.y, x2.z, x2.w);
+        x2 = bld4(rda, vda, nx + 128);
+        QUAD(x3.x, x3.y, x3.z, x3.w);
+        x3 = bld4(rda, vda, nx + 192);
+      }
+      for (int u = 0; u < p.pad; ++u) {
+        ws.peek_next(a0, a1);
+        if (ws.advance()) {
+          a0 = ws.record(0);
+          a1 = ws.record(1);
+        }
+      }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int ob = qq * hq + 16 * so;                 // first channel of this 16-channel block
+        if (ob < p.c0g) {
+          if (valid) bst4(acc[qq], rdx, vdx, tt * sdx + 4 * ob);
+        } else if (ob < p.c0g + H) {
+          bst4(acc[qq], rsc, vlane, ((ob - p.c0g) >> 4) * 1024);
+        }
+      }
+    }
+  }
+#undef QUAD
+}
+
+template <int H, int NW, int M>
+int launch_bwd_k(const BwdParams& p, int nwg, hipStream_t st) {
+  const size_t lds = (size_t)2 * p.chq * 4096;
+  auto k = lstm_bwd_kernel<H, NW, M>;
+  if (lds > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);
+  FNSSL_CHECK_LAUNCH("lstm_bwd_kernel");
+  return FNSSL_OK;
+}
+
+// training launch geometries: NW waves per workgroup, 4 ring records staged per wave
+template <int H>
+int launch_bwd(int nw, const BwdParams& p, int nwg, hipStream_t st) {
+  switch (nw) {
+    case 4: return launch_bwd_k<H, 4, 4>(p, nwg, st);
+    case 8: return launch_bwd_k<H, 8, 4>(p, nwg, st);
+    case 12: return launch_bwd_k<H, 12, 4>(p, nwg, st);
+  }
+  fnssl::set_error("lstm_backward: unsupported workgroup size %d", nw);
+  return FNSSL_E_INVALID;
+}
+
+template <int H>
+int launch_save(int nw, const LstmParams& p, int mode, int nwg, hipStream_t st) {
+  const bool has2 = (mode & kHas2) != 0;
+  switch (nw) {
+    case 4: return has2 ? launch_k<H, 4, 4, 1, kSave | kHas2>(p, nwg, st) : launch_k<H, 4, 4, 1, kSave>(p, nwg, st);
+    case 8: return has2 ? launch_k<H, 8, 4, 1, kSave | kHas2>(p, nwg, st) : launch_k<H, 8, 4, 1, kSave>(p, nwg, st);
+    case 12:
+      return has2 ? launch_k<H, 12, 4, 1, kSave | kHas2>(p, nwg, st) : launch_k<H, 12, 4, 1, kSave>(p, nwg, st);
+  }
+  fnssl::set_error("lstm_forward (training): unsupported workgroup size %d", nw);
+  return FNSSL_E_INVALID;
+}
+
+extern template int launch_bwd<128>(int, const BwdParams&, int, hipStream_t);
+extern template int launch_bwd<256>(int, const BwdParams&, int, hipStream_t);
+extern template int launch_save<128>(int, const LstmParams&, int, int, hipStream_t);
+extern template int launch_save<256>(int, const LstmParams&, int, int, hipStream_t);
+
+}  // namespace fnssl_lstm

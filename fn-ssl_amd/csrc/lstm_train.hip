@@ -1,0 +1,172 @@
+// Host side of the LSTM training kernels (lstm_train.h): the launch planner shared by the
+// reserve-saving forward and the BPTT kernel, the packer of the transposed weight stream, and the C ABI.
+#include <cstring>
+
+#include "common.h"
+
+#include "lstm_train.h"
+
+using namespace fnssl_lstm;
+
+namespace fnssl_lstm {
+
+static int device_cus() {
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return ncu;
+}
+
+// Rounds of <= 12 waves per CU, as even as possible; calls fn(nw, t0, t1) per round.
+template <class F>
+static int plan_rounds(int tasks, int ndir, F&& fn) {
+  const int ncu = device_cus();
+  const long long total = (long long)tasks * ndir;
+  const int W = (int)((total + ncu - 1) / ncu);
+  const int rounds = (W + 11) / 12;
+  const int wgs_per_dir_round = ncu / ndir > 0 ? ncu / ndir : 1;
+  int t0 = 0;
+  for (int r = 0; r < rounds && t0 < tasks; ++r) {
+    const long long left_total = (long long)(tasks - t0) * ndir;
+    const int want = (int)(((left_total + ncu - 1) / ncu + (rounds - r) - 1) / (rounds - r));
+    const int nw = want <= 4 ? 4 : want <= 8 ? 8 : 12;
+    int t1 = r + 1 == rounds ? tasks : t0 + wgs_per_dir_round * nw;
+    if (t1 > tasks) t1 = tasks;
+    const int rc = fn(nw, t0, t1);
+    if (rc != FNSSL_OK) return rc;
+    t0 = t1;
+  }
+  return FNSSL_OK;
+}
+
+// Training forward: called by fnssl_lstm_forward when the descriptor carries a reserve buffer.
+int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
+  const int tasks = p.ntasks;
+  return plan_rounds(tasks, p.ndir, [&](int nw, int t0, int t1) {
+    p.task0 = t0;
+    p.task1 = t1;
+    p.wgs_per_dir = (t1 - t0 + nw - 1) / nw;
+    const Variant vr{nw, 4, 1};
+    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
+    const int nwg = p.wgs_per_dir * p.ndir;
+    return H == 128 ? launch_save<128>(nw, p, mode | kSave, nwg, st) : launch_save<256>(nw, p, mode | kSave, nwg, st);
+  });
+}
+
+}  // namespace fnssl_lstm
+
+extern "C" {
+
+size_t fnssl_lstm_reserve_bytes(int nseq, int hidden, int ndir, int nsteps) {
+  if (nseq <= 0 || hidden <= 0 || hidden % 16 || ndir <= 0 || nsteps <= 0) return 0;
+  const size_t tasks = (size_t)(nseq + 15) / 16;
+  return tasks * ndir * (size_t)nsteps * (hidden / 16) * kReserveRecs * 1024;
+}
+
+size_t fnssl_lstm_bwd_packed_floats(int c0g, int hidden) {
+  if (hidden <= 0 || hidden % 16 || c0g < 0 || (c0g & 15)) return 0;
+  return (size_t)(bwd_co_pad(c0g, hidden) / 64) * bwd_quads_per_slice(hidden) * 4 * 256;
+}
+
+int fnssl_lstm_pack_bwd(const float* w_ih, const float* w_hh, int c_in, int c0g, int H, float* packed) {
+  FNSSL_REQUIRE(w_ih && w_hh && packed, "lstm_pack_bwd: null pointer");
+  const size_t total = fnssl_lstm_bwd_packed_floats(c0g, H);
+  FNSSL_REQUIRE(total > 0 && c0g <= c_in, "lstm_pack_bwd: unsupported sizes (c_in %d, c0g %d, H %d)", c_in, c0g, H);
+  std::memset(packed, 0, total * sizeof(float));
+  const int co = bwd_co_pad(c0g, H), hq = co / 4, nso = co / 64, nvb = 4 * H / 16;
+  auto wb = [&](int o, int ku) -> float {   // [W_ih[:, :c0g] | W_hh]^T
+    if (o < c0g) return w_ih[(size_t)ku * c_in + o];
+    if (o < c0g + H) return w_hh[(size_t)ku * H + (o - c0g)];
+    return 0.f;
+  };
+  float* rec = packed;
+  for (int so = 0; so < nso; ++so) {
+    rec += 4 * 256;   // "bias" quad: zeros (accumulator init)
+    for (int v = 0; v < nvb; ++v)
+      for (int j = 0; j < 4; ++j, rec += 256)
+        for (int l = 0; l < 64; ++l)
+          for (int qq = 0; qq < 4; ++qq)
+            rec[l * 4 + qq] = wb(qq * hq + 16 * so + (l & 15), 16 * v + 4 * (l >> 4) + j);
+  }
+  if ((size_t)(rec - packed) != total) {
+    fnssl::set_error("lstm_pack_bwd: internal size mismatch");
+    return FNSSL_E_INVALID;
+  }
+  return FNSSL_OK;
+}
+
+size_t fnssl_lstm_bwd_workspace_bytes(int nseq, int hidden, int ndir) {
+  if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
+  const size_t tasks = (size_t)(nseq + 15) / 16 + 16;
+  return tasks * ndir * (size_t)(2 * (hidden / 16)) * 1024 + 256;
+}
+
+int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) {
+  FNSSL_REQUIRE(d, "lstm_backward: null descriptor");
+  const int H = d->hidden;
+  FNSSL_REQUIRE(H == 128 || H == 256, "lstm_backward: hidden size %d unsupported (128/256)", H);
+  FNSSL_REQUIRE(d->ndir == 1 || d->ndir == 2, "lstm_backward: ndir must be 1 or 2");
+  FNSSL_REQUIRE(d->nseq > 0 && d->nsteps > 0 && d->q_inner > 0, "lstm_backward: empty problem");
+  FNSSL_REQUIRE(d->c0g >= 0 && d->c0g % 16 == 0, "lstm_backward: c0g %d must be a multiple of 16", d->c0g);
+  FNSSL_REQUIRE(d->reserve && d->dh.p && d->da && d->wpack_bwd[0] && (d->ndir == 1 || d->wpack_bwd[1]) &&
+                    (d->c0g == 0 || d->dx),
+                "lstm_backward: null pointer");
+  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  auto mult4 = [](long long v) { return (v & 3) == 0 && v >= 0; };
+  FNSSL_REQUIRE(aligned(d->reserve) && aligned(d->dh.p) && aligned(d->da) && aligned(d->dx) &&
+                    aligned(d->wpack_bwd[0]) && aligned(d->wpack_bwd[1]) && aligned(d->workspace),
+                "lstm_backward: pointers must be 16-byte aligned");
+  FNSSL_REQUIRE(mult4(d->dh.so) && mult4(d->dh.si) && mult4(d->dh.st) && mult4(d->da_so) && mult4(d->da_si) &&
+                    mult4(d->da_st) && mult4(d->dx_so) && mult4(d->dx_si) && mult4(d->dx_st),
+                "lstm_backward: strides must be non-negative multiples of 4 floats");
+  auto extent_ok = [&](long long so, long long si, long long st, long long width) {
+    return ((long double)so + 16.0L * si + (long double)d->nsteps * st + width) * 4.0L < 4.0e9L;
+  };
+  FNSSL_REQUIRE(extent_ok(d->dh.so, d->dh.si, d->dh.st, 2 * H) && extent_ok(d->da_so, d->da_si, d->da_st, 8 * H) &&
+                    (d->c0g == 0 || extent_ok(d->dx_so, d->dx_si, d->dx_st, 2 * d->c0g)) &&
+                    (long double)d->nsteps * (H / 16) * kReserveRecs * 1024 < 4.0e9L,
+                "lstm_backward: one sequence group must span < 4 GB");
+  const size_t need = fnssl_lstm_bwd_workspace_bytes(d->nseq, H, d->ndir);
+  if (!d->workspace || d->workspace_bytes < need) {
+    fnssl::set_error("lstm_backward: workspace %zu < %zu bytes", d->workspace_bytes, need);
+    return FNSSL_E_WORKSPACE;
+  }
+  BwdParams p;
+  p.reserve = d->reserve;
+  p.dh = View{d->dh.p, d->dh.so, d->dh.si, d->dh.st};
+  p.da = d->da;
+  p.da_so = d->da_so;
+  p.da_si = d->da_si;
+  p.da_st = d->da_st;
+  p.dx = d->dx;
+  p.dx_so = d->dx_so;
+  p.dx_si = d->dx_si;
+  p.dx_st = d->dx_st;
+  p.wpack[0] = d->wpack_bwd[0];
+  p.wpack[1] = d->wpack_bwd[1];
+  p.scratch = static_cast<float*>(d->workspace);
+  p.c0g = d->c0g;
+  p.co_pad = bwd_co_pad(d->c0g, H);
+  p.nseq = d->nseq;
+  p.q_inner = d->q_inner;
+  p.nsteps = d->nsteps;
+  p.ndir = d->ndir;
+  p.ntasks = (d->nseq + 15) / 16;
+  p.quads_per_slice = bwd_quads_per_slice(H);
+  hipStream_t st = fnssl::as_stream(stream);
+  const double flops = 2.0 * 4 * H * (double)(d->c0g + H) * d->nseq * (double)d->nsteps * d->ndir;
+  fnssl::TimedLaunch tl(H == 128 ? "lstm_bwd_h128" : "lstm_bwd_h256", st, flops);
+  return plan_rounds(p.ntasks, p.ndir, [&](int nw, int t0, int t1) {
+    p.task0 = t0;
+    p.task1 = t1;
+    p.wgs_per_dir = (t1 - t0 + nw - 1) / nw;
+    const Variant vr{nw, 4, 1};
+    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
+    const int nwg = p.wgs_per_dir * p.ndir;
+    return H == 128 ? launch_bwd<128>(nw, p, nwg, st) : launch_bwd<256>(nw, p, nwg, st);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,7 @@
+// Training LSTM kernels (forward with reserve, BPTT) for hidden size 256; see lstm_train.h.
+#include "lstm_train.h"
+
+namespace fnssl_lstm {
+template int launch_bwd<256>(int, const BwdParams&, int, hipStream_t);
+template int launch_save<256>(int, const LstmParams&, int, int, hipStream_t);
+}  // namespace fnssl_lstm

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -29,6 +29,8 @@ SYMBOLS = [
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features",
+    "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
+    "fnssl_lstm_backward",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
 ]
 
@@ -48,6 +50,20 @@ class LstmDesc(C.Structure):
         ("wpack", C.c_void_p * 2),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("variant", C.c_int),
+        ("reserve", C.c_void_p), ("reserve_bytes", C.c_size_t),
+    ]
+
+
+class LstmBwdDesc(C.Structure):
+    _fields_ = [
+        ("reserve", C.c_void_p),
+        ("dh", View),
+        ("da", C.c_void_p), ("da_so", C.c_longlong), ("da_si", C.c_longlong), ("da_st", C.c_longlong),
+        ("dx", C.c_void_p), ("dx_so", C.c_longlong), ("dx_si", C.c_longlong), ("dx_st", C.c_longlong),
+        ("c0g", C.c_int),
+        ("hidden", C.c_int), ("ndir", C.c_int), ("nseq", C.c_int), ("q_inner", C.c_int), ("nsteps", C.c_int),
+        ("wpack_bwd", C.c_void_p * 2),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -106,6 +122,14 @@ def load():
     lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
     lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
     lib.fnssl_ipd2doa.argtypes = [vp, ll, ll, ll, ll, vp, i, i, i, i, i, i, i, vp, vp, vp, vp]
+    lib.fnssl_lstm_reserve_bytes.argtypes = [i, i, i, i]
+    lib.fnssl_lstm_reserve_bytes.restype = sz
+    lib.fnssl_lstm_bwd_packed_floats.argtypes = [i, i]
+    lib.fnssl_lstm_bwd_packed_floats.restype = sz
+    lib.fnssl_lstm_pack_bwd.argtypes = [vp, vp, i, i, i, vp]
+    lib.fnssl_lstm_bwd_workspace_bytes.argtypes = [i, i, i]
+    lib.fnssl_lstm_bwd_workspace_bytes.restype = sz
+    lib.fnssl_lstm_backward.argtypes = [C.POINTER(LstmBwdDesc), vp]
     lib.fnssl_array_features.argtypes = [vp, vp, vp, vp, i, i, i, C.c_float, vp, vp, i, vp]
     lib.fnssl_conv3x3_packed_floats.argtypes = [i, i, i]
     lib.fnssl_conv3x3_packed_floats.restype = sz

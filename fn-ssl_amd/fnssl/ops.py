@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import CH_MODE, LstmDesc, Net, View, check
+from ._lib import LstmBwdDesc, CH_MODE, LstmDesc, Net, View, check
 
 SEG_FRAMES = 12
 NBIN = 257
@@ -198,7 +198,8 @@ def release_workspaces():
     _ws_cache.clear()
 
 
-def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None):
+def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
+               reserve=None):
     """One (bi)LSTM layer over strided views.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
@@ -207,6 +208,8 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     streams; ``out`` a logical [nb, nt, nf, ndir*hidden] tensor (any strides) that is written in place.
     With ``skip``/``out_sum`` (both logical [nb, nt, nf, ndir*hidden]; out_sum with out's strides) the
     kernel also stores out_sum = h + skip, i.e. the next layer's residual input.
+    ``reserve`` (a float32 device buffer of ``lstm_reserve_floats`` elements) switches to the training
+    forward, which also saves the gate activations and cell states for ``lstm_backward``.
     """
     _need_dev(x0, x1, x2, out, skip, out_sum, *packed)
     if mode not in ("full", "narrow"):
@@ -251,8 +254,68 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     ws = _workspace(wsb, out.device, "lstm")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.variant = variant
+    if reserve is not None:
+        _need_dev(reserve)
+        d.reserve, d.reserve_bytes = reserve.data_ptr(), reserve.numel() * 4
     check(lib.fnssl_lstm_forward(C.byref(d), _stream()), "lstm_forward")
     return out
+
+
+def lstm_reserve_floats(nseq: int, hidden: int, ndir: int, nsteps: int) -> int:
+    return _lib.load().fnssl_lstm_reserve_bytes(nseq, hidden, ndir, nsteps) // 4
+
+
+def pack_lstm_bwd_host(w_ih, w_hh, c0g: int) -> np.ndarray:
+    """Pack one direction's [W_ih[:, :c0g] | W_hh]^T into the backward kernel's weight stream."""
+    arrs = [np.ascontiguousarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+            for a in (w_ih, w_hh)]
+    hidden = arrs[1].shape[1]
+    c_in = arrs[0].shape[1]
+    lib = _lib.load()
+    n = lib.fnssl_lstm_bwd_packed_floats(c0g, hidden)
+    if n == 0 or arrs[0].shape[0] != 4 * hidden or arrs[1].shape[0] != 4 * hidden:
+        raise RuntimeError("fnssl.pack_lstm_bwd: unsupported sizes c0g=%d H=%d" % (c0g, hidden))
+    out = np.empty(n, dtype=np.float32)
+    check(lib.fnssl_lstm_pack_bwd(arrs[0].ctypes.data_as(C.c_void_p), arrs[1].ctypes.data_as(C.c_void_p), c_in, c0g,
+                                  hidden, out.ctypes.data_as(C.c_void_p)), "lstm_pack_bwd")
+    return out
+
+
+def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: int):
+    """Back-propagation through time of one (bi)LSTM layer.
+
+    dh: upstream gradient, logical [nb, nt, nf, ndir*hidden]; da (written): logical [nb, nt, nf, ndir*4*hidden]
+    pre-activation gate gradients; dx (written, or None when c0g == 0): logical [nb, nt, nf, ndir*c0g], one slab
+    per direction.  ``mode`` as in lstm_layer."""
+    _need_dev(reserve, dh, da, dx, *packed_bwd)
+    ndir = len(packed_bwd)
+    nb, nt, nf = dh.shape[:3]
+    if tuple(dh.shape) != (nb, nt, nf, ndir * hidden) or tuple(da.shape) != (nb, nt, nf, ndir * 4 * hidden):
+        raise RuntimeError("fnssl.lstm_backward: dh / da shapes %s / %s" % (tuple(dh.shape), tuple(da.shape)))
+    if (c0g > 0) != (dx is not None) or (dx is not None and tuple(dx.shape) != (nb, nt, nf, ndir * c0g)):
+        raise RuntimeError("fnssl.lstm_backward: dx must be [nb, nt, nf, ndir*c0g] (None when c0g == 0)")
+    dh = _conform(dh)
+    d = LstmBwdDesc()
+    d.reserve = reserve.data_ptr()
+    d.dh = _view(dh, mode)
+    v = _view(da, mode)
+    d.da, d.da_so, d.da_si, d.da_st = v.p, v.so, v.si, v.st
+    if dx is not None:
+        v = _view(dx, mode)
+        d.dx, d.dx_so, d.dx_si, d.dx_st = v.p, v.so, v.si, v.st
+    d.c0g, d.hidden, d.ndir = c0g, hidden, ndir
+    d.nseq = nb * (nt if mode == "full" else nf)
+    d.q_inner = nt if mode == "full" else nf
+    d.nsteps = nf if mode == "full" else nt
+    if reserve.numel() < lstm_reserve_floats(d.nseq, hidden, ndir, d.nsteps):
+        raise RuntimeError("fnssl.lstm_backward: reserve buffer too small")
+    d.wpack_bwd[0] = packed_bwd[0].data_ptr()
+    d.wpack_bwd[1] = packed_bwd[1].data_ptr() if ndir == 2 else 0
+    lib = _lib.load()
+    ws = _workspace(lib.fnssl_lstm_bwd_workspace_bytes(d.nseq, hidden, ndir), dh.device, "lstm_bwd")
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(lib.fnssl_lstm_backward(C.byref(d), _stream()), "lstm_backward")
+    return da, dx
 
 
 # --------------------------------------------------------------------------- #

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 1
+#define FNSSL_ABI_VERSION 2
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -132,6 +132,10 @@ typedef struct {
   float* workspace;    /* DEVICE, >= fnssl_lstm_workspace_bytes()             */
   size_t workspace_bytes;
   int variant;         /* 0 = default; see DESIGN.md (kernel variants)        */
+  /* training forward (autograd's "save for backward"): when non-NULL the kernel also stores the gate
+   * activations and cell state, >= fnssl_lstm_reserve_bytes(); hidden 128/256, no src1 / out_sum.  */
+  float* reserve;
+  size_t reserve_bytes;
 } fnssl_lstm_desc;
 
 /* Floats in one direction's packed weight stream for (input_size = c0 + c2, hidden). */
@@ -149,6 +153,45 @@ int fnssl_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir);
 
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
+
+/* ---- training (next row 8f-1): back-propagation through time ---------------------------------- */
+
+size_t fnssl_lstm_reserve_bytes(int nseq, int hidden, int ndir, int nsteps);
+
+/* Floats of one direction's transposed weight stream [W_ih[:, :c0g] | W_hh]^T (c0g = leading input
+ * channels whose gradient is wanted, a multiple of 16; 0 for a layer fed by data only). */
+size_t fnssl_lstm_bwd_packed_floats(int c0g, int hidden);
+
+/* Host-only: pack w_ih [4H, c_in], w_hh [4H, H] for fnssl_lstm_backward. */
+int fnssl_lstm_pack_bwd(const float* w_ih, const float* w_hh, int c_in, int c0g, int hidden, float* packed);
+
+size_t fnssl_lstm_bwd_workspace_bytes(int nseq, int hidden, int ndir);
+
+/*
+ * Backward of one (bi)LSTM layer through time (what autograd does for nn.LSTM in
+ * training_step, FN-SSL/Lightning/main.py:149-157): from the upstream gradient dh of the layer output
+ * and the forward's reserve it writes
+ *   da  the pre-activation gate gradients, [.., dir * 4H + (i | f | g | o)]: the weight gradients are
+ *       the plain GEMMs  dW_ih = da^T x,  dW_hh = da^T h_prev,  db = sum(da)  (host side, rocBLAS);
+ *   dx  the gradient of the first c0g input channels, one slab per direction [.., dir * c0g + ch]
+ *       (the caller adds the two directions).
+ * Views are addressed like fnssl_lstm_desc's (q / q_inner, q % q_inner, step).
+ */
+typedef struct {
+  const float* reserve;
+  fnssl_view dh;
+  float* da;
+  long long da_so, da_si, da_st;
+  float* dx;
+  long long dx_so, dx_si, dx_st;
+  int c0g;
+  int hidden, ndir, nseq, q_inner, nsteps;
+  const float* wpack_bwd[2];
+  void* workspace;
+  size_t workspace_bytes;
+} fnssl_lstm_bwd_desc;
+
+int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Head                                                                      */

@@ -30,7 +30,8 @@ SYMBOLS = [
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
-    "fnssl_lstm_backward",
+    "fnssl_lstm_backward", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
+    "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
 ]
 
@@ -65,6 +66,10 @@ class LstmBwdDesc(C.Structure):
         ("wpack_bwd", C.c_void_p * 2),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
+
+
+class BtfView(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sb", C.c_longlong), ("st", C.c_longlong), ("sf", C.c_longlong)]
 
 
 class Net(C.Structure):
@@ -130,6 +135,14 @@ def load():
     lib.fnssl_lstm_bwd_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_lstm_bwd_workspace_bytes.restype = sz
     lib.fnssl_lstm_backward.argtypes = [C.POINTER(LstmBwdDesc), vp]
+    lib.fnssl_train_combine.argtypes = [vp, ll, ll, ll, i, i, i, i, C.POINTER(BtfView), i, C.POINTER(BtfView), i, i,
+                                        C.c_uint, ll, vp]
+    lib.fnssl_dropout_scale.argtypes = [vp, ll, C.c_uint, ll, vp]
+    lib.fnssl_head_backward_workspace_bytes.argtypes = []
+    lib.fnssl_head_backward_workspace_bytes.restype = sz
+    lib.fnssl_head_backward.argtypes = [vp, vp, vp, vp, i, i, i, vp, vp, vp, i, vp, sz, vp]
+    lib.fnssl_mse_loss.argtypes = [vp, vp, i, i, i, i, ll, vp, vp, i, vp, sz, vp]
+    lib.fnssl_adam_step.argtypes = [vp, vp, vp, vp, ll, f, f, f, f, i, f, vp]
     lib.fnssl_array_features.argtypes = [vp, vp, vp, vp, i, i, i, C.c_float, vp, vp, i, vp]
     lib.fnssl_conv3x3_packed_floats.argtypes = [i, i, i]
     lib.fnssl_conv3x3_packed_floats.restype = sz

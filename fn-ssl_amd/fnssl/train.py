@@ -1,0 +1,345 @@
+"""Training step of FN_SSL on one MI355X per rank (BASELINE config 4).
+
+Replaces, for the network part, what Lightning + autograd do in the reference's ``training_step`` /
+``cal_loss`` / ``configure_optimizers`` (FN-SSL/Lightning/main.py:149-157, 191-198, 269-271) and DDP's
+gradient all-reduce (main.py:286-288):
+
+    forward (train mode)   LSTM kernels that also save their gate activations, dropout + residual adds
+                           as one fused element-wise kernel per tensor (fnssl_train_combine)
+    loss                   fnssl_mse_loss (MSE of the re-batched prediction)
+    backward               fnssl_head_backward, one BPTT kernel per LSTM layer (fnssl_lstm_backward),
+                           weight gradients as plain GEMMs  dW = dA^T [x | h_prev]  (rocBLAS via torch.addmm),
+                           gradient accumulation + dropout backward again through fnssl_train_combine
+    all-reduce             ONE sum all-reduce of the flat fp32 gradient (2 511 362 floats) over RCCL
+    optimizer              fnssl_adam_step on the flat parameter vector (grad / world_size folded in)
+
+PyTorch provides memory, streams, the GEMM library call and torch.distributed; there is no autograd
+graph and no CPU fallback.  Dropout masks are a pure function of (seed, step, rank, layer, element), so
+the backward regenerates them instead of storing them (oracle/train_ref.py restates the hash).
+
+Tensor naming: logical [pairs, nt, nf, C]; "F" tensors are stored [b, t, f, C] (full-band natural order:
+one sequence per (b, t), steps along f), "N" tensors [b, f, t, C] (narrow-band natural order).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import BtfView, check
+
+H_FULL, H_NARR_ONLINE, CH = 128, 256, 256
+
+
+def _fmix32(h: int) -> int:
+    h &= 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def layer_seed(seed: int, layer: int) -> int:
+    """Same as oracle.train_ref.layer_seed."""
+    return _fmix32((seed + 0x9E3779B9 * (layer + 1)) & 0xFFFFFFFF)
+
+
+def _btf(t):
+    """logical [b, t, f, C] tensor (any strides, C contiguous) -> BtfView"""
+    if t.stride(3) != 1:
+        raise RuntimeError("fnssl.train: channel dimension must be contiguous")
+    return BtfView(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def combine(out, masked=(), plain=(), seed32=None, b0=0):
+    """out = keep_scale(seed32) * sum(masked) + sum(plain); all logical [b, t, f, C]."""
+    nb, nt, nf, c = out.shape
+    for t in tuple(masked) + tuple(plain):
+        if tuple(t.shape) != (nb, nt, nf, c) or not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError("fnssl.train.combine: operand %s vs output %s" % (tuple(t.shape), tuple(out.shape)))
+    mv = (BtfView * max(len(masked), 1))(*[_btf(t) for t in masked])
+    pv = (BtfView * max(len(plain), 1))(*[_btf(t) for t in plain])
+    o = _btf(out)
+    check(_lib.load().fnssl_train_combine(o.p, o.sb, o.st, o.sf, nb, nt, nf, c, mv, len(masked), pv, len(plain),
+                                          0 if seed32 is None else 1, 0 if seed32 is None else seed32, b0,
+                                          ops._stream()), "train_combine")
+    return out
+
+
+def dropout_scale(shape, seed32, device, b0=0):
+    """The keep-scale tensor itself, logical [b, t, f, C] contiguous (tests / debugging)."""
+    nb, nt, nf, c = shape
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.load().fnssl_dropout_scale(out.data_ptr(), out.numel(), seed32, b0 * nt * nf * c, ops._stream()),
+          "dropout_scale")
+    return out
+
+
+class _Layer:
+    """Static description of one LSTM of the network."""
+
+    def __init__(self, name, mode, hidden, ndir, c0, c2, c0g):
+        self.name, self.mode, self.hidden, self.ndir, self.c0, self.c2, self.c0g = name, mode, hidden, ndir, c0, c2, c0g
+        self.sfx = [""] + (["_reverse"] if ndir == 2 else [])
+
+
+class TrainEngine:
+    """Owns the flat parameter / gradient / Adam-moment vectors of a ``Model.FN_SSL`` and runs training steps.
+
+    ``model`` must live on a ROCm device; its parameters are re-pointed into the flat vector (so
+    ``state_dict()`` / checkpoints keep working and always show the current weights).
+    ``chunk_pairs`` bounds the activation memory: the rank's batch is processed in chunks of that many
+    microphone pairs with gradient accumulation (the result does not depend on it).
+    """
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, seed=0, chunk_pairs=None, process_group=None):
+        if getattr(model, "is_doa", False):
+            raise RuntimeError("fnssl.train: the DOA-classification variant is not part of the training path")
+        self.model = model
+        self.lr, self.betas, self.eps, self.seed = lr, betas, eps, seed
+        self.chunk_pairs = chunk_pairs
+        self.pg = process_group
+        self.step_count = 0
+        self.online = bool(model.is_online)
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("fnssl.train: the model must be on a ROCm device (no CPU path)")
+        self.dev = dev
+        named = list(model.named_parameters())
+        self.names = [k for k, _ in named]
+        sizes = [p.numel() for _, p in named]
+        self.nparam = int(sum(sizes))
+        # element 0 is a constant 0 so that index maps can point "nowhere"
+        self.theta = torch.zeros(1 + self.nparam, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.theta)
+        self.exp_avg = torch.zeros_like(self.theta)
+        self.exp_avg_sq = torch.zeros_like(self.theta)
+        self.offset, off = {}, 1
+        for (k, p), n in zip(named, sizes):
+            self.theta[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.theta[off:off + n].view(p.shape)
+            self.offset[k] = (off, tuple(p.shape))
+            off += n
+        nh = H_NARR_ONLINE if self.online else H_FULL
+        nd = 1 if self.online else 2
+        self.layers = []
+        for k in (1, 2, 3):
+            first = k == 1
+            self.layers.append(_Layer("block_%d.fullLstm" % k, "full", H_FULL, 2, 0 if first else CH, 4 if first else 0,
+                                      0 if first else CH))
+            self.layers.append(_Layer("block_%d.narrLstm" % k, "narrow", nh, nd, CH, 4 if first else 0, CH))
+        self._build_index_maps()
+        self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._scratch = {}
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def gview(self, name):
+        off, shape = self.offset[name]
+        return self.grad[off:off + int(np.prod(shape))].view(shape)
+
+    def pview(self, name):
+        off, shape = self.offset[name]
+        return self.theta[off:off + int(np.prod(shape))].view(shape)
+
+    def _build_index_maps(self):
+        """Gather maps flat-vector -> packed weight streams, built once by running the host packers on
+        index-valued weights (indices < 2^24 are exact in fp32)."""
+        self.maps = {}
+        for L in self.layers:
+            for s in L.sfx:
+                oi, shi = self.offset["%s.weight_ih_l0%s" % (L.name, s)]
+                oh, shh = self.offset["%s.weight_hh_l0%s" % (L.name, s)]
+                obi, shb = self.offset["%s.bias_ih_l0%s" % (L.name, s)]
+                obh, _ = self.offset["%s.bias_hh_l0%s" % (L.name, s)]
+                wi = (oi + np.arange(np.prod(shi), dtype=np.float64)).astype(np.float32).reshape(shi)
+                wh = (oh + np.arange(np.prod(shh), dtype=np.float64)).astype(np.float32).reshape(shh)
+                bi = (obi + np.arange(shb[0], dtype=np.float64)).astype(np.float32)
+                bh = (obh + np.arange(shb[0], dtype=np.float64)).astype(np.float32)
+                z = np.zeros(shb[0], dtype=np.float32)
+                a = ops.pack_lstm_host(wi, wh, bi, z, L.c0, L.c2)
+                b = ops.pack_lstm_host(np.zeros_like(wi), np.zeros_like(wh), z, bh, L.c0, L.c2)
+                bw = ops.pack_lstm_bwd_host(wi, wh, L.c0g)
+                to = lambda v: torch.from_numpy(v.astype(np.int64)).to(self.dev)  # noqa: E731
+                self.maps[(L.name, s)] = (to(a), to(b), to(bw))
+
+    def _pack_all(self):
+        """Device-side re-pack of every weight stream from the current flat parameters (two gathers)."""
+        fw, bw = {}, {}
+        for L in self.layers:
+            fw[L.name] = []
+            bw[L.name] = []
+            for s in L.sfx:
+                ia, ib, ibw = self.maps[(L.name, s)]
+                fw[L.name].append(self.theta[ia] + self.theta[ib])
+                bw[L.name].append(self.theta[ibw])
+        return fw, bw
+
+    def _buf(self, key, shape):
+        n = int(np.prod(shape))
+        b = self._scratch.get(key)
+        if b is None or b.numel() < n:
+            b = torch.empty(n, dtype=torch.float32, device=self.dev)
+            self._scratch[key] = b
+        return b[:n].view(shape)
+
+    # ------------------------------------------------------------------ one chunk of pairs
+    def _natural(self, key, L, nbp, nt, nf, c):
+        """Logical [b, t, f, c] tensor stored in layer L's natural layout."""
+        if L.mode == "full":
+            return self._buf(key, (nbp, nt, nf, c))
+        return self._buf(key, (nbp, nf, nt, c)).permute(0, 2, 1, 3)
+
+    @staticmethod
+    def _rows(t_logical, L):
+        """[rows = seq * step, C] matrix of a tensor stored in L's natural layout."""
+        st = t_logical if L.mode == "full" else t_logical.permute(0, 2, 1, 3)
+        return st.reshape(-1, st.shape[-1])
+
+    def _weight_grads(self, L, da, x0, x2, hout):
+        """dW_ih = dA^T [x0 | x2],  dW_hh = dA^T h_prev,  db = sum dA  (accumulated into the flat gradient)."""
+        nseq_steps = self._rows(da, L)
+        H, nd = L.hidden, L.ndir
+        nsteps = da.shape[2] if L.mode == "full" else da.shape[1]
+        hrows = self._rows(hout, L).view(-1, nsteps, nd * H)
+        for di, s in enumerate(L.sfx):
+            a = nseq_steps[:, di * 4 * H:(di + 1) * 4 * H]
+            at = a.t()
+            gih = self.gview("%s.weight_ih_l0%s" % (L.name, s))
+            if L.c0:
+                gih[:, :L.c0].addmm_(at, self._rows(x0, L))
+            if L.c2:
+                gih[:, L.c0:].addmm_(at, self._rows(x2, L))
+            hp = self._buf("hprev", (hrows.shape[0], nsteps, H))
+            hd = hrows[:, :, di * H:(di + 1) * H]
+            if di == 0:
+                hp[:, 0].zero_()
+                hp[:, 1:].copy_(hd[:, :-1])
+            else:
+                hp[:, -1].zero_()
+                hp[:, :-1].copy_(hd[:, 1:])
+            self.gview("%s.weight_hh_l0%s" % (L.name, s)).addmm_(at, hp.view(-1, H))
+            db = a.sum(dim=0)
+            self.gview("%s.bias_ih_l0%s" % (L.name, s)).add_(db)
+            self.gview("%s.bias_hh_l0%s" % (L.name, s)).add_(db)
+
+    def _chunk(self, x, gt, b0, n_total, fw, bw, seeds):
+        """Forward + backward of pairs [b0, b0 + nbp) (x [nbp, 4, nf, nt]); accumulates grads and the loss."""
+        nbp, _, nf, nt = x.shape
+        npair = gt.shape[3]
+        Lf = [self.layers[0], self.layers[2], self.layers[4]]
+        Ln = [self.layers[1], self.layers[3], self.layers[5]]
+        XF = ops.nchw_to_seq(x)                                    # [b, t, f, 4]
+        XN = XF.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)   # same numbers, stored [b, f, t, 4]
+        res, U, F, V, N = {}, {}, {}, {}, {}
+        Xk = None
+        # ---------------- forward (train mode) ----------------
+        for k in (1, 2, 3):
+            lf, ln = Lf[k - 1], Ln[k - 1]
+            F[k] = self._natural("F%d" % k, lf, nbp, nt, nf, 2 * H_FULL)
+            res[lf.name] = self._buf("R" + lf.name, (ops.lstm_reserve_floats(nbp * nt, lf.hidden, 2, nf),))
+            if k == 1:
+                ops.lstm_layer("full", None, None, XF, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+            else:
+                U[k] = self._natural("U%d" % k, lf, nbp, nt, nf, CH)
+                combine(U[k], plain=(Xk, F[k - 1]))                                   # x + fb_skip  (:36-37)
+                ops.lstm_layer("full", U[k], None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+            V[k] = self._natural("V%d" % k, ln, nbp, nt, nf, CH)
+            if k == 1:
+                combine(V[k], masked=(F[k],), seed32=seeds[0], b0=b0)                # dropout_full (:40)
+            else:
+                combine(V[k], masked=(F[k],), plain=(Xk,), seed32=seeds[2 * k - 2], b0=b0)   # + nb_skip (:44-45)
+            N[k] = self._natural("N%d" % k, ln, nbp, nt, nf, ln.ndir * ln.hidden)
+            res[ln.name] = self._buf("R" + ln.name, (ops.lstm_reserve_floats(nbp * nf, ln.hidden, ln.ndir, nt),))
+            ops.lstm_layer("narrow", V[k], None, XN if k == 1 else None, fw[ln.name], ln.hidden, N[k],
+                           reserve=res[ln.name])
+            Xk = self._natural("X", ln, nbp, nt, nf, CH)
+            combine(Xk, masked=(N[k],), seed32=seeds[2 * k - 1], b0=b0)             # dropout_narr (:48)
+        X4 = Xk.permute(0, 2, 1, 3)                                                  # storage [b, f, t, 256]
+        wname, bname = "emb2ipd.weight", "emb2ipd.bias"
+        pred = ops.head(X4, self.pview(wname), self.pview(bname))                    # [nbp, nt2, 2nf]
+        nt2 = pred.shape[1]
+        lib = _lib.load()
+        dpred = self._buf("dpred", tuple(pred.shape))
+        ws = self._buf("ws_small", (max(lib.fnssl_head_backward_workspace_bytes() // 4, 256),))
+        check(lib.fnssl_mse_loss(pred.data_ptr(), gt.data_ptr(), nbp // npair, npair, nt2, 2 * nf, n_total,
+                                 dpred.data_ptr(), self.loss_dev.data_ptr(), 1, ws.data_ptr(), ws.numel() * 4,
+                                 ops._stream()), "mse_loss")
+        # ---------------- backward ----------------
+        G = self._buf("G", (nbp, nf, nt, CH))                                        # dL/dX4, N storage
+        check(lib.fnssl_head_backward(X4.data_ptr(), self.pview(wname).data_ptr(), pred.data_ptr(), dpred.data_ptr(),
+                                      nbp, nf, nt, G.data_ptr(), self.gview(wname).data_ptr(),
+                                      self.gview(bname).data_ptr(), 1, ws.data_ptr(), ws.numel() * 4, ops._stream()),
+              "head_backward")
+        gx = (G.permute(0, 2, 1, 3),)                     # operands whose sum is dL/dX_{k+1}
+        dfb = ()                                           # operands whose sum is dL/dF_k through fb_skip
+        for k in (3, 2, 1):
+            lf, ln = Lf[k - 1], Ln[k - 1]
+            DN = self._natural("DN", ln, nbp, nt, nf, ln.ndir * ln.hidden)
+            combine(DN, masked=gx, seed32=seeds[2 * k - 1], b0=b0)                   # dropout_narr backward
+            dA = self._natural("dA", ln, nbp, nt, nf, ln.ndir * 4 * ln.hidden)
+            DV = self._natural("DV%d" % (k & 1), ln, nbp, nt, nf, ln.ndir * CH)
+            ops.lstm_backward("narrow", res[ln.name], DN, dA, DV, bw[ln.name], ln.hidden, CH)
+            self._weight_grads(ln, dA, V[k], XN if k == 1 else None, N[k])
+            dv = tuple(DV[..., d * CH:(d + 1) * CH] for d in range(ln.ndir))        # one slab per direction
+            DF = self._natural("DF", lf, nbp, nt, nf, 2 * H_FULL)
+            combine(DF, masked=dv, plain=dfb, seed32=seeds[2 * k - 2], b0=b0)       # dropout_full backward + fb_skip
+            dA = self._natural("dA", lf, nbp, nt, nf, 2 * 4 * H_FULL)
+            if k > 1:
+                DU = self._natural("DU%d" % (k & 1), lf, nbp, nt, nf, 2 * CH)
+                ops.lstm_backward("full", res[lf.name], DF, dA, DU, bw[lf.name], lf.hidden, CH)
+                self._weight_grads(lf, dA, U[k], None, F[k])
+                du = (DU[..., :CH], DU[..., CH:])
+                if len(dv) + 2 > 3:          # offline narrow-band: 2 + 2 operands -> fold the full-band pair first
+                    S = self._natural("S", lf, nbp, nt, nf, CH)
+                    combine(S, plain=du)
+                    du = (S,)
+                gx = dv + du                 # dL/dX_k = dV_k + dU_k  (both uses of x: nb_skip and the full-band input)
+                dfb = du                     # dL/dF_{k-1} through fb_skip
+            else:
+                ops.lstm_backward("full", res[lf.name], DF, dA, None, bw[lf.name], lf.hidden, 0)
+                self._weight_grads(lf, dA, None, XF, F[k])
+        return pred
+
+    # ------------------------------------------------------------------ public API
+    def step(self, x, gt_ipd, sync_loss=True):
+        """One optimisation step.  x [nb*np, 4, nf, nt] features (data_preprocess output), gt_ipd
+        [nb, nt//12, 2*nf, np] targets, both on the device.  Returns the loss (float, or the device scalar when
+        ``sync_loss`` is False)."""
+        ops._need_dev(x, gt_ipd)
+        nbp, cin, nf, nt = x.shape
+        nb, nt2, nf2, npair = gt_ipd.shape
+        if cin != 4 or nb * npair != nbp or nt2 != nt // 12 or nf2 != 2 * nf or nt2 == 0:
+            raise RuntimeError("fnssl.train.step: x %s does not match gt_ipd %s" % (tuple(x.shape), tuple(gt_ipd.shape)))
+        self.step_count += 1
+        world = torch.distributed.get_world_size(self.pg) if (torch.distributed.is_available() and
+                                                              torch.distributed.is_initialized()) else 1
+        rank = torch.distributed.get_rank(self.pg) if world > 1 else 0
+        base = (self.seed * 1000003 + self.step_count * 8191 + rank * 131071) & 0xFFFFFFFF
+        seeds = [layer_seed(base, l) for l in range(6)]
+        self.last_seed = base
+        fw, bw = self._pack_all()
+        self.grad.zero_()
+        self.loss_dev.zero_()
+        n_total = nbp * nt2 * nf2
+        cp = self.chunk_pairs or nbp
+        cp = max(npair, (cp // npair) * npair)            # whole utterances per chunk
+        gt_ipd = gt_ipd.contiguous()
+        for b0 in range(0, nbp, cp):
+            b1 = min(nbp, b0 + cp)
+            self._chunk(x[b0:b1].contiguous(), gt_ipd[b0 // npair:b1 // npair], b0, n_total, fw, bw, seeds)
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        check(_lib.load().fnssl_adam_step(self.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                          self.exp_avg_sq.data_ptr(), self.theta.numel(), self.lr, self.betas[0],
+                                          self.betas[1], self.eps, self.step_count, 1.0 / world, ops._stream()),
+              "adam_step")
+        self.theta[0] = 0.0
+        return float(self.loss_dev.item()) if sync_loss else self.loss_dev
+
+    def gradients(self):
+        """name -> gradient tensor (views of the flat vector; as left by the last step, before the 1/world scale)."""
+        return {k: self.gview(k) for k in self.names}

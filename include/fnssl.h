@@ -193,6 +193,56 @@ typedef struct {
 
 int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream);
 
+/* A logical [nb, nt, nf, C] activation in any memory layout: element (b, t, f, c) at p[b*sb + t*st + f*sf + c]. */
+typedef struct {
+  const float* p;
+  long long sb, st, sf;
+} fnssl_btf_view;
+
+/*
+ * out = keep_scale(seed32) * (masked[0] + .. ) + (plain[0] + ..): the dropouts and residual adds of
+ * FNblock.forward in train mode (FN-SSL/Model.py:36-48) and their backward (gradient accumulation +
+ * dropout backward), including the full-band <-> narrow-band layout change (every operand has its own
+ * strides).  keep_scale is 0 or 1/(1-p) = 1.25 (p = 0.2), a pure function of seed32 and the logical
+ * element index ((b0 + b)*nt + t)*nf + f)*C + c, so forward and backward regenerate the same mask and
+ * no mask tensor exists.  use_mask = 0: plain sum.  C % 4 == 0.
+ */
+int fnssl_train_combine(float* out, long long o_sb, long long o_st, long long o_sf,
+                        int nb, int nt, int nf, int c,
+                        const fnssl_btf_view* masked, int n_masked,
+                        const fnssl_btf_view* plain, int n_plain,
+                        int use_mask, unsigned seed32, long long b0, void* stream);
+
+/* out[i] = keep_scale(seed32, offset + i): the mask itself (tests / debugging). */
+int fnssl_dropout_scale(float* out, long long n, unsigned seed32, long long offset, void* stream);
+
+size_t fnssl_head_backward_workspace_bytes(void);
+
+/*
+ * Backward of fnssl_head (pooling + emb2ipd + tanh, FN-SSL/Model.py:79-87):
+ *   x [nb, nf, nt, 256] the head input, pred / dpred [nb, nt//12, 2*nf]
+ *   dx [nb, nf, nt, 256] (written);  dw [2, 256], db [2] (written, or += when accumulate != 0)
+ */
+int fnssl_head_backward(const float* x, const float* w, const float* pred, const float* dpred,
+                        int nb, int nf, int nt, float* dx, float* dw, float* db, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * cal_loss (FN-SSL/Lightning/main.py:191-198): MSE between the re-batched prediction and the target.
+ *   pred [nb*np, nt2, nf2], gt [nb, nt2, nf2, np];  n_total = element count of the WHOLE batch the mean
+ *   runs over (>= nb*np*nt2*nf2 when the batch is processed in chunks)
+ *   dpred = 2 (pred - gt) / n_total;  *loss (DEVICE) = or += sum((pred - gt)^2) / n_total
+ *   workspace >= 1 KiB.
+ */
+int fnssl_mse_loss(const float* pred, const float* gt, int nb, int np, int nt2, int nf2, long long n_total,
+                   float* dpred, float* loss, int accumulate, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* torch.optim.Adam (main.py:269-271; no amsgrad, no weight decay) on a flat vector; the gradient is
+ * multiplied by grad_scale first (1 / world_size after the sum all-reduce).  step counts from 1. */
+int fnssl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Head                                                                      */
 /* ------------------------------------------------------------------------- */

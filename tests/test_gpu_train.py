@@ -103,3 +103,102 @@ def test_lstm_layer_gradients_match_autograd(dev, mode, H, bidir, c0, c2, c0g, n
         rel_close(dwih.cpu().numpy(), g["weight_ih_l0" + s], 2e-4, "dW_ih" + s)
         rel_close(dwhh.cpu().numpy(), g["weight_hh_l0" + s], 2e-4, "dW_hh" + s)
         rel_close(db.cpu().numpy(), g["bias_ih_l0" + s], 2e-4, "db" + s)
+
+
+def _engine(dev, online, wseed, **kw):
+    import Model
+    from fnssl import train
+    from fnssl import weights as W
+    sd = W.make_fnssl_state(wseed, 4, 256, online)
+    net = Model.FN_SSL(is_online=online)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev)
+    return sd, net, train.TrainEngine(net, **kw)
+
+
+def test_dropout_scale_matches_oracle_hash(dev):
+    from fnssl import train
+    from oracle import train_ref as T
+    for seed, layer in ((0, 0), (123456789, 5)):
+        s32 = train.layer_seed(seed, layer)
+        assert s32 == T.layer_seed(seed, layer)
+        got = train.dropout_scale((3, 5, 7, 256), s32, dev, b0=2).cpu().numpy()
+        assert np.array_equal(got, T.dropout_scale(s32, (3, 5, 7, 256), b0=2))
+
+
+def test_combine_is_dropout_plus_residual_in_any_layout(dev):
+    from fnssl import train
+    from oracle import train_ref as T
+    nb, nt, nf, c = 2, 5, 6, 256
+    a = to_dev(rs_randn(1, (nb, nt, nf, c)), dev)
+    b_store = to_dev(rs_randn(2, (nb, nf, nt, c)), dev)          # narrow-band storage
+    cc = to_dev(rs_randn(3, (nb, nt, nf, c)), dev)
+    s32 = train.layer_seed(9, 2)
+    out = torch.empty((nb, nf, nt, c), device=dev).permute(0, 2, 1, 3)
+    train.combine(out, masked=(a, b_store.permute(0, 2, 1, 3)), plain=(cc,), seed32=s32, b0=4)
+    m = T.dropout_scale(s32, (nb, nt, nf, c), b0=4)
+    want = (a.cpu().numpy() + b_store.permute(0, 2, 1, 3).cpu().numpy()) * m + cc.cpu().numpy()
+    assert np.array_equal(out.cpu().numpy(), want.astype(np.float32))
+    plain = torch.empty((nb, nt, nf, c), device=dev)
+    train.combine(plain, plain=(a, cc))
+    assert torch.equal(plain, a + cc)
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_training_step_matches_oracle_and_reference_golden(dev, case):
+    """Loss, every gradient and the Adam update of one step against the autograd oracle, and against the
+    projections of the REAL reference's gradients (g13)."""
+    from oracle import train_ref as T
+    g = load_golden("g13_train")
+    online, nb, npair, nf, nt, seed, wseed, xseed, gseed = [int(v) for v in g["c%d_cfg" % case]]
+    sd, net, eng = _engine(dev, bool(online), wseed)
+    x = rs_randn(xseed, (nb * npair, 4, nf, nt))
+    gt = rs_randn(gseed, (nb, nt // 12, 2 * nf, npair), 0.5)
+    # make the engine draw the golden's masks
+    eng.seed, eng.step_count = 0, 0
+    import fnssl.train as tr
+    orig = tr.layer_seed
+    try:
+        tr.layer_seed = lambda base, l: orig(seed, l)
+        loss = eng.step(to_dev(x, dev), to_dev(gt, dev))
+    finally:
+        tr.layer_seed = orig
+    want_loss, grads, new_sd, _, _ = T.train_step(sd, x, gt, seed, 256, bool(online))
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+    assert abs(loss - float(g["c%d_loss" % case])) <= 1e-5 * abs(want_loss)
+    got = eng.gradients()
+    names = [str(s) for s in g["c%d_names" % case]]
+    assert names == list(got.keys())
+    for i, k in enumerate(names):
+        rel_close(got[k].cpu().numpy(), grads[k], 5e-4, "grad " + k)
+        a = got[k].cpu().numpy().astype(np.float64)
+        r = rs_randn(5000 + i, a.shape).astype(np.float64)
+        want = g["c%d_gproj" % case][i]
+        assert abs(np.sqrt((a * a).sum()) - want[0]) <= 5e-4 * want[0] + 1e-12, ("norm vs reference", k)
+    for k in names:
+        d_got = net.state_dict()[k].cpu().numpy() - sd[k]
+        d_want = new_sd[k] - sd[k]
+        # Adam's first step moves every weight by ~lr * sign(grad): compare where the gradient is not tiny
+        big = np.abs(grads[k]) > 1e-3 * np.abs(grads[k]).max()
+        assert np.abs(d_got - d_want)[big].max() <= 2e-5, ("adam update", k)
+
+
+def test_training_steps_chunked_equals_whole_and_adam_state_advances(dev):
+    from oracle import train_ref as T
+    nb, npair, nf, nt = 2, 2, 4, 12
+    x = rs_randn(31, (nb * npair, 4, nf, nt))
+    gt = rs_randn(32, (nb, 1, 2 * nf, npair), 0.5)
+    sd, net_a, eng_a = _engine(dev, True, 77, seed=5)
+    _, net_b, eng_b = _engine(dev, True, 77, seed=5, chunk_pairs=2)
+    la = [eng_a.step(to_dev(x, dev), to_dev(gt, dev)) for _ in range(2)]
+    lb = [eng_b.step(to_dev(x, dev), to_dev(gt, dev)) for _ in range(2)]
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(la[0]) and abs(la[1] - lb[1]) <= 1e-5 * abs(la[1])
+    for k, v in net_a.state_dict().items():
+        assert (v - net_b.state_dict()[k]).abs().max() <= 1e-5, k
+    # two oracle steps with the engine's seeds
+    s1 = (5 * 1000003 + 1 * 8191) & 0xFFFFFFFF
+    s2 = (5 * 1000003 + 2 * 8191) & 0xFFFFFFFF
+    l1, _, sd1, st1, _ = T.train_step(sd, x, gt, s1, 256, True)
+    l2, _, sd2, _, _ = T.train_step(sd1, x, gt, s2, 256, True, adam_state=st1, step=2)
+    assert abs(la[0] - l1) <= 1e-5 * abs(l1) and abs(la[1] - l2) <= 1e-4 * abs(l2)
+    assert la[1] < la[0], "the loss goes down on a repeated batch"

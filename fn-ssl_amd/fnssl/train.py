@@ -79,6 +79,26 @@ def dropout_scale(shape, seed32, device, b0=0):
     return out
 
 
+def sync_gradients(flat_grad, group=None):
+    """DDP's exchange step (main.py:286-288): ONE sum all-reduce of the flat gradient; returns the factor the
+    optimizer has to apply (1 / world_size — Lightning DDP averages).  Works on any backend (RCCL on the
+    GPUs; the CPU tests run it over gloo)."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
+def shard_utterances(n_utts: int, rank: int, world: int):
+    """Contiguous utterance range of this rank (a global batch of 256 -> 32 per GPU at world 8)."""
+    per, rem = divmod(n_utts, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
 class _Layer:
     """Static description of one LSTM of the network."""
 
@@ -331,13 +351,17 @@ class TrainEngine:
         for b0 in range(0, nbp, cp):
             b1 = min(nbp, b0 + cp)
             self._chunk(x[b0:b1].contiguous(), gt_ipd[b0 // npair:b1 // npair], b0, n_total, fw, bw, seeds)
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        gscale = sync_gradients(self.grad, self.pg)
         check(_lib.load().fnssl_adam_step(self.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                           self.exp_avg_sq.data_ptr(), self.theta.numel(), self.lr, self.betas[0],
-                                          self.betas[1], self.eps, self.step_count, 1.0 / world, ops._stream()),
+                                          self.betas[1], self.eps, self.step_count, gscale, ops._stream()),
               "adam_step")
         self.theta[0] = 0.0
+        # the parameters changed under the inference modules' feet: drop their packed-weight caches
+        for m in self.model.modules():
+            for attr in ("_packed_key", "_net_key"):
+                if hasattr(m, attr):
+                    setattr(m, attr, None)
         return float(self.loss_dev.item()) if sync_loss else self.loss_dev
 
     def gradients(self):

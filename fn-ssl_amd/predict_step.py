@@ -6,8 +6,11 @@ returns the raw DP-IPD predictions ``[nb*np, nt//12, 512]``.
 ``LightningModule`` (so ``Trainer.predict`` / ``LightningCLI`` drive it exactly
 like the reference's ``main.py predict``); without it the same class derives
 from ``nn.Module`` and ``predict_step`` is called directly (``Predict.py``).
-Training/validation steps, the numpy DP-IPD target generator and the DOA
-metrics are outside this path.
+``training_step`` (main.py:149-157) runs the HIP training path (fnssl.train: forward with
+dropout, MSE loss, BPTT, RCCL gradient all-reduce, Adam) and, because that path carries its own
+backward and optimizer, returns the loss as a detached scalar; ``configure_optimizers`` hands Lightning
+nothing to do.  The numpy DP-IPD target generator and the DOA metrics stay outside this path
+(SURVEY.md §8): ``gt_batch['ipd']`` must already hold the target IPDs.
 """
 import torch
 
@@ -38,6 +41,44 @@ class MyModel(_Base):
 
     def forward(self, x):
         return self.arch(x)
+
+    # ---- training (main.py:149-157, 191-198, 269-279) ------------------------------------------
+    def _engine(self):
+        if getattr(self, "_train_engine", None) is None:
+            from fnssl import train
+            self._train_engine = train.TrainEngine(self.arch, lr=0.001)          # Adam, lr 1e-3 (main.py:270)
+        return self._train_engine
+
+    def training_step(self, batch, batch_idx: int = 0):
+        """batch = (mic_sig_batch [nb, ns, nch], gt_batch with 'ipd' [nb, nt//12, 512, np]).
+        One complete optimisation step on this rank's shard; returns {"loss": detached scalar}."""
+        mic_sig_batch, gt_batch = batch[0], batch[1]
+        x = ops.preprocess(mic_sig_batch.to(self.dev), self.ch_mode, 1e-6, layout=1)
+        loss = self._engine().step(x, gt_batch['ipd'].to(self.dev), sync_loss=False)
+        return {"loss": loss.detach().clone().reshape(())}
+
+    def cal_loss(self, pred_batch=None, gt_batch=None):
+        """main.py:191-198 on device: MSE of the re-batched prediction (no gradient is recorded)."""
+        pred = pred_batch.contiguous()
+        gt = gt_batch['ipd'].to(pred.device).contiguous()
+        nb, nt2, nf2, npair = gt.shape
+        lib = ops._lib.load()
+        dpred = torch.empty_like(pred)
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        ws = torch.empty(256, dtype=torch.float32, device=pred.device)
+        ops.check(lib.fnssl_mse_loss(pred.data_ptr(), gt.data_ptr(), nb, npair, nt2, nf2, pred.numel(),
+                                     dpred.data_ptr(), loss.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4,
+                                     ops._stream()), "mse_loss")
+        return loss.reshape(())
+
+    def configure_optimizers(self):
+        """The optimizer (Adam, lr 1e-3; the ExponentialLR decay is applied by ``on_train_epoch_end``) lives in
+        the HIP training engine; Lightning gets no optimizer to step."""
+        return None
+
+    def on_train_epoch_end(self):
+        if getattr(self, "_train_engine", None) is not None:
+            self._train_engine.lr *= 0.8988                                      # ExponentialLR gamma (main.py:272)
 
     def data_preprocess(self, mic_sig_batch=None, gt_batch=None, vad_batch=None, eps=1e-6, nor_flag=True):
         """Input half of main.py:200-225: [nb, ns, nch] -> [[nb*np, 4, 256, nt]] (reference layout)."""

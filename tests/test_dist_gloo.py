@@ -70,3 +70,36 @@ def test_two_rank_sharded_predict_matches_single_process(tmp_path, nb):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         np.testing.assert_array_equal(got, want)     # uneven shards (2+1, 1+0) included
+
+
+# ---- training: the gradient exchange step (fnssl.train.sync_gradients) over gloo ----------------------
+def _grad_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "fn-ssl_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from fnssl import train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = train.shard_utterances(5, rank, world)
+    # the "gradient" of a rank = sum over its utterances of a per-utterance vector
+    per_utt = torch.from_numpy(rs_randn(70, (5, 1000)))
+    flat = per_utt[lo:hi].sum(dim=0)
+    scale = train.sync_gradients(flat)
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), (flat * scale).numpy())
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    from fnssl import train
+    assert [train.shard_utterances(256, r, 8) for r in (0, 7)] == [(0, 32), (224, 256)]
+    spans = [train.shard_utterances(5, r, 2) for r in range(2)]
+    assert spans == [(0, 3), (3, 5)]
+    assert train.sync_gradients(torch.ones(3)) == 1.0          # no process group: identity
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want = rs_randn(70, (5, 1000)).sum(axis=0) / 2.0
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), "g%d.npy" % r))
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-6)

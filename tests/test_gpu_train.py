@@ -202,3 +202,28 @@ def test_training_steps_chunked_equals_whole_and_adam_state_advances(dev):
     l2, _, sd2, _, _ = T.train_step(sd1, x, gt, s2, 256, True, adam_state=st1, step=2)
     assert abs(la[0] - l1) <= 1e-5 * abs(l1) and abs(la[1] - l2) <= 1e-4 * abs(l2)
     assert la[1] < la[0], "the loss goes down on a repeated batch"
+
+
+def test_mymodel_training_step_dropin(dev):
+    """Lightning-style surface: training_step((mic_sig, {'ipd': gt})) -> {'loss'}; the inference entry sees
+    the updated weights afterwards; cal_loss equals the oracle's MSE."""
+    import predict_step as ps
+    from fnssl import weights as W
+    from oracle import train_ref as T
+    m = ps.MyModel(device="cuda")
+    m.arch.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_fnssl_state(5).items()})
+    m.to(dev)
+    sig = to_dev(rs_randn(41, (2, 512 + 23 * 256, 2), 0.1), dev)          # [nb, ns, nch] -> 24 frames
+    gt = to_dev(np.full((2, 2, 512, 1), 0.5, dtype=np.float32) + rs_randn(42, (2, 2, 512, 1), 0.05), dev)   # learnable
+    pred0 = m.predict_step(sig.permute(0, 2, 1))
+    l0 = m.cal_loss(pred0, {"ipd": gt})
+    want = float(T.cal_loss(pred0.cpu(), gt.cpu()))
+    assert abs(float(l0) - want) <= 1e-6 * want
+    out = m.training_step((sig, {"ipd": gt}), 0)
+    assert out["loss"].shape == () and torch.isfinite(out["loss"])
+    pred1 = m.predict_step(sig.permute(0, 2, 1))
+    assert not torch.equal(pred0, pred1), "inference must pick up the trained weights"
+    for _ in range(3):
+        m.training_step((sig, {"ipd": gt}), 0)
+    assert float(m.cal_loss(m.predict_step(sig.permute(0, 2, 1)), {"ipd": gt})) < float(l0)
+    assert m.configure_optimizers() is None

@@ -149,6 +149,57 @@ class FN_SSL(nn.Module):
         return self.forward_seq(ops.nchw_to_seq(x))               # permute(0,3,2,1), Model.py:73
 
 
+    def forward_stream(self, x, state=None):
+        """Streaming inference of the online (causal) model — the state carry the reference's causality
+        permits but does not implement.
+
+        x [nb', input_size, nf, T]: the NEXT T frames (T a positive multiple of 12); ``state`` is None for
+        the first chunk, afterwards what the previous call returned.  Returns (DP-IPD [nb', T//12, 2*nf],
+        state).  Consecutive chunks give bit-for-bit what ``forward`` gives on the whole signal: the
+        full-band BiLSTMs only look along frequency inside a frame, the narrow-band LSTMs continue from
+        their carried (h, c).
+        """
+        _require_eval(self)
+        if not self.is_online:
+            raise RuntimeError("FN_SSL.forward_stream: only the online model (uni-directional narrow-band) streams")
+        if x.ndim != 4 or x.shape[1] != self.input_size or x.shape[3] == 0 or x.shape[3] % ops.SEG_FRAMES:
+            raise RuntimeError("FN_SSL.forward_stream: expected [nb, %d, nf, T] with T a positive multiple of 12, got %s"
+                               % (self.input_size, tuple(x.shape)))
+        nb, _, nf, T = x.shape
+        dev = x.device
+        blocks = (self.block_1, self.block_2, self.block_3)
+        if state is None:
+            state = {"ws": [ops.lstm_state_workspace(nb * nf, b.narr_hidden_size, dev) for b in blocks],
+                     "h": [None, None, None], "shape": (nb, nf), "frames": 0}
+        elif state["shape"] != (nb, nf):
+            raise RuntimeError("FN_SSL.forward_stream: batch / bins changed between chunks")
+        cur = ops.nchw_to_seq(x)                                    # [nb, T, nf, C]
+        fb_prev = None
+        for k, blk in enumerate(blocks):
+            full_w, narr_w = blk._streams(dev)
+            f = torch.empty((nb, T, nf, 2 * blk.full_hidden_size), dtype=torch.float32, device=dev)
+            ops.lstm_layer("full", cur, None if blk.is_first else fb_prev, None, full_w, blk.full_hidden_size, f)
+            nbuf = torch.empty((nb, nf, T + 1, blk.narr_hidden_size), dtype=torch.float32, device=dev)
+            started = state["h"][k] is not None
+            if started:
+                nbuf[:, :, 0].copy_(state["h"][k])                  # h_{-1}: the row before the chunk's output
+            out = nbuf[:, :, 1:].permute(0, 2, 1, 3)                # logical [nb, T, nf, Hn]
+            if blk.is_first:
+                ops.lstm_layer("narrow", f, None, cur, narr_w, blk.narr_hidden_size, out,
+                               carry_workspace=state["ws"][k], carry=started)
+            else:
+                ops.lstm_layer("narrow", f, cur, None, narr_w, blk.narr_hidden_size, out,
+                               carry_workspace=state["ws"][k], carry=started)
+            state["h"][k] = nbuf[:, :, T].clone()
+            cur, fb_prev = out, f
+        y = ops.head(nbuf[:, :, 1:].contiguous(), self.emb2ipd.weight.detach(), self.emb2ipd.bias.detach())
+        if self.is_doa:
+            y = ops.linear(y.reshape(-1, y.shape[-1]), self.ipd2doa.weight.detach().t().contiguous(),
+                           self.ipd2doa.bias.detach()).reshape(nb, T // ops.SEG_FRAMES, -1)
+        state["frames"] += T
+        return y, state
+
+
 class FN_lightning(nn.Module):
     """Wrapper whose ``arch.`` prefix matches Lightning checkpoints (Model.py:92-99)."""
 

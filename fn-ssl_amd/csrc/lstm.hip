@@ -146,8 +146,12 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.src1 = View{d->src1.p, d->src1.so, d->src1.si, d->src1.st};
   p.src2 = View{d->src2.p, d->src2.so, d->src2.si, d->src2.st};
   p.skip = View{d->skip.p, d->skip.so, d->skip.si, d->skip.st};
-  p.out = d->out;
-  p.out_sum = d->out_sum;
+  FNSSL_REQUIRE(!d->carry_state || (d->ndir == 1 && !d->reserve),
+                "lstm_forward: carry_state needs a uni-directional layer (and is not a training mode)");
+  p.carry = d->carry_state ? 1 : 0;
+  // streaming: the kernel addresses the output one row down so that "step -1" is the caller's h_{-1} row
+  p.out = d->carry_state ? d->out - d->out_st : d->out;
+  p.out_sum = (d->carry_state && d->out_sum) ? d->out_sum - d->out_st : d->out_sum;
   p.out_so = d->out_so;
   p.out_si = d->out_si;
   p.out_st = d->out_st;

@@ -32,7 +32,8 @@ struct LstmParams {
   const float* wpack[2];
   float* cscratch;
   float* reserve;     // training forward (MODE bit kSave): gates + cell state per (dir, group, step, slice)
-  int ntasks;         // 16-sequence groups per direction (reserve indexing)
+  int ntasks;         // 16-sequence groups per direction (reserve / cell-state indexing)
+  int carry;          // streaming: 1 = h_{-1} is the row before `out` (host passes out - out_st), c_{-1} is in cscratch
   int c0, c2;
   int nseq, q_inner, nsteps, ndir;
   int wgs_per_dir;
@@ -292,8 +293,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
   unsigned voo2 = 0;
   const rsrc_t ro2 = SUM ? split_addr(p.out_sum, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo2) : ro;
+  // cell state: one record per (direction, 16-sequence group, slice) — independent of the launch geometry,
+  // so a streaming caller finds it again in the next call; idle tail waves get private dummy slots
   const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
-                              ((size_t)blockIdx.x * NW + w) * (NS * 1024));
+                              ((size_t)dir * (p.ntasks + 16) + (task < p.task1 ? task : p.ntasks + w)) * (NS * 1024));
+  const unsigned cy = (unsigned)p.carry;
   const bool tsave = SAVE && task < p.task1;
   const rsrc_t rres = SAVE ? make_rsrc(reinterpret_cast<const char*>(p.reserve) +
                                        ((size_t)dir * p.ntasks + (tsave ? task : 0)) * p.nsteps *
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   for (int step = 0; step < p.nsteps; ++step) {
     const unsigned tt = rev ? p.nsteps - 1 - step : step;
     const unsigned ttn = step + 1 < p.nsteps ? (rev ? tt - 1 : tt + 1) : tt;   // prefetch target
-    const unsigned o0 = tt * st0, o1 = tt * st1, o2 = tt * st2, oo = tt * sto, ok = tt * stk;
+    const unsigned o0 = tt * st0, o1 = tt * st1, o2 = tt * st2, oo = (tt + cy) * sto, ok = tt * stk;
 
     // the first 4-channel remainder block of each segment is the same for every
     // slice of the step: keep it in a register  (vo0 carries +4g floats: undo 3g)
@@ -386,16 +390,16 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       if (HAS1) xs0 += bld1(rx1, vo1 - 12 * g, o1 + 64 * nv0);
     }
     if (HAS2 && ns2 > 0) xs2 = bld1(rx2, vo2 + 4 * g, o2 + 64 * nv2);
-    if (step > 0 && !(abl & 32)) {
-      // h_{t-1}: each lane re-reads exactly the float4s it stored one step ago
-      const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
+    if ((step > 0 || cy) && !(abl & 32)) {
+      // h_{t-1}: each lane re-reads exactly the float4s it stored one step ago (streaming: one call ago)
+      const unsigned op = (rev ? tt + 1 : tt - 1 + cy) * sto;
 #pragma unroll
       for (int s = 0; s < NS; ++s) hold[s] = bld4(ro, voo, op + 64 * s);
     }
 
     for (int s = 0; s < NS; ++s) {
       v4f cprev = zero4, skipv = zero4;
-      if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
+      if ((step > 0 || cy) && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
       if (SUM) skipv = bld4(rsk, vok, ok + 64 * s);
       v4f xc0 = HAS1 ? add_rn4(pa0, pb0) : pa0;   // blocks 0, 1: issued during the previous slice
       v4f xc1 = HAS1 ? add_rn4(pa1, pb1) : pa1;

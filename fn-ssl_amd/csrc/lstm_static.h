@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
   const rsrc_t ro2 = SUM ? split_addr(p.out_sum, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo2) : ro;
   const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
-                              ((size_t)blockIdx.x * NW + w) * (NS * 1024));
+                              ((size_t)dir * (p.ntasks + 16) + (task < p.task1 ? task : p.ntasks + w)) * (NS * 1024));
+  const unsigned cy = (unsigned)p.carry;   // streaming (see lstm_rec_kernel)
   const rsrc_t rw = make_rsrc(p.wpack[dir]);
   const unsigned st0 = (unsigned)(p.src0.st * 4), st2 = HAS2 ? (unsigned)(p.src2.st * 4) : 0u;
   const unsigned sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
@@ -192,14 +193,14 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   for (int step = 0; step < p.nsteps; ++step) {
     const unsigned tt = rev ? p.nsteps - 1 - step : step;
     const unsigned ttn = step + 1 < p.nsteps ? (rev ? tt - 1 : tt + 1) : tt;
-    const unsigned o0 = tt * st0, o2 = tt * st2, oo = tt * sto, ok = tt * stk;
+    const unsigned o0 = tt * st0, o2 = tt * st2, oo = (tt + cy) * sto, ok = tt * stk;
     float xs0[NS0 > 0 ? NS0 : 1], xs2[NS2 > 0 ? NS2 : 1];   // 4-channel remainder blocks: lane (n, g) holds channel 4u + g
     static_for<NS0>([&](auto u) { xs0[u.value] = bld1(rx0, vo0, o0 + 64 * NV0 + 16 * u.value); });
     static_for<NS2>([&](auto u) { xs2[u.value] = bld1(rx2, vo2, o2 + 64 * NV2 + 16 * u.value); });
     v4f xv2[NV2 > 0 ? NV2 : 1];   // the concatenated input is the same for every slice: held for the whole step
     static_for<NV2>([&](auto v) { xv2[v.value] = bld4(rx2, vo2v, o2 + 64 * v.value); });
-    if (step > 0 && !(abl & 32)) {
-      const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
+    if ((step > 0 || cy) && !(abl & 32)) {
+      const unsigned op = (rev ? tt + 1 : tt - 1 + cy) * sto;
 #pragma unroll
       for (int s = 0; s < NS; ++s) hold[s] = bld4(ro, voo, op + 64 * s);
     }
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       });
       // cell state and residual operand of this slice: requested after the x part (whose ring
       // registers they reuse), still a whole recurrent part ahead of their use
-      if (step > 0 && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
+      if ((step > 0 || cy) && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
       if (SUM && !(abl & 16)) skipv = bld4(rsk, vok, ok + 64 * s);
       static_for<NS0>([&](auto u) { SQUAD1(1 + NV0 + decltype(u)::value, xs0[decltype(u)::value]); });
       static_for<NV2>([&](auto v) {

@@ -52,6 +52,7 @@ class LstmDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("variant", C.c_int),
         ("reserve", C.c_void_p), ("reserve_bytes", C.c_size_t),
+        ("carry_state", C.c_int),
     ]
 
 

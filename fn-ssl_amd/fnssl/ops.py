@@ -199,7 +199,7 @@ def release_workspaces():
 
 
 def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
-               reserve=None):
+               reserve=None, carry_workspace=None, carry=False):
     """One (bi)LSTM layer over strided views.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
@@ -210,6 +210,9 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     kernel also stores out_sum = h + skip, i.e. the next layer's residual input.
     ``reserve`` (a float32 device buffer of ``lstm_reserve_floats`` elements) switches to the training
     forward, which also saves the gate activations and cell states for ``lstm_backward``.
+    Streaming (uni-directional layers): pass a persistent ``carry_workspace`` (``lstm_state_workspace``); with
+    ``carry=True`` the recurrence continues from the cell state in it and from the h row one step before
+    ``out`` in memory (the caller's buffer holds the previous call's last h there).
     """
     _need_dev(x0, x1, x2, out, skip, out_sum, *packed)
     if mode not in ("full", "narrow"):
@@ -251,14 +254,29 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     d.wpack[1] = packed[1].data_ptr() if ndir == 2 else 0
     lib = _lib.load()
     wsb = lib.fnssl_lstm_workspace_bytes(d.nseq, hidden, ndir)
-    ws = _workspace(wsb, out.device, "lstm")
-    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if carry_workspace is not None:
+        _need_dev(carry_workspace)
+        if carry_workspace.numel() * 4 < wsb:
+            raise RuntimeError("fnssl.lstm_layer: carry workspace too small")
+        d.workspace, d.workspace_bytes = carry_workspace.data_ptr(), carry_workspace.numel() * 4
+        d.carry_state = 1 if carry else 0
+    else:
+        if carry:
+            raise RuntimeError("fnssl.lstm_layer: carry=True needs the persistent carry_workspace")
+        ws = _workspace(wsb, out.device, "lstm")
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.variant = variant
     if reserve is not None:
         _need_dev(reserve)
         d.reserve, d.reserve_bytes = reserve.data_ptr(), reserve.numel() * 4
     check(lib.fnssl_lstm_forward(C.byref(d), _stream()), "lstm_forward")
     return out
+
+
+def lstm_state_workspace(nseq: int, hidden: int, device):
+    """Persistent per-layer cell-state buffer for streaming (uni-directional) LSTM calls."""
+    n = _lib.load().fnssl_lstm_workspace_bytes(nseq, hidden, 1)
+    return torch.zeros((n + 3) // 4, dtype=torch.float32, device=device)
 
 
 def lstm_reserve_floats(nseq: int, hidden: int, ndir: int, nsteps: int) -> int:

@@ -136,6 +136,11 @@ typedef struct {
    * activations and cell state, >= fnssl_lstm_reserve_bytes(); hidden 128/256, no src1 / out_sum.  */
   float* reserve;
   size_t reserve_bytes;
+  /* streaming (uni-directional layers only): 1 = continue a sequence.  h_{-1} is read from the row
+   * one step BEFORE `out` (out - out_st: the caller's buffer must hold the last h of the previous call
+   * there) and c_{-1} from `workspace`, where every call leaves its final cell state (the layout only
+   * depends on nseq / hidden, so keep one workspace per layer between calls).                      */
+  int carry_state;
 } fnssl_lstm_desc;
 
 /* Floats in one direction's packed weight stream for (input_size = c0 + c2, hidden). */

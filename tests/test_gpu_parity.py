@@ -647,3 +647,49 @@ def test_ipdnet_waveform_to_ipd(dev):
     want = O.ipdnet_forward(sd, O.array_preprocess(sig), True)
     assert got.shape == want.shape == (1, 2, 512, 7, 2)
     assert_close(got.cpu().numpy(), want, RTOL, ATOL, "waveform -> IPD")
+
+
+# --------------------------------------------------------------------------- streaming
+def test_lstm_carry_state_continues_a_sequence(dev):
+    """Two calls with carry == one call over the concatenated steps, bit for bit (generic and static kernels)."""
+    from fnssl import ops
+    for c0, c2 in ((256, 0), (256, 4)):
+        H, nb, nf, T1, T2 = 256, 1, 40, 5, 7
+        sd = lstm_state(c0 + c2, H, False, 3100 + c2)
+        w = packed_dirs(sd, c0, c2, False, dev)
+        x0 = to_dev(rs_randn(3101, (nb, T1 + T2, nf, c0)), dev)
+        x2 = to_dev(rs_randn(3102, (nb, T1 + T2, nf, c2)), dev) if c2 else None
+        whole = torch.empty((nb, nf, T1 + T2, H), device=dev).permute(0, 2, 1, 3)
+        ops.lstm_layer("narrow", x0, None, x2, w, H, whole)
+        buf = torch.full((nb, nf, T1 + T2 + 1, H), float("nan"), device=dev)
+        ws = ops.lstm_state_workspace(nb * nf, H, dev)
+        a = buf[:, :, 1:T1 + 1].permute(0, 2, 1, 3)
+        ops.lstm_layer("narrow", x0[:, :T1], None, x2[:, :T1] if c2 else None, w, H, a, carry_workspace=ws)
+        b = buf[:, :, T1 + 1:].permute(0, 2, 1, 3)                  # the row before it is chunk 1's last h
+        ops.lstm_layer("narrow", x0[:, T1:], None, x2[:, T1:] if c2 else None, w, H, b, carry_workspace=ws, carry=True)
+        assert torch.equal(buf[:, :, 1:].permute(0, 2, 1, 3), whole), (c0, c2)
+    with pytest.raises(RuntimeError, match="carry"):
+        ops.lstm_layer("narrow", x0, None, x2, w, H, whole, carry=True)
+
+
+@pytest.mark.parametrize("doa", [False, True])
+def test_fnssl_forward_stream_equals_whole_signal(dev, doa):
+    import Model
+    from fnssl import weights as W
+    nf = 256 if doa else 24
+    net = Model.FN_SSL(is_doa=doa).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_fnssl_state(3200, is_doa=doa).items()})
+    net.to(dev)
+    x = to_dev(rs_randn(3201, (2, 4, nf, 48)), dev)
+    whole = net(x)
+    outs, state = [], None
+    for lo, hi in ((0, 12), (12, 36), (36, 48)):
+        y, state = net.forward_stream(x[..., lo:hi].contiguous(), state)
+        outs.append(y)
+    assert state["frames"] == 48
+    assert torch.equal(torch.cat(outs, dim=1), whole)
+    with pytest.raises(RuntimeError, match="multiple of 12"):
+        net.forward_stream(x[..., :13].contiguous())
+    off = Model.FN_SSL(is_online=False).eval().to(dev)
+    with pytest.raises(RuntimeError, match="online"):
+        off.forward_stream(x)

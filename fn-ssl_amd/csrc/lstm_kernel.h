@@ -154,7 +154,7 @@ struct WStream<NW, M, 0> {
   unsigned bytes_per_step;
   bool nobar;
   __device__ __forceinline__ void init(const float* wp, int lane, int /*w*/, int qps, int nslices, int /*chq*/,
-                                       int /*pad*/, char* /*smem*/) {
+                                       int /*pad*/, char* /*smem*/, int /*split*/ = 1, int /*part*/ = 0) {
     rw = make_rsrc(wp);
     vlane = lane * 16;
     cur = 0;
@@ -181,34 +181,42 @@ template <int NW, int M>
 struct WStream<NW, M, 1> {
   rsrc_t rw;
   unsigned vlane;
-  char* lds_rd;         // smem + lane*16
+  char* lds_rd;         // smem + lane*16 (+ part*4096 in split mode)
   char* lds_wr;         // smem + w*1024 + lane*16
   int w;
-  int chq;              // quads per chunk
+  int chq;              // (super-)quads per chunk
   int ch;               // records per chunk
-  int qps4;             // real records per slice
-  int vslice4;          // virtual records per slice (incl. padding)
-  int recs_per_step;    // real records per step
-  int src_slice_base;   // real record index of the slice the next staged chunk belongs to
-  int src_off;          // virtual record offset of that chunk inside its slice
-  int rq;               // quad index inside the ring, 0 .. 2*chq-1
-  int left;             // quads left in the current chunk
+  int qps;              // real quads per slice
+  int vq;               // virtual quads per slice (incl. padding)
+  int nsl;              // slices per step consumed by ONE wave (H/16, or H/16/split)
+  int split;            // waves sharing one 16-sequence group (1, 2, 4): the ring then carries "super-quads"
+  int sqb;              // bytes per (super-)quad in the ring = split * 4096
+  int src_slice;        // local slice the next staged chunk belongs to
+  int src_q;            // its first virtual (super-)quad inside the slice
+  int rq;               // (super-)quad index inside the ring, 0 .. 2*chq-1
+  int left;             // (super-)quads left in the current chunk
   int wslot;
   bool nobar;
   v4f stg[M];
 
+  // Split mode: wave part p of a group works on hidden slices [p*nsl, (p+1)*nsl); a super-quad holds the
+  // same quad position of the `split` slices that are in flight together, so all waves of the workgroup
+  // still advance through ONE stream in lockstep.  The stream in memory stays in the standard
+  // [slice][quad][record] order; only the staging loads compute their source address differently.
   __device__ __forceinline__ void issue_loads() {
+    const int per = 4 * split;               // records per super-quad
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int r = w + m * NW;              // record inside the chunk
-      const int vo = src_off + r;            // virtual offset inside the slice
-      if (r < ch && vo < qps4) stg[m] = bld4(rw, vlane, (unsigned)(src_slice_base + vo) * 1024u);
+      const int sq = src_q + r / per;        // virtual quad position inside the slice
+      const int pr = (r / 4) % split;        // which part's quad
+      if (r < ch && sq < qps)
+        stg[m] = bld4(rw, vlane, (unsigned)(((pr * nsl + src_slice) * qps + sq) * 4 + (r & 3)) * 1024u);
     }
-    src_off += ch;
-    if (src_off == vslice4) {
-      src_off = 0;
-      src_slice_base += qps4;
-      if (src_slice_base == recs_per_step) src_slice_base = 0;
+    src_q += chq;
+    if (src_q == vq) {
+      src_q = 0;
+      src_slice = src_slice + 1 == nsl ? 0 : src_slice + 1;
     }
   }
   __device__ __forceinline__ void commit_and_barrier() {
@@ -222,20 +230,22 @@ struct WStream<NW, M, 1> {
     else
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  __device__ __forceinline__ void init(const float* wp, int lane, int w_, int qps, int nslices, int chq_, int pad,
-                                       char* smem) {
+  __device__ __forceinline__ void init(const float* wp, int lane, int w_, int qps_, int nslices, int chq_, int pad,
+                                       char* smem, int split_ = 1, int part = 0) {
     rw = make_rsrc(wp);
     vlane = lane * 16;
     w = w_;
-    lds_rd = smem + lane * 16;
+    split = split_;
+    sqb = split_ * 4096;
+    lds_rd = smem + lane * 16 + part * 4096;
     lds_wr = smem + w_ * 1024 + lane * 16;
     chq = chq_;
-    ch = chq_ * 4;
-    qps4 = qps * 4;
-    vslice4 = (qps + pad) * 4;
-    recs_per_step = nslices * qps * 4;
-    src_slice_base = 0;
-    src_off = 0;
+    ch = chq_ * 4 * split_;
+    qps = qps_;
+    vq = qps_ + pad;
+    nsl = nslices;
+    src_slice = 0;
+    src_q = 0;
     rq = 0;
     left = chq_;
     wslot = 0;
@@ -244,13 +254,13 @@ struct WStream<NW, M, 1> {
     issue_loads();          // chunk 1 in flight
   }
   __device__ __forceinline__ v4f record(int j) const {
-    return *reinterpret_cast<const v4f*>(lds_rd + rq * 4096 + j * 1024);
+    return *reinterpret_cast<const v4f*>(lds_rd + rq * sqb + j * 1024);
   }
   __device__ __forceinline__ void peek_next(v4f& n0, v4f& n1) const {
     // may run ahead of the publishing barrier at a chunk end: the caller re-reads then
     const int nq = (rq + 1 == 2 * chq) ? 0 : rq + 1;
-    n0 = *reinterpret_cast<const v4f*>(lds_rd + nq * 4096);
-    n1 = *reinterpret_cast<const v4f*>(lds_rd + nq * 4096 + 1024);
+    n0 = *reinterpret_cast<const v4f*>(lds_rd + nq * sqb);
+    n1 = *reinterpret_cast<const v4f*>(lds_rd + nq * sqb + 1024);
   }
   __device__ __forceinline__ bool advance() {
     rq = (rq + 1 == 2 * chq) ? 0 : rq + 1;
@@ -267,9 +277,15 @@ struct WStream<NW, M, 1> {
 // ABL = true builds the timing-ablation twin (FNSSL_ABLATE bits: 1 no x loads, 2 no gate
 // transcendentals, 4 no c/h stores, 8 no ring barrier, 16 no c load, 32 no h reload); its
 // results are wrong by construction and it is never used unless the env var is set.
-template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false>
-__global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
+// SPLIT > 1 (few sequences): SPLIT waves of the workgroup share one 16-sequence group and divide its hidden
+// slices among themselves — wave part p computes slices [p*NS/SPLIT, (p+1)*NS/SPLIT) of every step, all of
+// them re-read the complete h_{t-1} from the output tensor after a workgroup barrier at the step end.
+template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false, int SPLIT = 1>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_rec_kernel(const LstmParams p) {
+  // (4-wave workgroups are what small launches use, several per CU: keep them at >= 3 waves per SIMD)
   constexpr int NS = H / 16;
+  constexpr int NSL = NS / SPLIT;   // slices per wave
+  static_assert(NS % SPLIT == 0 && NW % SPLIT == 0 && (SPLIT == 1 || WMODE == 1), "split geometry");
   constexpr bool HAS1 = (MODE & kHas1) != 0, HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
   constexpr bool SAVE = (MODE & kSave) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,7 +295,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int dir = blockIdx.x / p.wgs_per_dir;
   const int wg = blockIdx.x - dir * p.wgs_per_dir;
-  const int task = p.task0 + wg * NW + w;
+  const int part = SPLIT > 1 ? w % SPLIT : 0;
+  const int task = p.task0 + wg * (NW / SPLIT) + w / SPLIT;
   int q = task * 16 + n;
   const bool valid = q < p.nseq && task < p.task1;
   if (q >= p.nseq) q = p.nseq - 1;
@@ -315,7 +332,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
   const int abl = ABL ? p.ablate : 0;
   WStream<NW, M, WMODE> ws;
   ws.nobar = ABL && (abl & 8);
-  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, NS, p.chq, p.pad, smem);
+  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, NSL, p.chq, p.pad, smem, SPLIT, part);
   v4f a0 = ws.record(0), a1 = ws.record(1);   // A operands of the current quad's first half
 
   v4f hold[NS];
@@ -397,7 +414,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
       for (int s = 0; s < NS; ++s) hold[s] = bld4(ro, voo, op + 64 * s);
     }
 
-    for (int s = 0; s < NS; ++s) {
+    for (int sl = 0; sl < NSL; ++sl) {
+      const int s = SPLIT > 1 ? part * NSL + sl : sl;   // hidden slice this wave computes now
       v4f cprev = zero4, skipv = zero4;
       if ((step > 0 || cy) && !(abl & 16)) cprev = bld4(rc, vlane, s * 1024);
       if (SUM) skipv = bld4(rsk, vok, ok + 64 * s);
@@ -438,8 +456,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
           }
         }
       }
-      const unsigned n0 = (s + 1 < NS ? tt : ttn) * st0;
-      const unsigned n1 = (s + 1 < NS ? tt : ttn) * st1;
+      const unsigned n0 = (sl + 1 < NSL ? tt : ttn) * st0;
+      const unsigned n1 = (sl + 1 < NSL ? tt : ttn) * st1;
       {
         // blocks 0, 1 of the next slice (same x_t) or of the next step
         if (nv0 > 0 && !(abl & 1)) {
@@ -522,16 +540,20 @@ __global__ void __launch_bounds__(NW * 64) lstm_rec_kernel(const LstmParams p) {
         asm volatile("" ::"v"(cn), "v"(hn));
       }
     }
+    if (SPLIT > 1) {
+      // the partner waves read my h slices at the start of the next step: stores performed, then meet
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
   }
 #undef QUAD
 #undef QUAD1
 }
 
 // ---- launcher ----------------------------------------------------------------
-template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false>
+template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false, int SPLIT = 1>
 int launch_k(const LstmParams& p, int nwg, hipStream_t st) {
-  const size_t lds = WMODE ? (size_t)2 * p.chq * 4096 : 0;
-  auto k = lstm_rec_kernel<H, NW, M, WMODE, MODE, ABL>;
+  const size_t lds = WMODE ? (size_t)2 * p.chq * SPLIT * 4096 : 0;
+  auto k = lstm_rec_kernel<H, NW, M, WMODE, MODE, ABL, SPLIT>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -604,8 +626,9 @@ inline int default_variant(int H) {
 
 // Ring chunk: the largest chq <= NW*M/4 with (qps + pad) % chq == 0 for a padding
 // pad <= 3 quads (chunk boundaries then coincide with slice ends).
-inline void choose_chunk(int qps, const Variant& v, int& chq, int& pad) {
-  const int cap = v.NW * v.M / 4;
+inline void choose_chunk(int qps, const Variant& v, int& chq, int& pad, int split = 1, int max_chq = 0) {
+  int cap = v.NW * v.M / (4 * split);   // split mode: the ring carries super-quads of `split` quads
+  if (max_chq > 0 && cap > max_chq) cap = max_chq;   // LDS budget of the launch (several workgroups per CU)
   int best_c = 1, best_p = 0;
   for (int p = 0; p <= 3; ++p)
     for (int c = cap; c >= 1; --c)

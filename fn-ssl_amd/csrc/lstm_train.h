@@ -40,17 +40,23 @@ struct BwdParams {
 inline int bwd_co_pad(int c0g, int H) { return (c0g + H + 63) / 64 * 64; }
 inline int bwd_quads_per_slice(int H) { return 1 + (4 * H) / 16; }
 
-template <int H, int NW, int M>
+// SPLIT > 1: SPLIT waves share one 16-sequence group (see lstm_rec_kernel): each does its share of the hidden
+// slices in phase A and of the output slices in phase B; dA rows and the carried dh are exchanged through
+// memory with a workgroup barrier after each phase.
+template <int H, int NW, int M, int SPLIT = 1>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
   constexpr int NS = H / 16;
+  constexpr int NSL = NS / SPLIT;
   constexpr int NVB = 4 * H / 16;   // 16-channel blocks of one dA row
+  static_assert(NS % SPLIT == 0 && NW % SPLIT == 0, "split geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int dir = blockIdx.x / p.wgs_per_dir;
   const int wg = blockIdx.x - dir * p.wgs_per_dir;
-  const int task = p.task0 + wg * NW + w;
+  const int part = SPLIT > 1 ? w % SPLIT : 0;
+  const int task = p.task0 + wg * (NW / SPLIT) + w / SPLIT;
   const bool tvalid = task < p.task1;
   int q = task * 16 + n;
   const bool valid = q < p.nseq && tvalid;
@@ -64,17 +70,18 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
   const rsrc_t rres = make_rsrc(reinterpret_cast<const char*>(p.reserve) +
                                 ((size_t)dir * p.ntasks + (tvalid ? task : 0)) * p.nsteps *
                                     (size_t)(NS * kReserveRecs * 1024));
+  // carried dh / dc: one region per (direction, group), shared by the waves of a split group
   const rsrc_t rsc = make_rsrc(reinterpret_cast<const char*>(p.scratch) +
-                               ((size_t)blockIdx.x * NW + w) * (2 * NS * 1024));
+                               ((size_t)dir * (p.ntasks + 16) + (tvalid ? task : p.ntasks + w)) * (2 * NS * 1024));
   const unsigned sdh = (unsigned)(p.dh.st * 4), sda = (unsigned)(p.da_st * 4), sdx = (unsigned)(p.dx_st * 4);
   const unsigned vlane = lane * 16;
   const bool rev = dir == 1;
-  const int nso = p.co_pad >> 6;      // output slices (4 x 16 channels each)
-  const int hq = p.co_pad >> 2;       // channels per output quarter
+  const int nsol = (p.co_pad >> 6) / SPLIT;   // output slices (4 x 16 channels each) of this wave
+  const int hq = p.co_pad >> 2;               // channels per output quarter
 
   WStream<NW, M, 1> ws;
   ws.nobar = false;
-  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, nso, p.chq, p.pad, smem);
+  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, nsol, p.chq, p.pad, smem, SPLIT, part);
   v4f a0 = ws.record(0), a1 = ws.record(1);
   const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
   v4f acc[4];
@@ -103,7 +110,8 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
     const unsigned oa = tt * sda;
 
     // ---- phase A: gate gradients of every hidden slice ---------------------------------------
-    for (int s = 0; s < NS; ++s) {
+    for (int sl = 0; sl < NSL; ++sl) {
+      const int s = SPLIT > 1 ? part * NSL + sl : sl;
       const unsigned rb = (tt * NS + s) * (kReserveRecs * 1024);
       const v4f ig = bld4(rres, vlane, rb), fg = bld4(rres, vlane, rb + 1024);
       const v4f gg = bld4(rres, vlane, rb + 2048), og = bld4(rres, vlane, rb + 3072);
@@ -129,13 +137,18 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
         bst4(dao, rda, vda, oa + 12 * H + 64 * s);
       }
     }
-    // the B operands below are this wave's own dA rows: wait until the stores have been performed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the B operands below are the dA rows just written (by this wave, or by all waves of a split group):
+    // wait until the stores have been performed
+    if (SPLIT > 1)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- phase B: [dx | dh_prev]^T = [W_ih | W_hh]^T da^T -------------------------------------
     v4f x0 = bld4(rda, vda, oa), x1 = bld4(rda, vda, oa + 64), x2 = bld4(rda, vda, oa + 128),
         x3 = bld4(rda, vda, oa + 192);
-    for (int so = 0; so < nso; ++so) {
+    for (int sol = 0; sol < nsol; ++sol) {
+      const int so = SPLIT > 1 ? part * nsol + sol : sol;
       acc[0] = a0;   // "bias" quad of the stream: zeros
       acc[1] = a1;
       acc[2] = ws.record(2);
@@ -175,14 +188,15 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
         }
       }
     }
+    if (SPLIT > 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // carried dh visible to the group
   }
 #undef QUAD
 }
 
-template <int H, int NW, int M>
+template <int H, int NW, int M, int SPLIT = 1>
 int launch_bwd_k(const BwdParams& p, int nwg, hipStream_t st) {
-  const size_t lds = (size_t)2 * p.chq * 4096;
-  auto k = lstm_bwd_kernel<H, NW, M>;
+  const size_t lds = (size_t)2 * p.chq * SPLIT * 4096;
+  auto k = lstm_bwd_kernel<H, NW, M, SPLIT>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -191,34 +205,55 @@ int launch_bwd_k(const BwdParams& p, int nwg, hipStream_t st) {
   return FNSSL_OK;
 }
 
-// training launch geometries: NW waves per workgroup, 4 ring records staged per wave
 template <int H>
-int launch_bwd(int nw, const BwdParams& p, int nwg, hipStream_t st) {
-  switch (nw) {
-    case 4: return launch_bwd_k<H, 4, 4>(p, nwg, st);
-    case 8: return launch_bwd_k<H, 8, 4>(p, nwg, st);
-    case 12: return launch_bwd_k<H, 12, 4>(p, nwg, st);
+int launch_bwd(int nw, int split, const BwdParams& p, int nwg, hipStream_t st) {
+  if (split == 1) {
+    switch (nw) {
+      case 4: return launch_bwd_k<H, 4, 4>(p, nwg, st);
+      case 8: return launch_bwd_k<H, 8, 4>(p, nwg, st);
+      case 12: return launch_bwd_k<H, 12, 4>(p, nwg, st);
+    }
+  } else if (split == 2 && nw == 4) {
+    return launch_bwd_k<H, 4, 8, 2>(p, nwg, st);
+  } else if (split == 4 && nw == 4) {
+    return launch_bwd_k<H, 4, 8, 4>(p, nwg, st);
+  } else if (split == 4 && nw == 8) {
+    return launch_bwd_k<H, 8, 8, 4>(p, nwg, st);
   }
-  fnssl::set_error("lstm_backward: unsupported workgroup size %d", nw);
+  fnssl::set_error("lstm_backward: unsupported geometry (%d waves, split %d)", nw, split);
+  return FNSSL_E_INVALID;
+}
+
+// (nw, split): 4 / 8 / 12 waves per workgroup with one group per wave, or the split geometries for launches
+// with fewer wave tasks than SIMDs: 2 or 4 waves per 16-sequence group (8 ring records staged per wave)
+template <int H, int MODE>
+int launch_save_m(int nw, int split, const LstmParams& p, int nwg, hipStream_t st) {
+  if (split == 1) {
+    switch (nw) {
+      case 4: return launch_k<H, 4, 4, 1, MODE>(p, nwg, st);
+      case 8: return launch_k<H, 8, 4, 1, MODE>(p, nwg, st);
+      case 12: return launch_k<H, 12, 4, 1, MODE>(p, nwg, st);
+    }
+  } else if (split == 2 && nw == 4) {
+    return launch_k<H, 4, 4, 1, MODE, false, 2>(p, nwg, st);
+  } else if (split == 4 && nw == 4) {
+    return launch_k<H, 4, 4, 1, MODE, false, 4>(p, nwg, st);
+  } else if (split == 4 && nw == 8) {
+    return launch_k<H, 8, 8, 1, MODE, false, 4>(p, nwg, st);
+  }
+  fnssl::set_error("lstm_forward (training): unsupported geometry (%d waves, split %d)", nw, split);
   return FNSSL_E_INVALID;
 }
 
 template <int H>
-int launch_save(int nw, const LstmParams& p, int mode, int nwg, hipStream_t st) {
-  const bool has2 = (mode & kHas2) != 0;
-  switch (nw) {
-    case 4: return has2 ? launch_k<H, 4, 4, 1, kSave | kHas2>(p, nwg, st) : launch_k<H, 4, 4, 1, kSave>(p, nwg, st);
-    case 8: return has2 ? launch_k<H, 8, 4, 1, kSave | kHas2>(p, nwg, st) : launch_k<H, 8, 4, 1, kSave>(p, nwg, st);
-    case 12:
-      return has2 ? launch_k<H, 12, 4, 1, kSave | kHas2>(p, nwg, st) : launch_k<H, 12, 4, 1, kSave>(p, nwg, st);
-  }
-  fnssl::set_error("lstm_forward (training): unsupported workgroup size %d", nw);
-  return FNSSL_E_INVALID;
+int launch_save(int nw, int split, const LstmParams& p, int mode, int nwg, hipStream_t st) {
+  return (mode & kHas2) ? launch_save_m<H, kSave | kHas2>(nw, split, p, nwg, st)
+                        : launch_save_m<H, kSave>(nw, split, p, nwg, st);
 }
 
-extern template int launch_bwd<128>(int, const BwdParams&, int, hipStream_t);
-extern template int launch_bwd<256>(int, const BwdParams&, int, hipStream_t);
-extern template int launch_save<128>(int, const LstmParams&, int, int, hipStream_t);
-extern template int launch_save<256>(int, const LstmParams&, int, int, hipStream_t);
+extern template int launch_bwd<128>(int, int, const BwdParams&, int, hipStream_t);
+extern template int launch_bwd<256>(int, int, const BwdParams&, int, hipStream_t);
+extern template int launch_save<128>(int, int, const LstmParams&, int, int, hipStream_t);
+extern template int launch_save<256>(int, int, const LstmParams&, int, int, hipStream_t);
 
 }  // namespace fnssl_lstm

@@ -19,11 +19,38 @@ static int device_cus() {
   return ncu;
 }
 
-// Rounds of <= 12 waves per CU, as even as possible; calls fn(nw, t0, t1) per round.
+struct Geometry {
+  int nw, split, t0, t1;
+};
+
+// Largest ring chunk (in super-quads) that lets every workgroup of a single-launch split geometry be
+// resident at once: ceil(nwg / CUs) workgroups share a CU's 160 KB of LDS (2 ring slots each).
+static int lds_chunk_cap(int nwg, int split) {
+  const int ncu = device_cus();
+  const int per_cu = (nwg + ncu - 1) / ncu;
+  const int budget = (per_cu <= 1 ? 128 : per_cu >= 5 ? 32 : 160 / per_cu) * 1024;
+  const int cap = budget / (2 * split * 4096);
+  return cap > 0 ? cap : 1;
+}
+
+// Launch plan.  Plenty of 16-sequence groups: rounds of <= 12 waves per CU, as even as possible.  Fewer
+// groups than would give every SIMD two waves: ONE launch in which 2 or 4 waves share a group (split), so
+// the chip fills up with waves that each do a fraction of the per-step work.  FNSSL_TRAIN_SPLIT=1|2|4 forces.
 template <class F>
-static int plan_rounds(int tasks, int ndir, F&& fn) {
+static int plan_rounds(int tasks, int ndir, int max_split, F&& fn) {
   const int ncu = device_cus();
   const long long total = (long long)tasks * ndir;
+  int split = 1;
+  if (total * 4 <= 8LL * ncu)
+    split = 4;
+  else if (total * 2 <= 12LL * ncu)
+    split = 2;
+  if (const int f = env_int("FNSSL_TRAIN_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
+  if (split > max_split) split = max_split;
+  if (split > 1) {
+    const int nw = (split == 4 && total >= 2LL * ncu) ? 8 : 4;
+    return fn(Geometry{nw, split, 0, tasks});
+  }
   const int W = (int)((total + ncu - 1) / ncu);
   const int rounds = (W + 11) / 12;
   const int wgs_per_dir_round = ncu / ndir > 0 ? ncu / ndir : 1;
@@ -34,7 +61,7 @@ static int plan_rounds(int tasks, int ndir, F&& fn) {
     const int nw = want <= 4 ? 4 : want <= 8 ? 8 : 12;
     int t1 = r + 1 == rounds ? tasks : t0 + wgs_per_dir_round * nw;
     if (t1 > tasks) t1 = tasks;
-    const int rc = fn(nw, t0, t1);
+    const int rc = fn(Geometry{nw, 1, t0, t1});
     if (rc != FNSSL_OK) return rc;
     t0 = t1;
   }
@@ -43,15 +70,16 @@ static int plan_rounds(int tasks, int ndir, F&& fn) {
 
 // Training forward: called by fnssl_lstm_forward when the descriptor carries a reserve buffer.
 int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
-  const int tasks = p.ntasks;
-  return plan_rounds(tasks, p.ndir, [&](int nw, int t0, int t1) {
-    p.task0 = t0;
-    p.task1 = t1;
-    p.wgs_per_dir = (t1 - t0 + nw - 1) / nw;
-    const Variant vr{nw, 4, 1};
-    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
+  return plan_rounds(p.ntasks, p.ndir, 4, [&](const Geometry& gm) {
+    p.task0 = gm.t0;
+    p.task1 = gm.t1;
+    const int groups_per_wg = gm.nw / gm.split;
+    p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
+    const Variant vr{gm.nw, (gm.split > 1 && gm.nw == 8) ? 8 : 4, 1};   // staging registers as in launch_save_m
     const int nwg = p.wgs_per_dir * p.ndir;
-    return H == 128 ? launch_save<128>(nw, p, mode | kSave, nwg, st) : launch_save<256>(nw, p, mode | kSave, nwg, st);
+    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, gm.split, gm.split > 1 ? lds_chunk_cap(nwg, gm.split) : 0);
+    return H == 128 ? launch_save<128>(gm.nw, gm.split, p, mode | kSave, nwg, st)
+                    : launch_save<256>(gm.nw, gm.split, p, mode | kSave, nwg, st);
   });
 }
 
@@ -158,14 +186,17 @@ int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) {
   hipStream_t st = fnssl::as_stream(stream);
   const double flops = 2.0 * 4 * H * (double)(d->c0g + H) * d->nseq * (double)d->nsteps * d->ndir;
   fnssl::TimedLaunch tl(H == 128 ? "lstm_bwd_h128" : "lstm_bwd_h256", st, flops);
-  return plan_rounds(p.ntasks, p.ndir, [&](int nw, int t0, int t1) {
-    p.task0 = t0;
-    p.task1 = t1;
-    p.wgs_per_dir = (t1 - t0 + nw - 1) / nw;
-    const Variant vr{nw, 4, 1};
-    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
+  const int nso = p.co_pad / 64;
+  const int max_split = nso % 4 == 0 ? 4 : nso % 2 == 0 ? 2 : 1;   // output slices divide among the waves
+  return plan_rounds(p.ntasks, p.ndir, max_split, [&](const Geometry& gm) {
+    p.task0 = gm.t0;
+    p.task1 = gm.t1;
+    const int groups_per_wg = gm.nw / gm.split;
+    p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
+    const Variant vr{gm.nw, gm.split > 1 ? 8 : 4, 1};
     const int nwg = p.wgs_per_dir * p.ndir;
-    return H == 128 ? launch_bwd<128>(nw, p, nwg, st) : launch_bwd<256>(nw, p, nwg, st);
+    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, gm.split, gm.split > 1 ? lds_chunk_cap(nwg, gm.split) : 0);
+    return H == 128 ? launch_bwd<128>(gm.nw, gm.split, p, nwg, st) : launch_bwd<256>(gm.nw, gm.split, p, nwg, st);
   });
 }
 

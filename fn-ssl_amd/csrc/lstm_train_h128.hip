@@ -2,6 +2,6 @@
 #include "lstm_train.h"
 
 namespace fnssl_lstm {
-template int launch_bwd<128>(int, const BwdParams&, int, hipStream_t);
-template int launch_save<128>(int, const LstmParams&, int, int, hipStream_t);
+template int launch_bwd<128>(int, int, const BwdParams&, int, hipStream_t);
+template int launch_save<128>(int, int, const LstmParams&, int, int, hipStream_t);
 }  // namespace fnssl_lstm

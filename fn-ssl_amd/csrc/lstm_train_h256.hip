@@ -2,6 +2,6 @@
 #include "lstm_train.h"
 
 namespace fnssl_lstm {
-template int launch_bwd<256>(int, const BwdParams&, int, hipStream_t);
-template int launch_save<256>(int, const LstmParams&, int, int, hipStream_t);
+template int launch_bwd<256>(int, int, const BwdParams&, int, hipStream_t);
+template int launch_save<256>(int, int, const LstmParams&, int, int, hipStream_t);
 }  // namespace fnssl_lstm

@@ -32,6 +32,8 @@ extern template int launch_h<32>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_h<64>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_h<128>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_h<256>(int, const LstmParams&, int, int, hipStream_t);
+extern template int launch_split_h<128>(int, const LstmParams&, int, int, hipStream_t);
+extern template int launch_split_h<256>(int, const LstmParams&, int, int, hipStream_t);
 int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train.hip
 }  // namespace fnssl_lstm
 
@@ -226,16 +228,33 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   }
   if (const int forced = default_variant_override(H)) return launch_range(forced, 0, tasks);
 
-  // ---- launch planner ---------------------------------------------------------------
-  // Every wave does the same work, so a launch runs at the pace of its fullest CU.  Split the
-  // per-CU wave count W = ceil(total groups / CUs) into the fewest rounds of <= wmax waves and
-  // make the rounds as even as possible (config 2, full-band: 7200 groups -> 29 waves per CU ->
-  // rounds of 15 + 14 instead of 16 + 16).  Supported wave counts: the ring variants below.
   static const int ncu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
+  // ---- few sequences (a single utterance, a streaming chunk): several waves per 16-sequence group ------
+  {
+    const long long total = (long long)tasks * d->ndir;
+    int split = total * 4 <= 4LL * ncu ? 4 : total * 2 <= 4LL * ncu ? 2 : 1;   // fewer waves than SIMDs even after the split
+    if (const int f = env_int("FNSSL_LSTM_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
+    if (split > 1) {
+      const int nw = split == 4 ? 8 : 4, groups_per_wg = nw / split;
+      p.task0 = 0;
+      p.task1 = tasks;
+      p.wgs_per_dir = (tasks + groups_per_wg - 1) / groups_per_wg;
+      const Variant vr{nw, split == 4 ? 8 : 4, 1};
+      choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, split);
+      const int nwg = p.wgs_per_dir * d->ndir;
+      return H == 128 ? launch_split_h<128>(split, p, mode, nwg, st) : launch_split_h<256>(split, p, mode, nwg, st);
+    }
+  }
+
+  // ---- launch planner ---------------------------------------------------------------
+  // Every wave does the same work, so a launch runs at the pace of its fullest CU.  Split the
+  // per-CU wave count W = ceil(total groups / CUs) into the fewest rounds of <= wmax waves and
+  // make the rounds as even as possible (config 2, full-band: 7200 groups -> 29 waves per CU ->
+  // rounds of 15 + 14 instead of 16 + 16).  Supported wave counts: the ring variants below.
   struct Sup {
     int nw, variant;
   };

@@ -648,6 +648,30 @@ inline void choose_chunk(int qps, const Variant& v, int& chq, int& pad, int spli
   }
 }
 
+// Split geometries for launches with fewer 16-sequence groups than SIMDs (single utterances, streaming
+// chunks): 2 waves per group in 4-wave workgroups, or 4 waves per group in 8-wave workgroups.
+template <int H, int NW, int M, int SPLIT>
+int launch_split_t(const LstmParams& p, int mode, int nwg, hipStream_t st) {
+  switch (mode) {
+    case 0: return launch_k<H, NW, M, 1, 0, false, SPLIT>(p, nwg, st);
+    case kHas1: return launch_k<H, NW, M, 1, kHas1, false, SPLIT>(p, nwg, st);
+    case kHas2: return launch_k<H, NW, M, 1, kHas2, false, SPLIT>(p, nwg, st);
+    case kSum: return launch_k<H, NW, M, 1, kSum, false, SPLIT>(p, nwg, st);
+    case kHas2 | kSum: return launch_k<H, NW, M, 1, kHas2 | kSum, false, SPLIT>(p, nwg, st);
+    case kHas1 | kHas2: return launch_k<H, NW, M, 1, kHas1 | kHas2, false, SPLIT>(p, nwg, st);
+  }
+  fnssl::set_error("lstm: input combination %d not built (src1 together with out_sum)", mode);
+  return FNSSL_E_INVALID;
+}
+
+template <int H>
+int launch_split_h(int split, const LstmParams& p, int mode, int nwg, hipStream_t st) {
+  if (split == 2) return launch_split_t<H, 4, 4, 2>(p, mode, nwg, st);
+  if (split == 4) return launch_split_t<H, 8, 8, 4>(p, mode, nwg, st);
+  fnssl::set_error("lstm: unsupported split %d", split);
+  return FNSSL_E_INVALID;
+}
+
 template <int H>
 int launch_h(int variant, const LstmParams& p, int mode, int nwg, hipStream_t st) {
   switch (variant) {

@@ -13,7 +13,10 @@ constructor arguments, ``forward`` signatures, return shapes and ``state_dict`` 
 Against the reference's dataflow nothing is concatenated or permuted in memory: the concat skips
 (:34, :38) are a second operand segment of the consuming LSTM / conv kernel, the permutes are strides.
 ``nn.LSTM`` / ``nn.Conv2d`` sub-modules only hold parameters.  Forward-only (``eval()``), ROCm tensors
-only, fp32.
+only.  fp32 by default; after ``net.bfloat16()`` (BASELINE config 3: bf16 weights, fp32 accumulate) the LSTM
+layers run on bf16 MFMAs — weights and the [x | h] operands rounded to bf16, gates / cell state / every
+tensor in HBM fp32 — and the conv head uses the bf16-rounded weights; inputs of either dtype are accepted and
+the output comes back in the input's dtype.
 """
 import os
 import sys
@@ -32,6 +35,21 @@ from Model import _lstm_streams, _param_key, _require_eval          # noqa: E402
 def _split16(c):
     """Channels of a skip/input tensor as (vector channels, remainder channels) of the LSTM kernel."""
     return (c, 0) if c % 16 == 0 else (0, c)
+
+
+def _ceil16(c):
+    return (c + 15) // 16 * 16
+
+
+def _is_bf16(module):
+    return next(module.parameters()).dtype == torch.bfloat16
+
+
+def _pad_channels(t, c):
+    """Zero-pad the last dimension to c channels (bf16 path: whole 16-channel blocks)."""
+    if t.shape[-1] >= c:
+        return t
+    return torch.cat((t, t.new_zeros(tuple(t.shape[:-1]) + (c - t.shape[-1],))), dim=-1)
 
 
 class FNblock(nn.Module):
@@ -66,12 +84,22 @@ class FNblock(nn.Module):
     def _streams(self, device):
         key = (_param_key(self), str(device))
         if self._packed is None or self._packed_key != key:
-            if self.is_first:
-                c0, c2 = _split16(self.input_size)
+            fh2 = 2 * self.full_hidden_size
+            if _is_bf16(self):
+                # the skip / network-input segment is zero-padded to whole 16-channel blocks
+                cs = _ceil16(self.add_skip_dim)
+                if self.is_first:
+                    full = _lstm_streams(self.fullLstm, _ceil16(self.input_size), 0, device, True, _ceil16(self.input_size))
+                else:
+                    full = _lstm_streams(self.fullLstm, self.input_size, cs, device, True, self.input_size + cs)
+                narr = _lstm_streams(self.narrLstm, fh2, cs, device, True, fh2 + cs)
             else:
-                c0, c2 = self.input_size, self.add_skip_dim
-            full = _lstm_streams(self.fullLstm, c0, c2, device)
-            narr = _lstm_streams(self.narrLstm, 2 * self.full_hidden_size, self.add_skip_dim, device)
+                if self.is_first:
+                    c0, c2 = _split16(self.input_size)
+                else:
+                    c0, c2 = self.input_size, self.add_skip_dim
+                full = _lstm_streams(self.fullLstm, c0, c2, device)
+                narr = _lstm_streams(self.narrLstm, fh2, self.add_skip_dim, device)
             self._packed, self._packed_key = (full, narr), key
         return self._packed
 
@@ -83,24 +111,30 @@ class FNblock(nn.Module):
         _require_eval(self)
         if x_in is None:
             x_in = x_skip
+        bf = _is_bf16(self)
+        if bf:   # whole 16-channel blocks (no-ops when the caller already padded)
+            x_skip = _pad_channels(x_skip, _ceil16(self.add_skip_dim))
+            x_in = _pad_channels(x_in, _ceil16(x_in.shape[-1]))
         nb, nt, nf, _ = x_skip.shape
         full_w, narr_w = self._streams(x_skip.device)
         f = torch.empty((nb, nt, nf, 2 * self.full_hidden_size), dtype=torch.float32, device=x_skip.device)
         if self.is_first:
-            if _split16(self.input_size)[0]:
-                ops.lstm_layer("full", x_in, None, None, full_w, self.full_hidden_size, f)
+            if bf or _split16(self.input_size)[0]:
+                ops.lstm_layer("full", x_in, None, None, full_w, self.full_hidden_size, f, bf16=bf)
             else:
                 ops.lstm_layer("full", None, None, x_in, full_w, self.full_hidden_size, f)
         else:
-            ops.lstm_layer("full", x_main, None, x_in, full_w, self.full_hidden_size, f)      # cat :38 of the
-        nh = self.narr_hidden_size * (1 if self.is_online else 2)                              # block before
+            ops.lstm_layer("full", x_main, None, x_in, full_w, self.full_hidden_size, f, bf16=bf)   # cat :38 of the
+        nh = self.narr_hidden_size * (1 if self.is_online else 2)                                    # block before
         n = torch.empty((nb, nf, nt, nh), dtype=torch.float32, device=x_skip.device)
-        ops.lstm_layer("narrow", f, None, x_skip, narr_w, self.narr_hidden_size, n.permute(0, 2, 1, 3))   # cat :34
+        ops.lstm_layer("narrow", f, None, x_skip, narr_w, self.narr_hidden_size, n.permute(0, 2, 1, 3), bf16=bf)   # :34
         return n.permute(0, 2, 1, 3)
 
     def forward(self, x, fb_skip, nb_skip):
         """Reference signature: x [nb, nt, nf, C], fb_skip [nb*nt, nf, Cs], nb_skip [nb*nf, nt, Cs]
         -> [nb, nt, nf, Hn + Cs] (the concatenation is materialised only here, for API compatibility)."""
+        in_dtype = x.dtype
+        x, fb_skip, nb_skip = x.float(), fb_skip.float(), nb_skip.float()
         nb, nt, nf, nc = x.shape
         skip = fb_skip.reshape(nb, nt, nf, -1)
         if self.is_first:
@@ -110,7 +144,7 @@ class FNblock(nn.Module):
                 raise RuntimeError("FNblock: %d input channels, expected %d" % (nc, self.input_size + self.add_skip_dim))
             n = self.run(x[..., :self.input_size], skip, x[..., self.input_size:])
         nbs = nb_skip.reshape(nb, nf, nt, -1).permute(0, 2, 1, 3)
-        return torch.cat((n, nbs), dim=-1)
+        return torch.cat((n, nbs), dim=-1).to(in_dtype)
 
 
 class CausCnnBlock(nn.Module):
@@ -161,15 +195,16 @@ class CausCnnBlock(nn.Module):
 
     def forward(self, x):
         """Reference signature: x [nb, inp_dim, nf, nt] -> [nb, out_dim, nf, nt // 12]."""
+        in_dtype = x.dtype
         c = x.shape[1]
         ca = c - c % 16
-        xl = x.permute(0, 2, 3, 1).contiguous()                      # channels-last (plumbing)
+        xl = x.float().permute(0, 2, 3, 1).contiguous()              # channels-last (plumbing)
         if ca == 0:
             raise RuntimeError("CausCnnBlock: needs at least 16 input channels")
         xa = xl[..., :ca]
         xb = xl[..., ca:] if ca < c else None
         y = self.run(xa, xb)
-        return y[..., :self.out_dim].permute(0, 3, 1, 2)
+        return y[..., :self.out_dim].permute(0, 3, 1, 2).to(in_dtype)
 
 
 class IPDnet(nn.Module):
@@ -191,6 +226,8 @@ class IPDnet(nn.Module):
 
     def forward(self, x, offline_inference=False):
         _require_eval(self)
+        in_dtype = x.dtype
+        x = x.float()                                               # tensors in HBM are fp32 in both precisions
         nb, nc, nf, nt = x.shape
         if nc != self.input_size:
             raise RuntimeError("IPDnet: %d input channels, expected %d" % (nc, self.input_size))
@@ -206,13 +243,14 @@ class IPDnet(nn.Module):
             x = x.reshape(nb, nc, nf, nseg, self.n).permute(0, 3, 1, 2, 4).reshape(nb * nseg, nc, nf, self.n)
             nb, nt = nb * nseg, self.n
         xs = ops.nchw_to_seq(x)                                     # [nb, nt, nf, C]  (:93)
-        y = self.block_1.run(None, xs)
-        y = self.block_2.run(y, xs)                                 # logical [nb, nt, nf, Hn], stored [nb, nf, nt, Hn]
-        c = self.conv.run(y.permute(0, 2, 1, 3), xs.permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
+        xp = _pad_channels(xs, _ceil16(nc)) if _is_bf16(self) else xs   # bf16 kernels read whole 16-channel blocks
+        y = self.block_1.run(None, xp)
+        y = self.block_2.run(y, xp)                                 # logical [nb, nt, nf, Hn], stored [nb, nf, nt, Hn]
+        c = self.conv.run(y.permute(0, 2, 1, 3), xp[..., :nc].permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
         nt2 = nt // 12
         c = c[..., :self.cnn_out_dim].permute(0, 2, 1, 3)           # = conv(x).permute(0,3,2,1)  (:113)
         c = c.reshape(nb, nt2, nf, 2, -1).permute(0, 1, 3, 2, 4)
         if nseg > 1 or (not self.is_online and offline_inference):
             c = c.reshape(nb // nseg, nt2 * nseg, 2, nf * 2, -1).permute(0, 1, 3, 4, 2)
-            return c[:, :ou_frame, :, :, :]
-        return c.reshape(nb, nt2, 2, nf * 2, -1).permute(0, 1, 3, 4, 2)
+            return c[:, :ou_frame, :, :, :].to(in_dtype)
+        return c.reshape(nb, nt2, 2, nf * 2, -1).permute(0, 1, 3, 4, 2).to(in_dtype)

@@ -21,13 +21,18 @@ import torch.nn as nn
 from fnssl import ops
 
 
-def _lstm_streams(lstm: nn.LSTM, c0: int, c2: int, device):
-    """Pack an nn.LSTM's parameters into per-direction device weight streams."""
+def _lstm_streams(lstm: nn.LSTM, c0: int, c2: int, device, bf16: bool = False, pad_to: int = 0):
+    """Pack an nn.LSTM's parameters into per-direction device weight streams.  ``bf16``: the bf16-MFMA
+    stream; ``pad_to`` zero-pads the input columns (the last c2 ones are the skip segment) to that width."""
     out = []
     for sfx in [""] + (["_reverse"] if lstm.bidirectional else []):
-        out.append(ops.pack_lstm(getattr(lstm, "weight_ih_l0" + sfx), getattr(lstm, "weight_hh_l0" + sfx),
-                                 getattr(lstm, "bias_ih_l0" + sfx), getattr(lstm, "bias_hh_l0" + sfx),
-                                 c0, c2, device))
+        w_ih = getattr(lstm, "weight_ih_l0" + sfx).detach().float()
+        if pad_to and w_ih.shape[1] < pad_to:
+            w_ih = torch.cat((w_ih, w_ih.new_zeros((w_ih.shape[0], pad_to - w_ih.shape[1]))), dim=1)
+        args = (w_ih, getattr(lstm, "weight_hh_l0" + sfx).detach().float(),
+                getattr(lstm, "bias_ih_l0" + sfx).detach().float(), getattr(lstm, "bias_hh_l0" + sfx).detach().float(),
+                c0, c2, device)
+        out.append(ops.pack_lstm_bf16(*args) if bf16 else ops.pack_lstm(*args))
     return out
 
 

@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include "lstm_static.h"
+#include "lstm_bf16.h"
 
 using namespace fnssl_lstm;
 
@@ -35,6 +36,7 @@ extern template int launch_h<256>(int, const LstmParams&, int, int, hipStream_t)
 extern template int launch_split_h<128>(int, const LstmParams&, int, int, hipStream_t);
 extern template int launch_split_h<256>(int, const LstmParams&, int, int, hipStream_t);
 int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train.hip
+int forward_bf16(LstmParams p, int H, hipStream_t st);             // lstm_bf16.hip
 }  // namespace fnssl_lstm
 
 extern "C" {
@@ -180,6 +182,16 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   fnssl::TimedLaunch tl(names[hi], fnssl::as_stream(stream), flops);
   hipStream_t st = fnssl::as_stream(stream);
 
+  if (d->precision == FNSSL_PRECISION_BF16) {   // bf16 MFMA operands (weights packed by fnssl_lstm_pack_bf16)
+    FNSSL_REQUIRE(!(mode & (kHas1 | kSum)) && !d->reserve && !d->carry_state && d->c0 % 16 == 0 && d->c2 % 16 == 0,
+                  "lstm_forward: the bf16 path takes one summed and one concatenated input of 16-channel blocks, "
+                  "no fused residual / reserve / carry");
+    p.quads_per_slice = bf16_quads_per_slice(d->c0, d->c2, H);
+    p.chq = 0;
+    p.pad = 0;
+    return forward_bf16(p, H, st);
+  }
+  FNSSL_REQUIRE(d->precision == FNSSL_PRECISION_FP32, "lstm_forward: unknown precision %d", d->precision);
   if (d->reserve) {   // training forward: also save the gate activations (lstm_train.hip)
     FNSSL_REQUIRE((H == 128 || H == 256) && !(mode & (kHas1 | kSum)),
                   "lstm_forward: the reserve-saving forward needs hidden 128/256 and no src1 / out_sum");
@@ -234,20 +246,21 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     return n > 0 ? n : 256;
   }();
   // ---- few sequences (a single utterance, a streaming chunk): several waves per 16-sequence group ------
+  auto launch_split = [&](int split, int t0, int t1) -> int {
+    const int nw = split == 4 ? 8 : 4, groups_per_wg = nw / split;
+    p.task0 = t0;
+    p.task1 = t1;
+    p.wgs_per_dir = (t1 - t0 + groups_per_wg - 1) / groups_per_wg;
+    const Variant vr{nw, split == 4 ? 8 : 4, 1};
+    choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, split);
+    const int nwg = p.wgs_per_dir * d->ndir;
+    return H == 128 ? launch_split_h<128>(split, p, mode, nwg, st) : launch_split_h<256>(split, p, mode, nwg, st);
+  };
   {
     const long long total = (long long)tasks * d->ndir;
     int split = total * 4 <= 4LL * ncu ? 4 : total * 2 <= 4LL * ncu ? 2 : 1;   // fewer waves than SIMDs even after the split
     if (const int f = env_int("FNSSL_LSTM_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
-    if (split > 1) {
-      const int nw = split == 4 ? 8 : 4, groups_per_wg = nw / split;
-      p.task0 = 0;
-      p.task1 = tasks;
-      p.wgs_per_dir = (tasks + groups_per_wg - 1) / groups_per_wg;
-      const Variant vr{nw, split == 4 ? 8 : 4, 1};
-      choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, split);
-      const int nwg = p.wgs_per_dir * d->ndir;
-      return H == 128 ? launch_split_h<128>(split, p, mode, nwg, st) : launch_split_h<256>(split, p, mode, nwg, st);
-    }
+    if (split > 1) return launch_split(split, 0, tasks);
   }
 
   // ---- launch planner ---------------------------------------------------------------

@@ -113,6 +113,11 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
 __device__ __forceinline__ v4f bld4(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// Load that bypasses the per-CU vector L1 (sc1: agent scope) — for data this wave (or a partner wave) STORED
+// earlier and reads back through memory: a write does not refresh a line the L1 already holds.
+__device__ __forceinline__ v4f bld4_l2(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));
+}
 __device__ __forceinline__ float bld1(rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -30,7 +30,7 @@ SYMBOLS = [
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
-    "fnssl_lstm_backward", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
+    "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
 ]
@@ -53,6 +53,7 @@ class LstmDesc(C.Structure):
         ("variant", C.c_int),
         ("reserve", C.c_void_p), ("reserve_bytes", C.c_size_t),
         ("carry_state", C.c_int),
+        ("precision", C.c_int),
     ]
 
 
@@ -128,6 +129,9 @@ def load():
     lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
     lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
     lib.fnssl_ipd2doa.argtypes = [vp, ll, ll, ll, ll, vp, i, i, i, i, i, i, i, vp, vp, vp, vp]
+    lib.fnssl_lstm_packed_floats_bf16.argtypes = [i, i, i]
+    lib.fnssl_lstm_packed_floats_bf16.restype = sz
+    lib.fnssl_lstm_pack_bf16.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.fnssl_lstm_reserve_bytes.argtypes = [i, i, i, i]
     lib.fnssl_lstm_reserve_bytes.restype = sz
     lib.fnssl_lstm_bwd_packed_floats.argtypes = [i, i]

@@ -163,6 +163,25 @@ def pack_lstm(w_ih, w_hh, b_ih, b_hh, c0: int, c2: int, device) -> torch.Tensor:
     return torch.from_numpy(pack_lstm_host(w_ih, w_hh, b_ih, b_hh, c0, c2)).to(device)
 
 
+def pack_lstm_bf16(w_ih, w_hh, b_ih, b_hh, c0: int, c2: int, device) -> torch.Tensor:
+    """Weight stream of the bf16-MFMA kernels: weights rounded to bf16 (nearest even), bias fp32.
+    c0, c2 multiples of 16, hidden a multiple of 32."""
+    arrs = [np.ascontiguousarray(a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+            for a in (w_ih, w_hh, b_ih, b_hh)]
+    hidden = arrs[1].shape[1]
+    if arrs[0].shape != (4 * hidden, c0 + c2) or arrs[1].shape != (4 * hidden, hidden):
+        raise RuntimeError("fnssl.pack_lstm_bf16: weight shapes %s / %s do not match c0+c2=%d, H=%d"
+                           % (arrs[0].shape, arrs[1].shape, c0 + c2, hidden))
+    lib = _lib.load()
+    n = lib.fnssl_lstm_packed_floats_bf16(c0, c2, hidden)
+    if n == 0:
+        raise RuntimeError("fnssl.pack_lstm_bf16: unsupported sizes c0=%d c2=%d H=%d (16 / 16 / 32)" % (c0, c2, hidden))
+    out = np.empty(n, dtype=np.float32)
+    check(lib.fnssl_lstm_pack_bf16(*[a.ctypes.data_as(C.c_void_p) for a in arrs], c0, c2, hidden,
+                                   out.ctypes.data_as(C.c_void_p)), "lstm_pack_bf16")
+    return torch.from_numpy(out).to(device)
+
+
 def _view(t, mode):
     """4-D logical [nb, nt, nf, C] tensor -> (View, q_inner) for 'full' (seq=(b,t), step=f) or
     'narrow' (seq=(b,f), step=t)."""
@@ -199,7 +218,7 @@ def release_workspaces():
 
 
 def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
-               reserve=None, carry_workspace=None, carry=False):
+               reserve=None, carry_workspace=None, carry=False, bf16=False):
     """One (bi)LSTM layer over strided views.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
@@ -213,6 +232,8 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     Streaming (uni-directional layers): pass a persistent ``carry_workspace`` (``lstm_state_workspace``); with
     ``carry=True`` the recurrence continues from the cell state in it and from the h row one step before
     ``out`` in memory (the caller's buffer holds the previous call's last h there).
+    ``bf16=True``: ``packed`` comes from ``pack_lstm_bf16`` and the matrix product runs on bf16 MFMAs (operands
+    rounded to bf16, fp32 accumulate; all tensors stay fp32).
     """
     _need_dev(x0, x1, x2, out, skip, out_sum, *packed)
     if mode not in ("full", "narrow"):
@@ -266,6 +287,7 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
         ws = _workspace(wsb, out.device, "lstm")
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.variant = variant
+    d.precision = 1 if bf16 else 0
     if reserve is not None:
         _need_dev(reserve)
         d.reserve, d.reserve_bytes = reserve.data_ptr(), reserve.numel() * 4
@@ -341,7 +363,7 @@ def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: 
 # --------------------------------------------------------------------------- #
 def pack_conv3x3(weight, ca: int, cb: int, device) -> torch.Tensor:
     """Pack a Conv2d weight [cout, ca + cb, 3, 3] into the conv kernel's weight stream."""
-    w = np.ascontiguousarray(weight.detach().cpu().numpy() if isinstance(weight, torch.Tensor) else weight,
+    w = np.ascontiguousarray(weight.detach().float().cpu().numpy() if isinstance(weight, torch.Tensor) else weight,
                              dtype=np.float32)
     cout = w.shape[0]
     if w.shape != (cout, ca + cb, 3, 3):

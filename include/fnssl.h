@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 2
+#define FNSSL_ABI_VERSION 3
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -141,7 +141,20 @@ typedef struct {
    * there) and c_{-1} from `workspace`, where every call leaves its final cell state (the layout only
    * depends on nseq / hidden, so keep one workspace per layer between calls).                      */
   int carry_state;
+  /* arithmetic of the matrix product: FNSSL_PRECISION_FP32 (default: exact fp32 MFMA), or
+   * FNSSL_PRECISION_BF16: weights (wpack from fnssl_lstm_pack_bf16) and the [x | h] operands are rounded
+   * to bf16, accumulation / gates / cell state / all tensors stay fp32 (BASELINE config 3).  Built for
+   * the IPDnet layer shapes (c0, c2 multiples of 16, no src1 / out_sum).                              */
+  int precision;
 } fnssl_lstm_desc;
+
+#define FNSSL_PRECISION_FP32 0
+#define FNSSL_PRECISION_BF16 1
+
+/* bf16 weight stream (bias stays fp32): size in floats, and the host-only packer. */
+size_t fnssl_lstm_packed_floats_bf16(int c0, int c2, int hidden);
+int fnssl_lstm_pack_bf16(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                         int c0, int c2, int hidden, float* packed);
 
 /* Floats in one direction's packed weight stream for (input_size = c0 + c2, hidden). */
 size_t fnssl_lstm_packed_floats(int c0, int c2, int hidden);

@@ -175,8 +175,15 @@ def _sigmoid(x):
     return (F32(1.0) / (F32(1.0) + np.exp(-x, dtype=F32))).astype(F32)
 
 
+def bf16_round(a) -> np.ndarray:
+    """fp32 -> nearest-even bf16, returned as fp32 (what v_cvt_pk_bf16_f32 / the bf16 weight packer do)."""
+    u = np.ascontiguousarray(a, dtype=F32).view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xFFFF0000)).astype(np.uint32)
+    return r.view(F32).reshape(np.shape(a))
+
+
 def lstm_dir(x: np.ndarray, w_ih, w_hh, b_ih, b_hh, reverse: bool = False,
-             h0=None, c0=None) -> np.ndarray:
+             h0=None, c0=None, bf16: bool = False) -> np.ndarray:
     """One direction of a 1-layer batch_first nn.LSTM with zero initial state.
 
     PyTorch semantics (gate order i, f, g, o):
@@ -184,10 +191,15 @@ def lstm_dir(x: np.ndarray, w_ih, w_hh, b_ih, b_hh, reverse: bool = False,
         c_t = sigmoid(f) * c_{t-1} + sigmoid(i) * tanh(g)
         h_t = sigmoid(o) * tanh(c_t)
     x [N, T, I] -> h [N, T, H].  Used by FN-SSL/Model.py:25-29,38,46.
+
+    bf16=True restates the bf16-MFMA kernels (csrc/lstm_bf16.h): W_ih, W_hh and the operands x_t, h_{t-1} are
+    rounded to bf16 where they enter the product; bias, accumulation, gates, cell state and the stored h are fp32.
     """
     x = np.asarray(x, dtype=F32)
     N, T, _ = x.shape
     H = w_hh.shape[1]
+    if bf16:
+        x, w_ih, w_hh = bf16_round(x), bf16_round(w_ih), bf16_round(w_hh)
     xw = (x.reshape(N * T, -1) @ w_ih.T.astype(F32)).reshape(N, T, 4 * H)
     xw = (xw + (b_ih + b_hh).astype(F32)).astype(F32)
     whhT = np.ascontiguousarray(w_hh.T.astype(F32))
@@ -196,7 +208,7 @@ def lstm_dir(x: np.ndarray, w_ih, w_hh, b_ih, b_hh, reverse: bool = False,
     out = np.empty((N, T, H), dtype=F32)
     steps = range(T - 1, -1, -1) if reverse else range(T)
     for t in steps:
-        g = (xw[:, t] + h @ whhT).astype(F32)
+        g = (xw[:, t] + (bf16_round(h) if bf16 else h) @ whhT).astype(F32)
         i = _sigmoid(g[:, 0:H])
         f = _sigmoid(g[:, H:2 * H])
         gg = np.tanh(g[:, 2 * H:3 * H], dtype=F32)
@@ -207,14 +219,14 @@ def lstm_dir(x: np.ndarray, w_ih, w_hh, b_ih, b_hh, reverse: bool = False,
     return out
 
 
-def lstm(x: np.ndarray, sd: dict, prefix: str, bidirectional: bool) -> np.ndarray:
+def lstm(x: np.ndarray, sd: dict, prefix: str, bidirectional: bool, bf16: bool = False) -> np.ndarray:
     """nn.LSTM forward (output only); bi-dir output is [fwd || bwd]."""
     p = lambda n: sd[prefix + n]  # noqa: E731
-    fwd = lstm_dir(x, p("weight_ih_l0"), p("weight_hh_l0"), p("bias_ih_l0"), p("bias_hh_l0"))
+    fwd = lstm_dir(x, p("weight_ih_l0"), p("weight_hh_l0"), p("bias_ih_l0"), p("bias_hh_l0"), bf16=bf16)
     if not bidirectional:
         return fwd
     bwd = lstm_dir(x, p("weight_ih_l0_reverse"), p("weight_hh_l0_reverse"),
-                   p("bias_ih_l0_reverse"), p("bias_hh_l0_reverse"), reverse=True)
+                   p("bias_ih_l0_reverse"), p("bias_hh_l0_reverse"), reverse=True, bf16=bf16)
     return np.concatenate([fwd, bwd], axis=-1)
 
 
@@ -374,14 +386,14 @@ def pred_to_doa(pred: np.ndarray, nb: int, mic_location, ch_mode: str = "MM", ma
 # --------------------------------------------------------------------------- #
 # IPDnet, fixed array.  Reference IPDnet/FixedAarryIPDnet.py
 # --------------------------------------------------------------------------- #
-def ipdnet_block(sd, prefix, x, skip, is_online):
+def ipdnet_block(sd, prefix, x, skip, is_online, bf16=False):
     """IPDnet FNblock.forward (eval), FixedAarryIPDnet.py:29-40.  x [nb, nt, nf, C], skip [nb, nt, nf, Cs]:
     full-band BiLSTM, concat skip, narrow-band LSTM, concat skip -> [nb, nt, nf, Hn + Cs]."""
     nb, nt, nf, _ = x.shape
-    f = lstm(x.reshape(nb * nt, nf, -1), sd, prefix + "fullLstm.", True)                         # :31-32
+    f = lstm(x.reshape(nb * nt, nf, -1), sd, prefix + "fullLstm.", True, bf16)                   # :31-32
     v = np.concatenate([f, skip.reshape(nb * nt, nf, -1)], axis=-1)                              # :34
     v = np.transpose(v.reshape(nb, nt, nf, -1), (0, 2, 1, 3)).reshape(nb * nf, nt, -1)           # :35
-    n = lstm(v, sd, prefix + "narrLstm.", not is_online)                                         # :36
+    n = lstm(v, sd, prefix + "narrLstm.", not is_online, bf16)                                   # :36
     n = np.concatenate([n, np.transpose(skip, (0, 2, 1, 3)).reshape(nb * nf, nt, -1)], axis=-1)  # :38
     return np.ascontiguousarray(np.transpose(n.reshape(nb, nf, nt, -1), (0, 2, 1, 3)))           # :39
 
@@ -406,17 +418,19 @@ def avgpool_t(x, k):
     return (x[:, :, :, :t2 * k].reshape(nb, c, F, t2, k).sum(axis=4, dtype=F32) / F32(k)).astype(F32)
 
 
-def caus_cnn_block(sd, prefix, x):
-    """CausCnnBlock.forward, FixedAarryIPDnet.py:61-73.  x [nb, Cin, F, T] -> [nb, Cout, F, T // 12]."""
-    out = np.maximum(conv3x3_pad12(x, sd[prefix + "conv1.weight"]), 0)[:, :, :, :-2]
+def caus_cnn_block(sd, prefix, x, bf16=False):
+    """CausCnnBlock.forward, FixedAarryIPDnet.py:61-73.  x [nb, Cin, F, T] -> [nb, Cout, F, T // 12].
+    bf16=True: bf16-rounded weights (the module after .bfloat16()), fp32 activations and arithmetic."""
+    wq = (lambda a: bf16_round(a)) if bf16 else (lambda a: a)
+    out = np.maximum(conv3x3_pad12(x, wq(sd[prefix + "conv1.weight"])), 0)[:, :, :, :-2]
     out = avgpool_t(out, 3)
-    out = np.maximum(conv3x3_pad12(out, sd[prefix + "conv2.weight"]), 0)[:, :, :, :-2]
+    out = np.maximum(conv3x3_pad12(out, wq(sd[prefix + "conv2.weight"])), 0)[:, :, :, :-2]
     out = avgpool_t(out, 4)
-    out = conv3x3_pad12(out, sd[prefix + "conv3.weight"])[:, :, :, :-2]
+    out = conv3x3_pad12(out, wq(sd[prefix + "conv3.weight"]))[:, :, :, :-2]
     return np.tanh(out, dtype=F32)
 
 
-def ipdnet_forward(sd, x, is_online=True, n_seg=0):
+def ipdnet_forward(sd, x, is_online=True, n_seg=0, bf16=False):
     """IPDnet.forward, FixedAarryIPDnet.py:91-120.  x [nb, 2*nch, nf, nt] -> [nb, nt // 12, 2*nf, nch - 1, max_track].
     n_seg > 0 (offline networks only) = chunk-wise inference (offline_inference=True, :96-100, :114-116):
     the time axis is zero-padded to a multiple of n_seg and the segments are processed independently."""
@@ -428,16 +442,19 @@ def ipdnet_forward(sd, x, is_online=True, n_seg=0):
         xp = np.concatenate([x, np.zeros((nb, pad, nf, x.shape[3]), dtype=F32)], axis=1)
         nseg = (nt + pad) // n_seg
         xs = xp.reshape(nb * nseg, n_seg, nf, -1)                             # :98-99
-        ys = ipdnet_forward(sd, np.transpose(xs, (0, 3, 2, 1)), is_online)    # [nb*nseg, nt2, 2nf, P, 2]
+        ys = ipdnet_forward(sd, np.transpose(xs, (0, 3, 2, 1)), is_online, bf16=bf16)   # [nb*nseg, nt2, 2nf, P, 2]
         nt2 = n_seg // 12
         # undo the final permute, regroup segments along time (:115), redo it
         c = np.transpose(ys, (0, 1, 4, 2, 3)).reshape(nb, nseg * nt2, 2, 2 * nf, -1)
         return np.ascontiguousarray(np.transpose(c, (0, 1, 3, 4, 2))[:, :ou_frame])
-    y = ipdnet_block(sd, "block_1.", x, x, is_online)
-    y = ipdnet_block(sd, "block_2.", y, x, is_online)
+    if bf16:   # config 3: bf16 parameters (biases too, the module is .bfloat16()) and a bf16 input
+        sd = {k: bf16_round(v) for k, v in sd.items()}
+        x = bf16_round(x)
+    y = ipdnet_block(sd, "block_1.", x, x, is_online, bf16)
+    y = ipdnet_block(sd, "block_2.", y, x, is_online, bf16)
     y = np.transpose(y, (0, 3, 2, 1))                                         # [nb, C', nf, nt]
     nt2 = nt // 12
-    c = caus_cnn_block(sd, "conv.", y)                                        # [nb, Cout, nf, nt2]
+    c = caus_cnn_block(sd, "conv.", y, bf16)                                  # [nb, Cout, nf, nt2]
     c = np.transpose(c, (0, 3, 2, 1)).reshape(nb, nt2, nf, 2, -1)             # :113
     c = np.transpose(c, (0, 1, 3, 2, 4))                                      # [nb, nt2, 2, nf, K]
     return np.ascontiguousarray(np.transpose(c.reshape(nb, nt2, 2, nf * 2, -1), (0, 1, 3, 4, 2)))   # :118

@@ -693,3 +693,83 @@ def test_fnssl_forward_stream_equals_whole_signal(dev, doa):
     off = Model.FN_SSL(is_online=False).eval().to(dev)
     with pytest.raises(RuntimeError, match="online"):
         off.forward_stream(x)
+
+
+# --------------------------------------------------------------------------- bf16 MFMA path (BASELINE config 3)
+# Tolerances.  Against the bf16-emulating oracle (same operand rounding, fp32 accumulation in another order;
+# an operand that sits on a rounding boundary can flip one bf16 ulp = 2^-8 relative) the LSTM outputs agree to
+# 4e-3 absolute (|h| <= 1; typically 1e-6).  Against the fp32 oracle the network output (tanh, |y| <= 1) is within 2e-2
+# relative + 2e-3 absolute — the tolerance SURVEY.md §8d suggests for config 3.
+BF_ATOL = 4e-3
+
+
+@pytest.mark.parametrize("mode,H,bidir,c0,c2,nb,nt,nf", [
+    ("narrow", 256, False, 256, 16, 1, 9, 40),      # IPDnet hidden 256: narrow-band, ragged last group
+    ("full", 128, True, 256, 16, 1, 20, 7),         # full-band of block 2, both directions
+    ("full", 128, True, 16, 0, 2, 9, 6),            # full-band of block 1: the 16 input channels alone
+    ("narrow", 128, False, 128, 16, 2, 7, 16),      # hidden 128 (two microphones, padded skip)
+    ("full", 64, True, 128, 16, 1, 18, 5),
+    ("full", 64, True, 16, 0, 1, 17, 4),
+    ("narrow", 128, True, 256, 16, 1, 6, 24),       # offline narrow-band (bi-directional H=128 on 256 + 16)
+])
+def test_lstm_bf16_layer_matches_bf16_oracle(dev, mode, H, bidir, c0, c2, nb, nt, nf):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    I = c0 + c2
+    sd = lstm_state(I, H, bidir, 4100 + H + I)
+    x = rs_randn(4101, (nb, nt, nf, I), 0.7)
+    seq = x.reshape(nb * nt, nf, I) if mode == "full" else np.transpose(x, (0, 2, 1, 3)).reshape(nb * nf, nt, I)
+    want = O.lstm(seq, sd, "L.", bidir, bf16=True)
+    want32 = O.lstm(seq, sd, "L.", bidir)
+    ndir = 2 if bidir else 1
+    want, want32 = [w.reshape(nb, nt, nf, -1) if mode == "full" else np.transpose(w.reshape(nb, nf, nt, -1), (0, 2, 1, 3))
+                    for w in (want, want32)]
+    w = [ops.pack_lstm_bf16(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s],
+                            sd["L.bias_hh_l0" + s], c0, c2, dev) for s in ([""] + (["_reverse"] if bidir else []))]
+    xd = to_dev(x, dev)
+    out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+    ops.lstm_layer(mode, xd[..., :c0].contiguous(), None, xd[..., c0:].contiguous() if c2 else None, w, H, out, bf16=True)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= BF_ATOL, "vs bf16 oracle: %g" % np.abs(got - want).max()
+    assert np.abs(got - want32).max() <= 3e-2, "vs fp32 oracle: %g" % np.abs(got - want32).max()
+
+
+def test_lstm_bf16_rejects_unbuilt_shapes(dev):
+    from fnssl import ops
+    sd = lstm_state(256, 256, False, 4200)
+    w = [ops.pack_lstm_bf16(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], 256, 0, dev)]
+    x = torch.zeros((1, 4, 16, 256), device=dev)
+    out = torch.zeros((1, 4, 16, 256), device=dev)
+    with pytest.raises(RuntimeError, match="bf16 path is not built"):
+        ops.lstm_layer("narrow", x, None, None, w, 256, out, bf16=True)
+    with pytest.raises(RuntimeError, match="unsupported sizes"):
+        ops.pack_lstm_bf16(np.zeros((1024, 260), np.float32), sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"],
+                           256, 4, dev)
+
+
+@pytest.mark.parametrize("isz,hid,online,shape", [(16, 256, True, (1, 16, 32, 24)), (4, 128, True, (2, 4, 16, 24)),
+                                                  (16, 256, False, (1, 16, 16, 36))])
+def test_ipdnet_bf16_config3(dev, isz, hid, online, shape):
+    """IPDnet after .bfloat16() (bf16 weights, bf16 MFMA operands, fp32 accumulate) against the bf16-emulating
+    oracle and, at the config-3 tolerance, against the fp32 oracle."""
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    M = _ipdnet_module()
+    sd = W.make_ipdnet_state(4300 + isz, isz, hid, 2, online)
+    net = M.IPDnet(input_size=isz, hidden_size=hid, max_track=2, is_online=online).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev).bfloat16()
+    x = rs_randn(4301, shape)
+    y = net(to_dev(x, dev).bfloat16())
+    assert y.dtype == torch.bfloat16
+    want_bf = O.ipdnet_forward(sd, x, online, bf16=True)
+    want_32 = O.ipdnet_forward(sd, x, online)
+    got = y.float().cpu().numpy()
+    assert got.shape == want_32.shape
+    # the returned tensor is itself rounded to bf16 (relative 2^-9)
+    assert np.abs(got - want_bf).max() <= BF_ATOL + 4e-3 * np.abs(want_bf).max(), np.abs(got - want_bf).max()
+    assert_close(got, want_32, 2e-2, 2e-3, "bf16 IPDnet vs fp32 oracle")
+    # fp32 input works too and returns fp32
+    y32 = net(to_dev(O.bf16_round(x), dev))
+    assert y32.dtype == torch.float32 and np.abs(y32.cpu().numpy() - want_bf).max() <= BF_ATOL

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--offline", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="config 3 as written: bf16 weights / MFMA operands, fp32 accumulate")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     isz = 2 * args.mics
@@ -37,6 +38,8 @@ def main():
     net = M.IPDnet(input_size=isz, hidden_size=args.hidden, max_track=2, is_online=not args.offline).eval()
     net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     net.to(dev)
+    if args.bf16:
+        net.bfloat16()
     g = torch.Generator(device=dev)
     g.manual_seed(0)
     ns = 256 * (args.frames + 1)
@@ -65,7 +68,7 @@ def main():
     print(json.dumps({
         "metric": "TF-frames/sec IPDnet forward (fixed array), waveform -> DP-IPD",
         "value": round(args.nb * args.frames / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 2),
-        "dtype": "fp32", "data": "synthetic",
+        "dtype": "bf16 (MFMA operands; fp32 accumulate and tensors)" if args.bf16 else "fp32", "data": "synthetic",
         "config": {"workload": "IPDnet %d-mic hidden %d %s, batch %d, 256 bins x %d frames"
                    % (args.mics, args.hidden, "offline" if args.offline else "online", args.nb, args.frames)},
         "tflops_per_step": round(flops / 1e12, 2), "achieved_tflops": round(flops / dt / 1e12, 1),

@@ -173,25 +173,32 @@ class CausCnnBlock(nn.Module):
             h = self.cnn_hidden_dim
             if h % 16:
                 raise RuntimeError("CausCnnBlock: cnn_hidden_dim must be a multiple of 16")
-            self._packed = (ops.pack_conv3x3(self.conv1.weight, ca, cb, device),
-                            ops.pack_conv3x3(self.conv2.weight, h, 0, device),
-                            ops.pack_conv3x3(self.conv3.weight, h, 0, device))
+            bf = _is_bf16(self)
+            w1 = self.conv1.weight.detach().float()
+            if w1.shape[1] < ca + cb:        # bf16 path: the skip segment arrives zero-padded to 16 channels
+                w1 = torch.cat((w1, w1.new_zeros((w1.shape[0], ca + cb - w1.shape[1], 3, 3))), dim=1)
+            self._packed = (ops.pack_conv3x3(w1, ca, cb, device, bf),
+                            ops.pack_conv3x3(self.conv2.weight, h, 0, device, bf),
+                            ops.pack_conv3x3(self.conv3.weight, h, 0, device, bf))
             self._packed_key = key
         return self._packed
 
     def run(self, xa, xb):
         """Channel concatenation [xa | xb] of logical [nb, nf, nt, C] tensors -> [nb, nf, nt//12, ceil4(out_dim)]."""
         _require_eval(self)
+        bf = _is_bf16(self)
+        if bf and xb is not None:
+            xb = _pad_channels(xb, _ceil16(xb.shape[3]))          # whole 16-channel blocks (zero weights there)
         ca = xa.shape[3]
         cb = 0 if xb is None else xb.shape[3]
-        if ca + cb != self.inp_dim:
+        if ca + cb != self.inp_dim and not (bf and ca + cb == _ceil16(self.inp_dim - ca) + ca):
             raise RuntimeError("CausCnnBlock: %d + %d input channels, expected %d" % (ca, cb, self.inp_dim))
         w1, w2, w3 = self._streams(xa.device, ca, cb)
-        y = ops.conv3x3_causal(xa, xb, w1, self.cnn_hidden_dim, "relu")
+        y = ops.conv3x3_causal(xa, xb, w1, self.cnn_hidden_dim, "relu", bf)
         y = ops.avgpool_time(y, 3)
-        y = ops.conv3x3_causal(y, None, w2, self.cnn_hidden_dim, "relu")
+        y = ops.conv3x3_causal(y, None, w2, self.cnn_hidden_dim, "relu", bf)
         y = ops.avgpool_time(y, 4)
-        return ops.conv3x3_causal(y, None, w3, self.out_dim, "tanh")
+        return ops.conv3x3_causal(y, None, w3, self.out_dim, "tanh", bf)
 
     def forward(self, x):
         """Reference signature: x [nb, inp_dim, nf, nt] -> [nb, out_dim, nf, nt // 12]."""
@@ -246,7 +253,8 @@ class IPDnet(nn.Module):
         xp = _pad_channels(xs, _ceil16(nc)) if _is_bf16(self) else xs   # bf16 kernels read whole 16-channel blocks
         y = self.block_1.run(None, xp)
         y = self.block_2.run(y, xp)                                 # logical [nb, nt, nf, Hn], stored [nb, nf, nt, Hn]
-        c = self.conv.run(y.permute(0, 2, 1, 3), xp[..., :nc].permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
+        xc = xp if _is_bf16(self) else xp[..., :nc]               # (bf16: the padded channels meet zero weights)
+        c = self.conv.run(y.permute(0, 2, 1, 3), xc.permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
         nt2 = nt // 12
         c = c[..., :self.cnn_out_dim].permute(0, 2, 1, 3)           # = conv(x).permute(0,3,2,1)  (:113)
         c = c.reshape(nb, nt2, nf, 2, -1).permute(0, 1, 3, 2, 4)

@@ -162,6 +162,97 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_kernel(const ConvParams p) {
   }
 }
 
+// bf16-MFMA twin (BASELINE config 3): weights bf16 in the stream, the activation operands rounded to bf16 when
+// they enter the MFMA, fp32 accumulation and tensors.  One v_mfma_f32_16x16x32_bf16 per (output tile, PAIR of
+// 16-channel blocks); a record = the A operand of one tile for one pair (lane (i, g): output channel 16j + i,
+// channels 16*b0 + 4g + {0..3} and 16*b1 + 4g + {0..3}), NT records per pair = NT/4 quads.  Blocks run over the
+// concatenation [xa | xb] (both multiples of 16 channels); an odd last block is paired with zeros.
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+
+template <int NT, int NW, int M>
+__global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams p) {
+  static_assert(NT == 4 || NT == 8, "4 or 8 output-channel tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+  WStream<NW, M, 1> ws;
+  ws.nobar = false;
+  ws.init(p.wpack, lane, w, p.quads_per_pass, 1, p.chq, p.pad, smem);
+  const int nva = p.ca >> 4, nv = nva + (p.cb >> 4), npairs = (nv + 1) >> 1;
+  const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (int pass = 0; pass < p.passes; ++pass) {
+    int tile = (pass * (int)gridDim.x + (int)blockIdx.x) * NW + w;
+    const bool tvalid = tile < p.ntiles;
+    if (!tvalid) tile = p.ntiles - 1;
+    const int tt = tile % p.tiles_t;
+    const int bf = tile / p.tiles_t;
+    const int f = bf % p.nf;
+    const int b = __builtin_amdgcn_readfirstlane(bf / p.nf);
+    const rsrc_t ra = make_rsrc(p.xa + (long long)b * p.a_sb);
+    const rsrc_t rb = make_rsrc(p.xb ? p.xb + (long long)b * p.b_sb : p.xa);
+    const rsrc_t ro = make_rsrc(p.out + (long long)b * p.nf * p.nt * p.cout_stride);
+    int tpos = tt * 16 + n;
+    const bool pvalid = tvalid && tpos < p.nt;
+    v4f acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = zero4;
+
+    for (int df = -1; df <= 1; ++df) {
+      const int ff = f + df;
+      const bool frow = ff >= 0 && ff < p.nf;
+      const int fc = frow ? ff : f;
+      for (int dt = 0; dt < 3; ++dt) {
+        int ts = tpos + dt - 2;
+        const bool live = frow && ts >= 0;
+        ts = ts < 0 ? 0 : (ts >= p.nt ? p.nt - 1 : ts);
+        const unsigned offa = (unsigned)(((long long)fc * p.a_sf + (long long)ts * p.a_st) * 4) + 16 * g;
+        const unsigned offb = (unsigned)(((long long)fc * p.b_sf + (long long)ts * p.b_st) * 4) + 16 * g;
+        auto block = [&](int v) -> v4f {   // 16-channel block v of [xa | xb]; zeros past the end
+          if (v >= nv) return zero4;
+          return v < nva ? bld4(ra, offa, 64 * v) : bld4(rb, offb, 64 * (v - nva));
+        };
+        v4f n0 = block(0), n1 = block(1);
+        for (int pi = 0; pi < npairs; ++pi) {
+          v4f c0 = n0, c1 = n1;
+          if (!live) {
+            c0 = zero4;
+            c1 = zero4;
+          }
+          n0 = block(2 * pi + 2);   // operands of the next pair: in flight behind this pair's MFMAs
+          n1 = block(2 * pi + 3);
+          const v4bf lo = __builtin_convertvector(c0, v4bf), hi = __builtin_convertvector(c1, v4bf);
+          const v8bf bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int qd = 0; qd < NT / 4; ++qd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[4 * qd + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, ws.record(j)), bv,
+                                                                        acc[4 * qd + j], 0, 0, 0);
+            (void)ws.advance();
+          }
+        }
+      }
+    }
+    for (int u = 0; u < p.pad; ++u) (void)ws.advance();
+    if (tpos >= p.nt) tpos = p.nt - 1;
+    const unsigned obase = (unsigned)((((long long)f * p.nt + tpos) * p.cout_stride) * 4) + 16 * g;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      v4f r = acc[j];
+      if (p.act == 1) {
+        r = v4f{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
+      } else if (p.act == 2) {
+        r = v4f{tanhf(r.x), tanhf(r.y), tanhf(r.z), tanhf(r.w)};
+      }
+      if (pvalid && 16 * j + 4 * g < p.cout) bst4(r, ro, obase, 64 * j);
+    }
+  }
+}
+
 // out[b, f, t2, c] = mean_k in[b, f, K*t2 + k, c]   (AvgPool2d((1, K)), floors)
 __global__ void __launch_bounds__(256)
 pool_t_kernel(const float4* __restrict__ in, int rows, int nt, int c4, int K, float4* __restrict__ out) {
@@ -243,12 +334,59 @@ int fnssl_conv3x3_pack(const float* w, int cout, int ca, int cb, float* packed) 
   return FNSSL_OK;
 }
 
-int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
-                         long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout,
-                         int nb, int nf, int nt, int act, float* out, int cout_stride, void* stream) {
+static unsigned short conv_to_bf16(float f) {   // round to nearest even
+  unsigned u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+static int bf16_quads_per_pass(int cout, int ca, int cb) {
+  const int npairs = ((ca >> 4) + (cb >> 4) + 1) / 2;
+  return 9 * npairs * (conv_nt_tiles(cout) / 4);
+}
+
+size_t fnssl_conv3x3_packed_floats_bf16(int cout, int ca, int cb) {
+  if (cout <= 0 || cout > 128 || ca <= 0 || cb < 0 || (ca & 15) || (cb & 15)) return 0;
+  return (size_t)bf16_quads_per_pass(cout, ca, cb) * 4 * 256;
+}
+
+int fnssl_conv3x3_pack_bf16(const float* w, int cout, int ca, int cb, float* packed) {
+  FNSSL_REQUIRE(w && packed, "conv3x3_pack_bf16: null pointer");
+  const size_t total = fnssl_conv3x3_packed_floats_bf16(cout, ca, cb);
+  FNSSL_REQUIRE(total > 0, "conv3x3_pack_bf16: unsupported sizes (cout %d <= 128, ca %d and cb %d multiples of 16)", cout,
+                ca, cb);
+  std::memset(packed, 0, total * sizeof(float));
+  const int cin = ca + cb, nv = cin >> 4, NT = conv_nt_tiles(cout);
+  float* recf = packed;
+  for (int df = 0; df < 3; ++df)
+    for (int dt = 0; dt < 3; ++dt)
+      for (int pi = 0; pi < (nv + 1) / 2; ++pi)
+        for (int j = 0; j < NT; ++j, recf += 256) {   // record = output tile j
+          unsigned short* rec = reinterpret_cast<unsigned short*>(recf);
+          for (int l = 0; l < 64; ++l)
+            for (int half = 0; half < 2; ++half)
+              for (int jj = 0; jj < 4; ++jj) {
+                const int blk = 2 * pi + half, oc = 16 * j + (l & 15), ci = 16 * blk + 4 * (l >> 4) + jj;
+                const float v = (blk < nv && oc < cout) ? w[(((size_t)oc * cin + ci) * 3 + df) * 3 + dt] : 0.f;
+                rec[l * 8 + half * 4 + jj] = conv_to_bf16(v);
+              }
+        }
+  if ((size_t)(recf - packed) != total) {
+    fnssl::set_error("conv3x3_pack_bf16: internal size mismatch");
+    return FNSSL_E_INVALID;
+  }
+  return FNSSL_OK;
+}
+
+static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
+                    long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout, int nb,
+                    int nf, int nt, int act, float* out, int cout_stride, void* stream) {
   FNSSL_REQUIRE(xa && wpack && out, "conv3x3: null pointer");
   FNSSL_REQUIRE(nb > 0 && nf > 0 && nt > 0, "conv3x3: empty problem");
-  FNSSL_REQUIRE(fnssl_conv3x3_packed_floats(cout, ca, cb) > 0 && ca > 0, "conv3x3: unsupported channel counts");
+  FNSSL_REQUIRE((bf ? fnssl_conv3x3_packed_floats_bf16(cout, ca, cb) : fnssl_conv3x3_packed_floats(cout, ca, cb)) > 0 &&
+                    ca > 0,
+                "conv3x3: unsupported channel counts");
   FNSSL_REQUIRE(cb == 0 || xb, "conv3x3: segment B missing");
   FNSSL_REQUIRE(cout_stride >= cout && cout_stride % 4 == 0 && act >= 0 && act <= 2, "conv3x3: bad output spec");
   auto fits = [&](long long sb, long long sf, long long st, int c) {
@@ -281,7 +419,8 @@ int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long l
   p.ntiles = nb * nf * p.tiles_t;
   const int NT = conv_nt_tiles(cout);
   constexpr int NW = 12, M = 4;
-  p.quads_per_pass = NT == 8 ? quads_per_pass_host<8>(ca, cb) : quads_per_pass_host<4>(ca, cb);
+  p.quads_per_pass = bf ? bf16_quads_per_pass(cout, ca, cb)
+                        : (NT == 8 ? quads_per_pass_host<8>(ca, cb) : quads_per_pass_host<4>(ca, cb));
   Variant vr{NW, M, 1};
   choose_chunk(p.quads_per_pass, vr, p.chq, p.pad);
   static const int ncu = [] {
@@ -294,8 +433,20 @@ int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long l
   p.passes = (groups + nwg - 1) / nwg;
   const size_t lds = (size_t)2 * p.chq * 4096;
   const double flops = 2.0 * 9 * (ca + cb) * (double)cout * nb * nf * (double)nt;
-  fnssl::TimedLaunch tl("conv3x3", fnssl::as_stream(stream), flops);
-  if (NT == 8) {
+  fnssl::TimedLaunch tl(bf ? "conv3x3_bf16" : "conv3x3", fnssl::as_stream(stream), flops);
+  if (bf) {
+    if (NT == 8) {
+      auto k = conv3x3_bf16_kernel<8, NW, M>;
+      if (lds > 48 * 1024)
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, fnssl::as_stream(stream), p);
+    } else {
+      auto k = conv3x3_bf16_kernel<4, NW, M>;
+      if (lds > 48 * 1024)
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, fnssl::as_stream(stream), p);
+    }
+  } else if (NT == 8) {
     auto k = conv3x3_kernel<8, NW, M>;
     if (lds > 48 * 1024)
       FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -308,6 +459,20 @@ int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long l
   }
   FNSSL_CHECK_LAUNCH("conv3x3_kernel");
   return FNSSL_OK;
+}
+
+int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
+                         long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout,
+                         int nb, int nf, int nt, int act, float* out, int cout_stride, void* stream) {
+  return conv_run(false, xa, a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf, nt, act, out,
+                  cout_stride, stream);
+}
+
+int fnssl_conv3x3_causal_bf16(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
+                              long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout,
+                              int nb, int nf, int nt, int act, float* out, int cout_stride, void* stream) {
+  return conv_run(true, xa, a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf, nt, act, out,
+                  cout_stride, stream);
 }
 
 int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y, void* stream) {

@@ -28,7 +28,8 @@ SYMBOLS = [
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
-    "fnssl_avgpool_time", "fnssl_array_features",
+    "fnssl_avgpool_time", "fnssl_array_features", "fnssl_conv3x3_packed_floats_bf16", "fnssl_conv3x3_pack_bf16",
+    "fnssl_conv3x3_causal_bf16",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
     "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
@@ -153,6 +154,10 @@ def load():
     lib.fnssl_conv3x3_packed_floats.restype = sz
     lib.fnssl_conv3x3_pack.argtypes = [vp, i, i, i, vp]
     lib.fnssl_conv3x3_causal.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
+    lib.fnssl_conv3x3_packed_floats_bf16.argtypes = [i, i, i]
+    lib.fnssl_conv3x3_packed_floats_bf16.restype = sz
+    lib.fnssl_conv3x3_pack_bf16.argtypes = [vp, i, i, i, vp]
+    lib.fnssl_conv3x3_causal_bf16.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
     lib.fnssl_avgpool_time.argtypes = [vp, i, i, i, i, vp, vp]
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz

@@ -361,8 +361,9 @@ def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: 
 # --------------------------------------------------------------------------- #
 # causal 3x3 conv + time pooling (IPDnet head)
 # --------------------------------------------------------------------------- #
-def pack_conv3x3(weight, ca: int, cb: int, device) -> torch.Tensor:
-    """Pack a Conv2d weight [cout, ca + cb, 3, 3] into the conv kernel's weight stream."""
+def pack_conv3x3(weight, ca: int, cb: int, device, bf16: bool = False) -> torch.Tensor:
+    """Pack a Conv2d weight [cout, ca + cb, 3, 3] into the conv kernel's weight stream (``bf16``: the bf16-MFMA
+    stream; ca, cb multiples of 16)."""
     w = np.ascontiguousarray(weight.detach().float().cpu().numpy() if isinstance(weight, torch.Tensor) else weight,
                              dtype=np.float32)
     cout = w.shape[0]
@@ -370,16 +371,16 @@ def pack_conv3x3(weight, ca: int, cb: int, device) -> torch.Tensor:
         raise RuntimeError("fnssl.pack_conv3x3: weight shape %s does not match [cout, %d + %d, 3, 3]"
                            % (w.shape, ca, cb))
     lib = _lib.load()
-    n = lib.fnssl_conv3x3_packed_floats(cout, ca, cb)
+    n = (lib.fnssl_conv3x3_packed_floats_bf16 if bf16 else lib.fnssl_conv3x3_packed_floats)(cout, ca, cb)
     if n == 0:
         raise RuntimeError("fnssl.pack_conv3x3: unsupported sizes cout=%d ca=%d cb=%d" % (cout, ca, cb))
     out = np.empty(n, dtype=np.float32)
-    check(lib.fnssl_conv3x3_pack(w.ctypes.data_as(C.c_void_p), cout, ca, cb, out.ctypes.data_as(C.c_void_p)),
-          "conv3x3_pack")
+    check((lib.fnssl_conv3x3_pack_bf16 if bf16 else lib.fnssl_conv3x3_pack)(
+        w.ctypes.data_as(C.c_void_p), cout, ca, cb, out.ctypes.data_as(C.c_void_p)), "conv3x3_pack")
     return torch.from_numpy(out).to(device)
 
 
-def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none"):
+def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none", bf16: bool = False):
     """Causal 3x3 conv over (bin, time) of the channel concatenation [xa | xb].
 
     xa / xb: logical [nb, nf, nt, C] tensors with arbitrary batch / bin / time strides and a
@@ -398,9 +399,10 @@ def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none"):
     sa = xa.stride()
     sb_ = xb.stride() if xb is not None else (0, 0, 0, 1)
     code = {"none": 0, "relu": 1, "tanh": 2}[act]
-    check(_lib.load().fnssl_conv3x3_causal(_ptr(xa), sa[0], sa[1], sa[2], ca,
-                                           _ptr(xb) if xb is not None else None, sb_[0], sb_[1], sb_[2], cb,
-                                           _ptr(packed), cout, nb, nf, nt, code, _ptr(out), cs, _stream()),
+    fn = _lib.load().fnssl_conv3x3_causal_bf16 if bf16 else _lib.load().fnssl_conv3x3_causal
+    check(fn(_ptr(xa), sa[0], sa[1], sa[2], ca,
+             _ptr(xb) if xb is not None else None, sb_[0], sb_[1], sb_[2], cb,
+             _ptr(packed), cout, nb, nf, nt, code, _ptr(out), cs, _stream()),
           "conv3x3_causal")
     return out
 

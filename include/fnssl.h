@@ -335,6 +335,15 @@ int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long l
                          const float* wpack, int cout, int nb, int nf, int nt, int act,
                          float* out, int cout_stride, void* stream);
 
+/* bf16-MFMA variant (BASELINE config 3): weights rounded to bf16 in the stream, activation operands rounded
+ * to bf16 as they enter the MFMA, fp32 accumulation and tensors; ca and cb multiples of 16. */
+size_t fnssl_conv3x3_packed_floats_bf16(int cout, int ca, int cb);
+int fnssl_conv3x3_pack_bf16(const float* w, int cout, int ca, int cb, float* packed);
+int fnssl_conv3x3_causal_bf16(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca,
+                              const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
+                              const float* wpack, int cout, int nb, int nf, int nt, int act,
+                              float* out, int cout_stride, void* stream);
+
 /* y[row, t2, c] = mean_{k < K} x[row, K*t2 + k, c]   (AvgPool2d((1, K)); c % 4 == 0). */
 int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y, void* stream);
 

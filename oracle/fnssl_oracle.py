@@ -420,13 +420,13 @@ def avgpool_t(x, k):
 
 def caus_cnn_block(sd, prefix, x, bf16=False):
     """CausCnnBlock.forward, FixedAarryIPDnet.py:61-73.  x [nb, Cin, F, T] -> [nb, Cout, F, T // 12].
-    bf16=True: bf16-rounded weights (the module after .bfloat16()), fp32 activations and arithmetic."""
-    wq = (lambda a: bf16_round(a)) if bf16 else (lambda a: a)
-    out = np.maximum(conv3x3_pad12(x, wq(sd[prefix + "conv1.weight"])), 0)[:, :, :, :-2]
+    bf16=True: weights and each conv's input rounded to bf16 (MFMA operands), fp32 accumulation / pooling / tensors."""
+    wq = (lambda a: bf16_round(a)) if bf16 else (lambda a: a)   # weights AND conv inputs enter the MFMA as bf16
+    out = np.maximum(conv3x3_pad12(wq(x), wq(sd[prefix + "conv1.weight"])), 0)[:, :, :, :-2]
     out = avgpool_t(out, 3)
-    out = np.maximum(conv3x3_pad12(out, wq(sd[prefix + "conv2.weight"])), 0)[:, :, :, :-2]
+    out = np.maximum(conv3x3_pad12(wq(out), wq(sd[prefix + "conv2.weight"])), 0)[:, :, :, :-2]
     out = avgpool_t(out, 4)
-    out = conv3x3_pad12(out, wq(sd[prefix + "conv3.weight"]))[:, :, :, :-2]
+    out = conv3x3_pad12(wq(out), wq(sd[prefix + "conv3.weight"]))[:, :, :, :-2]
     return np.tanh(out, dtype=F32)
 
 

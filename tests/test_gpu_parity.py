@@ -773,3 +773,22 @@ def test_ipdnet_bf16_config3(dev, isz, hid, online, shape):
     # fp32 input works too and returns fp32
     y32 = net(to_dev(O.bf16_round(x), dev))
     assert y32.dtype == torch.float32 and np.abs(y32.cpu().numpy() - want_bf).max() <= BF_ATOL
+
+
+@pytest.mark.parametrize("cout,ca,cb,nb,nf,nt,act", [(128, 256, 16, 1, 4, 21, "relu"), (128, 128, 0, 2, 3, 16, "relu"),
+                                                      (28, 128, 0, 1, 2, 9, "tanh"), (4, 128, 0, 1, 5, 5, "tanh"),
+                                                      (128, 16, 16, 1, 3, 17, "none")])
+def test_conv3x3_bf16_matches_bf16_oracle(dev, cout, ca, cb, nb, nf, nt, act):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    w = rs_randn(4400 + cout + ca, (cout, ca + cb, 3, 3), 0.1)
+    xa = rs_randn(4401, (nb, nf, nt, ca))
+    xb = rs_randn(4402, (nb, nf, nt, cb)) if cb else None
+    packed = ops.pack_conv3x3(w, ca, cb, dev, bf16=True)
+    got = ops.conv3x3_causal(to_dev(xa, dev), to_dev(xb, dev) if cb else None, packed, cout, act, bf16=True).cpu().numpy()
+    want = _oracle_conv(O.bf16_round(xa), O.bf16_round(xb) if cb else None, O.bf16_round(w), act)
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(got[..., :cout] - want).max() <= 2e-5 * scale, np.abs(got[..., :cout] - want).max()
+    assert not got[..., cout:].any()
+    with pytest.raises(RuntimeError, match="unsupported sizes"):
+        ops.pack_conv3x3(np.zeros((8, 20, 3, 3), np.float32), 16, 4, dev, bf16=True)

@@ -72,7 +72,8 @@ def main():
         "config": {"workload": "IPDnet %d-mic hidden %d %s, batch %d, 256 bins x %d frames"
                    % (args.mics, args.hidden, "offline" if args.offline else "online", args.nb, args.frames)},
         "tflops_per_step": round(flops / 1e12, 2), "achieved_tflops": round(flops / dt / 1e12, 1),
-        "frac_of_fp32_mfma_peak": round(flops / dt / 157.3e12, 3),
+        ("frac_of_bf16_mfma_peak" if args.bf16 else "frac_of_fp32_mfma_peak"):
+            round(flops / dt / (2500e12 if args.bf16 else 157.3e12), 3),
         "out_shape": list(y.shape), "finite": bool(torch.isfinite(y).all()), "kernels": kern}))
 
 

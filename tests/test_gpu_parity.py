@@ -792,3 +792,42 @@ def test_conv3x3_bf16_matches_bf16_oracle(dev, cout, ca, cb, nb, nf, nt, act):
     assert not got[..., cout:].any()
     with pytest.raises(RuntimeError, match="unsupported sizes"):
         ops.pack_conv3x3(np.zeros((8, 20, 3, 3), np.float32), 16, 4, dev, bf16=True)
+
+
+# --------------------------------------------------------------------------- randomized shape sweep
+def test_lstm_random_shapes_all_launch_paths(dev):
+    """40 seeded random layer shapes (hidden size, input segments, batch, frames, bins, direction, layout) through
+    whatever launch path the planner picks (generic / shape-specialised / several-waves-per-group / multi-round),
+    each against the oracle; plus the explicit single-geometry variant, which must agree bit for bit."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    rng = np.random.RandomState(20260927)
+    for it in range(40):
+        H = int(rng.choice([16, 32, 64, 128, 256]))
+        bidir = bool(rng.randint(2))
+        mode = "full" if rng.randint(2) else "narrow"
+        c0 = int(rng.choice([0, 4, 16, 64, 128, 256])) if H >= 64 else int(rng.choice([4, 16, 32]))
+        c2 = int(rng.choice([0, 4, 16])) if c0 else int(rng.choice([4, 16]))
+        nb, nt, nf = int(rng.randint(1, 4)), int(rng.randint(1, 10)), int(rng.randint(1, 45))
+        I = c0 + c2
+        sd = lstm_state(I, H, bidir, 5000 + it)
+        x = rs_randn(5100 + it, (nb, nt, nf, I), 0.8)
+        seq = x.reshape(nb * nt, nf, I) if mode == "full" else np.transpose(x, (0, 2, 1, 3)).reshape(nb * nf, nt, I)
+        want = O.lstm(seq, sd, "L.", bidir)
+        want = want.reshape(nb, nt, nf, -1) if mode == "full" else np.transpose(want.reshape(nb, nf, nt, -1), (0, 2, 1, 3))
+        w = packed_dirs(sd, c0, c2, bidir, dev)
+        xd = to_dev(x, dev)
+        x0 = xd[..., :c0].contiguous() if c0 else None
+        x2 = xd[..., c0:].contiguous() if c2 else None
+        ndir = 2 if bidir else 1
+        outs = []
+        for variant in (0, 2):
+            if mode == "narrow":       # natural narrow-band storage
+                out = torch.full((nb, nf, nt, ndir * H), float("nan"), device=dev).permute(0, 2, 1, 3)
+            else:
+                out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+            ops.lstm_layer(mode, x0, None, x2, w, H, out, variant)
+            outs.append(out)
+        tag = (it, mode, H, bidir, c0, c2, nb, nt, nf)
+        assert_close(outs[0].cpu().numpy(), want, RTOL, ATOL, "random shape %s" % (tag,))
+        assert torch.equal(outs[0], outs[1]), tag

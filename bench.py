@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--ch-mode", default="MM")
     ap.add_argument("--chunk-pairs", type=int, default=0)
     ap.add_argument("--offline", action="store_true", help="is_online=False (bidirectional narrow-band LSTM)")
+    ap.add_argument("--bf16", action="store_true",
+                    help="NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, fp32 "
+                         "accumulate/tensors); reported with dtype 'bf16' and its measured deviation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample")
@@ -97,6 +100,8 @@ def main():
     model.arch.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.arch.chunk_pairs = args.chunk_pairs
     model = model.to(dev).eval()
+    if args.bf16:
+        model.arch.bfloat16()          # optional fast mode, see --bf16
 
     ns = 512 + (args.frames - 1) * 256
     gen = torch.Generator(device=dev)
@@ -145,7 +150,13 @@ def main():
         with open(tpath) as f:
             traffic = json.load(f).get("bytes_per_launch")
     dom = kern.get("lstm_h256") if online else None
-    if dom and dom["ms"] > 0:
+    if dom and dom["ms"] > 0 and args.bf16:
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
+                "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+                "traffic": None, "launches": dom["count"], "avg_ms": round(dom["ms"] / max(1, dom["count"]), 3),
+                "flop_per_launch": dom["flops"] / max(1, dom["count"])}
+    elif dom and dom["ms"] > 0:
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "lstm_rec_kernel<H=256> (narrow-band LSTM)",
                 "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -186,16 +197,18 @@ def main():
         # ... except through the full-band BiLSTM, which runs along frequency only: exact prefix)
         got = model.predict_step(batch[:args.cpu_utts, :, :cns], 0).cpu()
         err = (got - ref_out).abs()
-        parity = {"max_abs_err": float(err.max()), "rtol": 1e-4, "atol": 1e-5, "frames": cpu_frames,
-                  "ok": bool((err <= 1e-5 + 1e-4 * ref_out.abs()).all())}
+        rt, at = (2e-2, 4e-3) if args.bf16 else (1e-4, 1e-5)
+        parity = {"max_abs_err": float(err.max()), "rtol": rt, "atol": at, "frames": cpu_frames,
+                  "ok": bool((err <= at + rt * ref_out.abs()).all())}
         log("parity vs CPU reference: max abs err %.3g ok=%s" % (parity["max_abs_err"], parity["ok"]))
 
     if rank == 0:
         line = {
-            "metric": "TF-frames/sec DP-IPD forward, 4-mic 257-bin x 300-frame",
+            "metric": "TF-frames/sec DP-IPD forward, 4-mic 257-bin x 300-frame" +
+                      (" [optional bf16 fast mode: NOT the BASELINE fp32 metric]" if args.bf16 else ""),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: FN-SSL (%s) DP-IPD forward," % ("online" if online else "offline") + " waveform->STFT->features->"
                                    "3x(full-band BiLSTM + narrow-band LSTM)->head; %d utterances/GPU x %d mics "
                                    "('%s' = %d pairs) x 257 bins x %d frames, fp32; frame = one STFT frame of one "

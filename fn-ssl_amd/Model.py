@@ -41,6 +41,11 @@ def _param_key(module: nn.Module):
     return tuple((p.data_ptr(), p._version, str(p.device)) for p in module.parameters())
 
 
+def _is_bf16(module: nn.Module) -> bool:
+    """True after ``module.bfloat16()``: bf16 parameters select the bf16-MFMA kernels (fp32 accumulate / tensors)."""
+    return next(module.parameters()).dtype == torch.bfloat16
+
+
 def _require_eval(m: nn.Module):
     if m.training:
         raise RuntimeError("%s: this is the forward-only MI355X path — call .eval() first "
@@ -80,8 +85,18 @@ class FNblock(nn.Module):
         key = (_param_key(self), str(device))
         if self._packed is None or self._packed_key != key:
             fh2 = 2 * self.full_hidden_size
-            full = _lstm_streams(self.fullLstm, self.input_size, 0, device)
-            narr = _lstm_streams(self.narrLstm, fh2, self.input_size if self.is_first else 0, device)
+            if _is_bf16(self):
+                # bf16-MFMA streams; the 4 data channels of block 1 are zero-padded to one 16-channel block
+                cp = (self.input_size + 15) // 16 * 16
+                if self.is_first:
+                    full = _lstm_streams(self.fullLstm, cp, 0, device, True, cp)
+                    narr = _lstm_streams(self.narrLstm, fh2, cp, device, True, fh2 + cp)
+                else:
+                    full = _lstm_streams(self.fullLstm, self.input_size, 0, device, True)
+                    narr = _lstm_streams(self.narrLstm, fh2, 0, device, True)
+            else:
+                full = _lstm_streams(self.fullLstm, self.input_size, 0, device)
+                narr = _lstm_streams(self.narrLstm, fh2, self.input_size if self.is_first else 0, device)
             self._packed, self._packed_key = (full, narr), key
         return self._packed
 
@@ -93,6 +108,8 @@ class FNblock(nn.Module):
         narrow-band output, exactly like the reference's (Model.py:49).
         """
         _require_eval(self)
+        if _is_bf16(self):
+            raise RuntimeError("FNblock.forward: the bf16 path runs through FN_SSL.forward (blocks are fused there)")
         nb, nt, nf, nc = x.shape
         full_w, narr_w = self._streams(x.device)
         fh2 = 2 * self.full_hidden_size
@@ -144,14 +161,53 @@ class FN_SSL(nn.Module):
     def forward_seq(self, x0):
         """x0 [nb', nt, nf, input_size] (the layout the front-end kernels emit) -> DP-IPD."""
         _require_eval(self)
+        if _is_bf16(self):
+            return self._forward_seq_bf16(x0.float()).to(x0.dtype)
         return self.device_net(x0.device).forward(x0, self.chunk_pairs)
+
+    def _forward_seq_bf16(self, x0):
+        """Fast mode after ``.bfloat16()``: the six LSTM products run on bf16 MFMAs (weights and [x | h] operands
+        rounded to bf16, fp32 accumulation); residual adds, head and every tensor in HBM stay fp32.  NOT the
+        reference's arithmetic — see DESIGN.md §9 for the measured deviation."""
+        from fnssl import train as _train                       # combine(): fused element-wise sums
+        nbp = x0.shape[0]
+        cp = self.chunk_pairs if self.chunk_pairs > 0 else nbp
+        outs = []
+        for b0 in range(0, nbp, cp):
+            x = x0[b0:b0 + cp]
+            nb, nt, nf, c = x.shape
+            dev = x.device
+            xs = torch.cat((x, x.new_zeros((nb, nt, nf, (c + 15) // 16 * 16 - c))), dim=-1) if c % 16 else x
+            cur, fb_prev = None, None
+            for blk in (self.block_1, self.block_2, self.block_3):
+                full_w, narr_w = blk._streams(dev)
+                f = torch.empty((nb, nt, nf, 2 * blk.full_hidden_size), dtype=torch.float32, device=dev)
+                nh = blk.narr_hidden_size * (1 if blk.is_online else 2)
+                n = torch.empty((nb, nf, nt, nh), dtype=torch.float32, device=dev).permute(0, 2, 1, 3)
+                if blk.is_first:
+                    ops.lstm_layer("full", xs, None, None, full_w, blk.full_hidden_size, f, bf16=True)
+                    ops.lstm_layer("narrow", f, None, xs, narr_w, blk.narr_hidden_size, n, bf16=True)     # cat :42-43
+                else:
+                    u = torch.empty_like(f)
+                    _train.combine(u, plain=(cur, fb_prev))                                       # x + fb_skip :36-37
+                    ops.lstm_layer("full", u, None, None, full_w, blk.full_hidden_size, f, bf16=True)
+                    v = torch.empty((nb, nf, nt, f.shape[3]), dtype=torch.float32, device=dev).permute(0, 2, 1, 3)
+                    _train.combine(v, plain=(f, cur))                                             # + nb_skip :44-45
+                    ops.lstm_layer("narrow", v, None, None, narr_w, blk.narr_hidden_size, n, bf16=True)
+                cur, fb_prev = n, f
+            y = ops.head(cur.permute(0, 2, 1, 3), self.emb2ipd.weight.detach().float(), self.emb2ipd.bias.detach().float())
+            if self.is_doa:
+                y = ops.linear(y.reshape(-1, y.shape[-1]), self.ipd2doa.weight.detach().float().t().contiguous(),
+                               self.ipd2doa.bias.detach().float()).reshape(nb, y.shape[1], -1)
+            outs.append(y)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
     def forward(self, x):
         """x [nb', input_size, nf, nt] -> [nb', nt//12, 2*nf]  (or [.., 180] with is_doa)."""
         _require_eval(self)
         if x.ndim != 4 or x.shape[1] != self.input_size:
             raise RuntimeError("FN_SSL: expected [nb, %d, nf, nt], got %s" % (self.input_size, tuple(x.shape)))
-        return self.forward_seq(ops.nchw_to_seq(x))               # permute(0,3,2,1), Model.py:73
+        return self.forward_seq(ops.nchw_to_seq(x.float())).to(x.dtype)   # permute(0,3,2,1), Model.py:73
 
 
     def forward_stream(self, x, state=None):

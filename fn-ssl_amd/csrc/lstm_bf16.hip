@@ -18,6 +18,11 @@ int launch_bf16(const LstmParams& p, int H, int NW, int nwg, hipStream_t st) {
   TRYB(128, 8, 4, 16, 1, 7, 0)
   TRYB(128, 4, 12, 1, 0, 6, 0)
   TRYB(128, 8, 4, 1, 0, 6, 0)
+  // FN-SSL (no concatenated segment in blocks 2 / 3; block 1 uses the [256 | 16] and 16-channel shapes above with the
+  // 4 input channels zero-padded): narrow-band 256 <- 256, full-band / offline narrow-band 128 <- 256
+  TRYB(256, 4, 12, 16, 0, 9, 1)
+  TRYB(128, 4, 12, 16, 0, 7, 1)
+  TRYB(128, 8, 4, 16, 0, 7, 1)
   // IPDnet, hidden 128 (two microphones, input zero-padded to 16 channels): 128 <- [128 | 16], 64 <- [128 | 16], 64 <- 16
   TRYB(128, 4, 12, 8, 1, 10, 0)
   TRYB(128, 8, 4, 8, 1, 5, 0)

@@ -231,7 +231,7 @@ def lstm(x: np.ndarray, sd: dict, prefix: str, bidirectional: bool, bf16: bool =
 
 
 def fnblock_forward(sd: dict, prefix: str, x: np.ndarray, fb_skip=None, *,
-                    is_first: bool, is_online: bool):
+                    is_first: bool, is_online: bool, bf16: bool = False):
     """FNblock.forward in eval mode, FN-SSL/Model.py:31-50.
 
     x [nb, nt, nf, C] -> (x_out [nb, nt, nf, Hn], fb_skip [nb*nt, nf, 2*Hf],
@@ -243,14 +243,14 @@ def fnblock_forward(sd: dict, prefix: str, x: np.ndarray, fb_skip=None, *,
     xf = x.reshape(nb * nt, nf, -1)                                           # :35
     if not is_first:
         xf = (xf + fb_skip).astype(F32)                                       # :36-37
-    f = lstm(xf, sd, prefix + "fullLstm.", True)                              # :38
+    f = lstm(xf, sd, prefix + "fullLstm.", True, bf16)                        # :38
     fb_out = f                                                                # :39
     v = np.transpose(f.reshape(nb, nt, nf, -1), (0, 2, 1, 3)).reshape(nb * nf, nt, -1)  # :41
     if is_first:
         v = np.concatenate([v, nb_skip], axis=-1)                             # :42-43
     else:
         v = (v + nb_skip).astype(F32)                                         # :44-45
-    n = lstm(v, sd, prefix + "narrLstm.", not is_online)                      # :46
+    n = lstm(v, sd, prefix + "narrLstm.", not is_online, bf16)                # :46
     nb_out = n                                                                # :47
     xo = np.transpose(n.reshape(nb, nf, nt, -1), (0, 2, 1, 3))                # :49
     return np.ascontiguousarray(xo), fb_out, nb_out
@@ -271,12 +271,18 @@ def head_forward(sd: dict, x: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate([ipd[..., 0], ipd[..., 1]], axis=2))
 
 
-def fnssl_forward(sd: dict, x: np.ndarray, is_online: bool = True, is_doa: bool = False) -> np.ndarray:
-    """FN_SSL.forward, FN-SSL/Model.py:72-90.  x [nb', 4, nf, nt] -> [nb', nt//12, 2nf]."""
+def fnssl_forward(sd: dict, x: np.ndarray, is_online: bool = True, is_doa: bool = False,
+                  bf16: bool = False) -> np.ndarray:
+    """FN_SSL.forward, FN-SSL/Model.py:72-90.  x [nb', 4, nf, nt] -> [nb', nt//12, 2nf].
+    bf16=True: the module after .bfloat16() — bf16 parameters and input, LSTM products on bf16 operands
+    (fp32 accumulate, residual adds, head and tensors in fp32)."""
+    if bf16:
+        sd = {k: bf16_round(v) for k, v in sd.items()}
+        x = bf16_round(x)
     x = np.transpose(np.asarray(x, dtype=F32), (0, 3, 2, 1))                  # :73
-    x, fb, _ = fnblock_forward(sd, "block_1.", x, is_first=True, is_online=is_online)
-    x, fb, _ = fnblock_forward(sd, "block_2.", x, fb, is_first=False, is_online=is_online)
-    x, fb, _ = fnblock_forward(sd, "block_3.", x, fb, is_first=False, is_online=is_online)
+    x, fb, _ = fnblock_forward(sd, "block_1.", x, is_first=True, is_online=is_online, bf16=bf16)
+    x, fb, _ = fnblock_forward(sd, "block_2.", x, fb, is_first=False, is_online=is_online, bf16=bf16)
+    x, fb, _ = fnblock_forward(sd, "block_3.", x, fb, is_first=False, is_online=is_online, bf16=bf16)
     res = head_forward(sd, x)
     if is_doa:
         res = (res @ sd["ipd2doa.weight"].T.astype(F32) + sd["ipd2doa.bias"]).astype(F32)  # :88-89

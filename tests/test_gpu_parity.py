@@ -737,15 +737,15 @@ def test_lstm_bf16_layer_matches_bf16_oracle(dev, mode, H, bidir, c0, c2, nb, nt
 
 def test_lstm_bf16_rejects_unbuilt_shapes(dev):
     from fnssl import ops
-    sd = lstm_state(256, 256, False, 4200)
-    w = [ops.pack_lstm_bf16(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], 256, 0, dev)]
-    x = torch.zeros((1, 4, 16, 256), device=dev)
+    sd = lstm_state(128, 256, False, 4200)
+    w = [ops.pack_lstm_bf16(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], 128, 0, dev)]
+    x = torch.zeros((1, 4, 16, 128), device=dev)
     out = torch.zeros((1, 4, 16, 256), device=dev)
     with pytest.raises(RuntimeError, match="bf16 path is not built"):
         ops.lstm_layer("narrow", x, None, None, w, 256, out, bf16=True)
     with pytest.raises(RuntimeError, match="unsupported sizes"):
-        ops.pack_lstm_bf16(np.zeros((1024, 260), np.float32), sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"],
-                           256, 4, dev)
+        ops.pack_lstm_bf16(np.zeros((1024, 132), np.float32), sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"],
+                           128, 4, dev)
 
 
 @pytest.mark.parametrize("isz,hid,online,shape", [(16, 256, True, (1, 16, 32, 24)), (4, 128, True, (2, 4, 16, 24)),
@@ -831,3 +831,28 @@ def test_lstm_random_shapes_all_launch_paths(dev):
         tag = (it, mode, H, bidir, c0, c2, nb, nt, nf)
         assert_close(outs[0].cpu().numpy(), want, RTOL, ATOL, "random shape %s" % (tag,))
         assert torch.equal(outs[0], outs[1]), tag
+
+
+@pytest.mark.parametrize("online", [True, False])
+def test_fnssl_bf16_fast_mode(dev, online):
+    """FN_SSL after .bfloat16(): bf16 MFMA operands in the six LSTMs, everything else fp32 — against the
+    bf16-emulating oracle (tight) and the fp32 oracle (the deviation a user of the fast mode gets)."""
+    import Model
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    sd = W.make_fnssl_state(4500, is_online=online)
+    net = Model.FN_SSL(is_online=online).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev).bfloat16()
+    x = rs_randn(4501, (2, 4, 24, 36))
+    y = net(to_dev(x, dev).bfloat16())
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (2, 3, 48)
+    want_bf = O.fnssl_forward(sd, x, online, bf16=True)
+    want_32 = O.fnssl_forward(sd, x, online)
+    got = y.float().cpu().numpy()
+    assert np.abs(got - want_bf).max() <= BF_ATOL + 4e-3 * np.abs(want_bf).max()
+    assert_close(got, want_32, 2e-2, 4e-3, "bf16 fast mode vs fp32 oracle")
+    y32 = net(to_dev(O.bf16_round(x), dev))                      # fp32 in, fp32 out
+    assert y32.dtype == torch.float32 and np.abs(y32.cpu().numpy() - want_bf).max() <= BF_ATOL
+    with pytest.raises(RuntimeError, match="FN_SSL.forward"):
+        net.block_1(to_dev(rs_randn(1, (1, 2, 3, 4)), dev))

@@ -26,6 +26,9 @@ struct TimedLaunch {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the current device (256 on MI355X); the launch planners size their rounds with it.
+int device_cus();
+
 }  // namespace fnssl
 
 #define FNSSL_REQUIRE(cond, ...)            \

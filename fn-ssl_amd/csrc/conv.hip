@@ -423,11 +423,7 @@ static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, lo
                         : (NT == 8 ? quads_per_pass_host<8>(ca, cb) : quads_per_pass_host<4>(ca, cb));
   Variant vr{NW, M, 1};
   choose_chunk(p.quads_per_pass, vr, p.chq, p.pad);
-  static const int ncu = [] {
-    int dev = 0, nn = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&nn, hipDeviceAttributeMultiprocessorCount, dev);
-    return nn > 0 ? nn : 256;
-  }();
+  const int ncu = fnssl::device_cus();
   const int groups = (p.ntiles + NW - 1) / NW;
   const int nwg = groups < ncu ? groups : ncu;
   p.passes = (groups + nwg - 1) / nwg;

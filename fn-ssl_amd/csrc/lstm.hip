@@ -240,11 +240,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   }
   if (const int forced = default_variant_override(H)) return launch_range(forced, 0, tasks);
 
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  const int ncu = fnssl::device_cus();
   // ---- few sequences (a single utterance, a streaming chunk): several waves per 16-sequence group ------
   auto launch_split = [&](int split, int t0, int t1) -> int {
     const int nw = split == 4 ? 8 : 4, groups_per_wg = nw / split;

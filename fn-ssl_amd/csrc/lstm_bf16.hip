@@ -42,11 +42,7 @@ static unsigned short to_bf16(float f) {   // round to nearest even
 
 // Launch plan of the bf16 path: 4 or 8 waves per workgroup, rounds of 8 waves per CU.
 int forward_bf16(LstmParams p, int H, hipStream_t st) {
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  const int ncu = fnssl::device_cus();
   const int tasks = p.ntasks;
   const long long total = (long long)tasks * p.ndir;
   const int W = (int)((total + ncu - 1) / ncu);

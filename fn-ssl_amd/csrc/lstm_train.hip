@@ -10,14 +10,7 @@ using namespace fnssl_lstm;
 
 namespace fnssl_lstm {
 
-static int device_cus() {
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  return ncu;
-}
+using fnssl::device_cus;
 
 struct Geometry {
   int nw, split, t0, t1;

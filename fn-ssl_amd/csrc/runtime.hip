@@ -9,6 +9,16 @@
 
 namespace fnssl {
 
+int device_cus() {
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return ncu;
+}
+
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {

@@ -5,6 +5,7 @@
 #include "common.h"
 
 #include "lstm_train.h"
+#include "lstm_split_static.h"
 
 using namespace fnssl_lstm;
 
@@ -70,6 +71,10 @@ int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
     p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
     const Variant vr{gm.nw, (gm.split > 1 && gm.nw == 8) ? 8 : 4, 1};   // staging registers as in launch_save_m
     const int nwg = p.wgs_per_dir * p.ndir;
+    if (gm.split > 1 && !env_int("FNSSL_TRAIN_NO_STATIC", 1, 1)) {   // shape-specialised kernels first
+      const int rc = launch_split_static(p, H, gm.nw, gm.split, mode | kSave, lds_chunk_cap(nwg, gm.split), nwg, st);
+      if (rc != kNoStatic) return rc;
+    }
     choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, gm.split, gm.split > 1 ? lds_chunk_cap(nwg, gm.split) : 0);
     return H == 128 ? launch_save<128>(gm.nw, gm.split, p, mode | kSave, nwg, st)
                     : launch_save<256>(gm.nw, gm.split, p, mode | kSave, nwg, st);

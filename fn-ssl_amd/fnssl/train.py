@@ -170,7 +170,7 @@ class TrainEngine:
         self.layers = []
         for k in (1, 2, 3):
             first = k == 1
-            self.layers.append(_Layer("block_%d.fullLstm" % k, "full", H_FULL, 2, 0 if first else CH, 4 if first else 0,
+            self.layers.append(_Layer("block_%d.fullLstm" % k, "full", H_FULL, 2, 4 if first else CH, 0,
                                       0 if first else CH))
             self.layers.append(_Layer("block_%d.narrLstm" % k, "narrow", nh, nd, CH, 4 if first else 0, CH))
         self._build_index_maps()
@@ -282,7 +282,7 @@ class TrainEngine:
             F[k] = self._natural("F%d" % k, lf, nbp, nt, nf, 2 * H_FULL)
             res[lf.name] = self._buf("R" + lf.name, (ops.lstm_reserve_floats(nbp * nt, lf.hidden, 2, nf),))
             if k == 1:
-                ops.lstm_layer("full", None, None, XF, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+                ops.lstm_layer("full", XF, None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
             else:
                 U[k] = self._natural("U%d" % k, lf, nbp, nt, nf, CH)
                 combine(U[k], plain=(Xk, F[k - 1]))                                   # x + fb_skip  (:36-37)
@@ -341,7 +341,7 @@ class TrainEngine:
                 dfb = du                     # dL/dF_{k-1} through fb_skip
             else:
                 ops.lstm_backward("full", res[lf.name], DF, dA, None, bw[lf.name], lf.hidden, 0)
-                self._weight_grads(lf, dA, None, XF, F[k])
+                self._weight_grads(lf, dA, XF, None, F[k])
         return pred
 
     # ------------------------------------------------------------------ public API

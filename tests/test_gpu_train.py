@@ -227,3 +227,41 @@ def test_mymodel_training_step_dropin(dev):
         m.training_step((sig, {"ipd": gt}), 0)
     assert float(m.cal_loss(m.predict_step(sig.permute(0, 2, 1)), {"ipd": gt})) < float(l0)
     assert m.configure_optimizers() is None
+
+
+@pytest.mark.parametrize("mode,H,bidir,c0,c2,nb,nt,nf", [
+    ("narrow", 256, False, 256, 0, 2, 3, 4096),      # 512 groups -> 4 waves per group, 8-wave workgroups
+    ("narrow", 256, False, 256, 4, 2, 3, 4096),
+    ("narrow", 256, False, 256, 0, 2, 3, 8192),      # 1024 groups -> 2 waves per group, 4-wave workgroups
+    ("full", 128, True, 256, 0, 1, 9600, 3),         # config-4 full-band geometry: 600 groups x 2 directions
+    ("full", 128, True, 4, 0, 1, 9600, 3),
+])
+def test_split_static_training_forward_equals_generic(dev, mode, H, bidir, c0, c2, nb, nt, nf):
+    """The shape-specialised split kernels of the training forward write the same h AND the same reserve as the
+    generic kernels, bit for bit (env FNSSL_TRAIN_NO_STATIC switches them off)."""
+    import os
+    from fnssl import ops
+    from fnssl import weights as W
+    ndir = 2 if bidir else 1
+    I = c0 + c2
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(I, H, bidir)], seed=970 + c0 + c2)
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s],
+                            sd["L.bias_hh_l0" + s], c0, c2, dev) for s in ([""] + (["_reverse"] if bidir else []))]
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.randn((nb, nt, nf, I), generator=g, device=dev) * 0.7
+    x0, x2 = x[..., :c0].contiguous(), (x[..., c0:].contiguous() if c2 else None)
+    nseq, nsteps = (nb * nt, nf) if mode == "full" else (nb * nf, nt)
+    res = []
+    for no_static in ("0", "1"):
+        os.environ["FNSSL_TRAIN_NO_STATIC"] = no_static
+        try:
+            out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+            reserve = torch.full((ops.lstm_reserve_floats(nseq, H, ndir, nsteps),), float("nan"), device=dev)
+            ops.lstm_layer(mode, x0, None, x2, packed, H, out, reserve=reserve)
+            res.append((out, reserve))
+        finally:
+            os.environ.pop("FNSSL_TRAIN_NO_STATIC", None)
+    assert not torch.isnan(res[0][0]).any()
+    assert torch.equal(res[0][0], res[1][0]), "h"
+    assert torch.equal(torch.nan_to_num(res[0][1], nan=-7.0), torch.nan_to_num(res[1][1], nan=-7.0)), "reserve"

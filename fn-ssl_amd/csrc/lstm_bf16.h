@@ -159,7 +159,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_bf16_kernel(const LstmParams p) 
 #pragma unroll
   for (int i = 0; i < NHP; ++i) hcur[i] = pack_bf16(zero4, zero4);
   request_x(rev ? p.nsteps - 1 : 0);
-  v4f creg[NS];   // the cell state lives in registers too
+  // The cell state lives in registers too.  (A variant that kept it in the lane-private scratch, like the fp32
+  // kernels, read back wrong values in lanes 12-15 of even slices on ROCm 7.2 / gfx950 — addresses that
+  // coincide with h-store offsets, i.e. a buffer-descriptor mix-up at the 106-SGPR limit, independent of
+  // waitcnts and cache policy; registers are faster anyway.)
+  v4f creg[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) creg[i] = zero4;
 

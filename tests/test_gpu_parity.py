@@ -856,3 +856,32 @@ def test_fnssl_bf16_fast_mode(dev, online):
     assert y32.dtype == torch.float32 and np.abs(y32.cpu().numpy() - want_bf).max() <= BF_ATOL
     with pytest.raises(RuntimeError, match="FN_SSL.forward"):
         net.block_1(to_dev(rs_randn(1, (1, 2, 3, 4)), dev))
+
+
+# --------------------------------------------------------------------------- size-independent properties
+def test_online_models_are_causal_bit_for_bit(dev):
+    """The online FN-SSL and IPDnet must not look ahead: the output for the first 36 frames is the same whether
+    or not 12 more frames follow (full-band layers only mix frequencies, narrow-band LSTMs and the conv head are
+    causal).  Checked bit for bit at the full 256-bin width, in fp32 and in the bf16 mode."""
+    import Model
+    from fnssl import weights as W
+    M = _ipdnet_module()
+    fn = Model.FN_SSL().eval()
+    fn.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_fnssl_state(5300).items()})
+    ipd = M.IPDnet(input_size=16, hidden_size=256, max_track=2, is_online=True).eval()
+    ipd.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_ipdnet_state(5301, 16, 256, 2, True).items()})
+    xf = to_dev(rs_randn(5302, (3, 4, 256, 48)), dev)
+    xi = to_dev(rs_randn(5303, (2, 16, 256, 48)), dev)
+    for net, x in ((fn, xf), (ipd, xi)):
+        net.to(dev)
+        for bf in (False, True):
+            if bf:
+                net.bfloat16()
+            whole = net(x)
+            prefix = net(x[..., :36].contiguous())
+            assert torch.equal(whole[:, :3], prefix), (type(net).__name__, bf)
+    # the offline FN-SSL is NOT causal (bi-directional narrow-band LSTM): the same check must fail there
+    off = Model.FN_SSL(is_online=False).eval()
+    off.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_fnssl_state(5304, is_online=False).items()})
+    off.to(dev)
+    assert not torch.equal(off(xf)[:, :3], off(xf[..., :36].contiguous()))

@@ -262,3 +262,71 @@ class IPDnet(nn.Module):
             c = c.reshape(nb // nseg, nt2 * nseg, 2, nf * 2, -1).permute(0, 1, 3, 4, 2)
             return c[:, :ou_frame, :, :, :].to(in_dtype)
         return c.reshape(nb, nt2, 2, nf * 2, -1).permute(0, 1, 3, 4, 2).to(in_dtype)
+
+    def forward_stream(self, x, state=None):
+        """Streaming inference of the online model (the state carry SURVEY.md §8f rank 3 asks for; the reference's
+        causality permits it but it has no such entry): x [nb, 2*nch, nf, T] = the NEXT T frames (T a positive
+        multiple of 12), ``state`` = None for the first chunk, then what the previous call returned.  Returns
+        (IPD [nb, T//12, 2*nf, nch-1, max_track], state).  Consecutive chunks reproduce ``forward`` on the whole
+        signal bit for bit: the narrow-band LSTMs continue from their carried (h, c), every causal conv sees the
+        last two frames of its previous input, and the 3 / 4-frame poolings stay aligned because T % 12 == 0."""
+        _require_eval(self)
+        if not self.is_online or _is_bf16(self):
+            raise RuntimeError("IPDnet.forward_stream: online fp32 model only")
+        if x.ndim != 4 or x.shape[1] != self.input_size or x.shape[3] == 0 or x.shape[3] % 12:
+            raise RuntimeError("IPDnet.forward_stream: expected [nb, %d, nf, T] with T a positive multiple of 12, got %s"
+                               % (self.input_size, tuple(x.shape)))
+        x = x.float()
+        nb, nc, nf, T = x.shape
+        dev = x.device
+        blocks = (self.block_1, self.block_2)
+        hid = self.conv.cnn_hidden_dim
+        if state is None:
+            state = {"ws": [ops.lstm_state_workspace(nb * nf, b.narr_hidden_size, dev) for b in blocks],
+                     "n_tail": [torch.zeros((nb, nf, 2, b.narr_hidden_size), device=dev) for b in blocks],
+                     "x_tail": torch.zeros((nb, 2, nf, nc), device=dev),
+                     "p_tail": [torch.zeros((nb, nf, 2, hid), device=dev) for _ in range(2)],
+                     "shape": (nb, nf), "frames": 0}
+        elif state["shape"] != (nb, nf):
+            raise RuntimeError("IPDnet.forward_stream: batch / bins changed between chunks")
+        started = state["frames"] > 0
+        xbuf = torch.empty((nb, T + 2, nf, nc), dtype=torch.float32, device=dev)
+        xbuf[:, :2].copy_(state["x_tail"])
+        xbuf[:, 2:].copy_(ops.nchw_to_seq(x))                      # [nb, T, nf, C] behind the 2 carried frames
+        xs = xbuf[:, 2:]
+        cur = None
+        for k, blk in enumerate(blocks):
+            full_w, narr_w = blk._streams(dev)
+            f = torch.empty((nb, T, nf, 2 * blk.full_hidden_size), dtype=torch.float32, device=dev)
+            if blk.is_first:
+                if _split16(blk.input_size)[0]:
+                    ops.lstm_layer("full", xs, None, None, full_w, blk.full_hidden_size, f)
+                else:
+                    ops.lstm_layer("full", None, None, xs, full_w, blk.full_hidden_size, f)
+            else:
+                ops.lstm_layer("full", cur, None, xs, full_w, blk.full_hidden_size, f)
+            nbuf = torch.empty((nb, nf, T + 2, blk.narr_hidden_size), dtype=torch.float32, device=dev)
+            nbuf[:, :, :2].copy_(state["n_tail"][k])               # the last two output frames of the previous chunk
+            out = nbuf[:, :, 2:].permute(0, 2, 1, 3)
+            ops.lstm_layer("narrow", f, None, xs, narr_w, blk.narr_hidden_size, out,
+                           carry_workspace=state["ws"][k], carry=started)
+            state["n_tail"][k] = nbuf[:, :, T:].clone()
+            cur = out
+        state["x_tail"] = xbuf[:, T:].clone()
+        ca, cb = nbuf.shape[3], nc
+        w1, w2, w3 = self.conv._streams(dev, ca, cb)
+        y = ops.conv3x3_causal(nbuf, xbuf.permute(0, 2, 1, 3), w1, hid, "relu")[:, :, 2:]      # drop the carried frames
+        p1 = ops.avgpool_time(y, 3)
+        in2 = torch.cat((state["p_tail"][0], p1), dim=2)
+        y = ops.conv3x3_causal(in2, None, w2, hid, "relu")[:, :, 2:]
+        state["p_tail"][0] = in2[:, :, -2:].clone()
+        p2 = ops.avgpool_time(y, 4)
+        in3 = torch.cat((state["p_tail"][1], p2), dim=2)           # a 12-frame chunk adds ONE frame here
+        c = ops.conv3x3_causal(in3, None, w3, self.cnn_out_dim, "tanh")[:, :, 2:]
+        state["p_tail"][1] = in3[:, :, -2:].clone()
+        state["frames"] += T
+        nt2 = T // 12
+        c = c[..., :self.cnn_out_dim].permute(0, 2, 1, 3)
+        c = c.reshape(nb, nt2, nf, 2, -1).permute(0, 1, 3, 2, 4)
+        return c.reshape(nb, nt2, 2, nf * 2, -1).permute(0, 1, 3, 4, 2), state
+

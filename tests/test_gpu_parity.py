@@ -885,3 +885,26 @@ def test_online_models_are_causal_bit_for_bit(dev):
     off.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_fnssl_state(5304, is_online=False).items()})
     off.to(dev)
     assert not torch.equal(off(xf)[:, :3], off(xf[..., :36].contiguous()))
+
+
+@pytest.mark.parametrize("isz,hid", [(16, 256), (4, 128)])
+def test_ipdnet_forward_stream_equals_whole_signal(dev, isz, hid):
+    from fnssl import weights as W
+    M = _ipdnet_module()
+    sd = W.make_ipdnet_state(5400 + isz, isz, hid, 2, True)
+    net = M.IPDnet(input_size=isz, hidden_size=hid, max_track=2, is_online=True).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev)
+    x = to_dev(rs_randn(5401, (2, isz, 20, 72)), dev)
+    whole = net(x)
+    outs, state = [], None
+    for lo, hi in ((0, 12), (12, 48), (48, 60), (60, 72)):
+        y, state = net.forward_stream(x[..., lo:hi].contiguous(), state)
+        outs.append(y)
+    assert state["frames"] == 72
+    assert torch.equal(torch.cat(outs, dim=1), whole)
+    with pytest.raises(RuntimeError, match="multiple of 12"):
+        net.forward_stream(x[..., :10].contiguous())
+    off = M.IPDnet(input_size=isz, hidden_size=hid, is_online=False).eval().to(dev)
+    with pytest.raises(RuntimeError, match="online"):
+        off.forward_stream(x[..., :12].contiguous())

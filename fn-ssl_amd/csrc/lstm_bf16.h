@@ -102,16 +102,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bf16_kernel(const LstmParams p) 
   auto rec = [&](auto ql, int j) {
     return *reinterpret_cast<const v4f*>(cb + decltype(ql)::value * 4096 + j * 1024);
   };
-  v4f a0 = rec(ic<0>{}, 0), a1 = rec(ic<0>{}, 1);
+  // A operands: the four records of a quad are requested one whole quad ahead (the four MFMAs of a quad take
+  // only ~70 cycles, less than an LDS round trip, so a half-quad lookahead as in the fp32 kernels stalls on
+  // every quad); an[0..3] always hold the NEXT quad to be consumed.
+  v4f an0 = rec(ic<0>{}, 0), an1 = rec(ic<0>{}, 1), an2 = rec(ic<0>{}, 2), an3 = rec(ic<0>{}, 3);
   v4f acc[4];
-  auto ring_step = [&](auto qi_c) {
-    constexpr int QL = decltype(qi_c)::value % CHQ;
-    if constexpr (QL + 1 < CHQ) {
-      a0 = rec(ic<QL + 1>{}, 0);
-      a1 = rec(ic<QL + 1>{}, 1);
-    }
-  };
-  auto ring_end = [&](auto qi_c) {
+  // after quad QI: request quad QI + 1 (same chunk), or commit / re-read at a chunk end
+  auto ring_next = [&](auto qi_c) {
     constexpr int QL = decltype(qi_c)::value % CHQ;
     if constexpr (QL + 1 == (CHQ + 1) / 2 && CHQ > 1) stage_write();
     if constexpr (QL + 1 == CHQ) {
@@ -120,8 +117,10 @@ __global__ void __launch_bounds__(NW * 64) lstm_bf16_kernel(const LstmParams p) 
       issue_loads();
       rslot ^= 1;
       cb = lds_rd + rslot * (CH * 1024);
-      a0 = rec(ic<0>{}, 0);
-      a1 = rec(ic<0>{}, 1);
+      an0 = rec(ic<0>{}, 0);
+      an1 = rec(ic<0>{}, 1);
+      an2 = rec(ic<0>{}, 2);
+      an3 = rec(ic<0>{}, 3);
     }
   };
 #define MFMA_BF(ACC, AV, BV) \
@@ -129,13 +128,18 @@ __global__ void __launch_bounds__(NW * 64) lstm_bf16_kernel(const LstmParams p) 
   // one quad: the four gate MFMAs of a 32-channel pair; B is the packed operand
 #define BQUAD(QI, BV)                                                              \
   do {                                                                             \
-    const v4f a2_ = rec(ic<(QI) % CHQ>{}, 2), a3_ = rec(ic<(QI) % CHQ>{}, 3);      \
-    MFMA_BF(acc[0], a0, BV);                                                       \
-    MFMA_BF(acc[1], a1, BV);                                                       \
-    ring_step(ic<(QI)>{});                                                         \
-    MFMA_BF(acc[2], a2_, BV);                                                      \
-    MFMA_BF(acc[3], a3_, BV);                                                      \
-    ring_end(ic<(QI)>{});                                                          \
+    const v4f c0_ = an0, c1_ = an1, c2_ = an2, c3_ = an3;                          \
+    if constexpr (((QI) % CHQ) + 1 < CHQ) {                                        \
+      an0 = rec(ic<((QI) % CHQ) + 1>{}, 0);                                        \
+      an1 = rec(ic<((QI) % CHQ) + 1>{}, 1);                                        \
+      an2 = rec(ic<((QI) % CHQ) + 1>{}, 2);                                        \
+      an3 = rec(ic<((QI) % CHQ) + 1>{}, 3);                                        \
+    }                                                                              \
+    MFMA_BF(acc[0], c0_, BV);                                                      \
+    MFMA_BF(acc[1], c1_, BV);                                                      \
+    MFMA_BF(acc[2], c2_, BV);                                                      \
+    MFMA_BF(acc[3], c3_, BV);                                                      \
+    ring_next(ic<(QI)>{});                                                         \
   } while (0)
 
   const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
@@ -177,17 +181,28 @@ __global__ void __launch_bounds__(NW * 64) lstm_bf16_kernel(const LstmParams p) 
     static_for<NS>([&](auto sc) {
       constexpr int S = decltype(sc)::value;
       const v4f cprev = creg[S];
-      acc[0] = a0;   // bias quad (fp32)
-      acc[1] = a1;
-      acc[2] = rec(ic<0>{}, 2);
-      acc[3] = rec(ic<0>{}, 3);
-      ring_step(ic<0>{});
-      ring_end(ic<0>{});
+      acc[0] = an0;   // bias quad (fp32)
+      acc[1] = an1;
+      acc[2] = an2;
+      acc[3] = an3;
+      if constexpr (1 < CHQ) {
+        an0 = rec(ic<1>{}, 0);
+        an1 = rec(ic<1>{}, 1);
+        an2 = rec(ic<1>{}, 2);
+        an3 = rec(ic<1>{}, 3);
+      }
+      ring_next(ic<0>{});
       static_for<NXP>([&](auto pi) { BQUAD(1 + decltype(pi)::value, xb[decltype(pi)::value]); });
       static_for<NHP>([&](auto hp) { BQUAD(1 + NXP + decltype(hp)::value, hcur[decltype(hp)::value]); });
       static_for<PAD>([&](auto u) {
-        ring_step(ic<QPS + decltype(u)::value>{});
-        ring_end(ic<QPS + decltype(u)::value>{});
+        constexpr int QP = QPS + decltype(u)::value;
+        if constexpr ((QP % CHQ) + 1 < CHQ) {
+          an0 = rec(ic<(QP % CHQ) + 1>{}, 0);
+          an1 = rec(ic<(QP % CHQ) + 1>{}, 1);
+          an2 = rec(ic<(QP % CHQ) + 1>{}, 2);
+          an3 = rec(ic<(QP % CHQ) + 1>{}, 3);
+        }
+        ring_next(ic<QP>{});
       });
       const v4f ig = sigmoid4(acc[0]);
       const v4f fg = sigmoid4(acc[1]);

@@ -43,7 +43,10 @@ inline int bwd_quads_per_slice(int H) { return 1 + (4 * H) / 16; }
 // SPLIT > 1: SPLIT waves share one 16-sequence group (see lstm_rec_kernel): each does its share of the hidden
 // slices in phase A and of the output slices in phase B; dA rows and the carried dh are exchanged through
 // memory with a workgroup barrier after each phase.
-template <int H, int NW, int M, int SPLIT = 1>
+// DIRECT (split launches): no LDS ring and no ring barriers — with few waves on the chip the L2 has bandwidth
+// to spare, so each wave streams its own share of the weight quads straight from L2 into a 4-quad-deep
+// register pipeline (16 records in flight); only the two per-step barriers of the split remain.
+template <int H, int NW, int M, int SPLIT = 1, bool DIRECT = false>
 __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
   constexpr int NS = H / 16;
   constexpr int NSL = NS / SPLIT;
@@ -81,10 +84,41 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
 
   WStream<NW, M, 1> ws;
   ws.nobar = false;
-  ws.init(p.wpack[dir], lane, w, p.quads_per_slice, nsol, p.chq, p.pad, smem, SPLIT, part);
-  v4f a0 = ws.record(0), a1 = ws.record(1);
+  v4f a0, a1;
+  if (!DIRECT) {
+    ws.init(p.wpack[dir], lane, w, p.quads_per_slice, nsol, p.chq, p.pad, smem, SPLIT, part);
+    a0 = ws.record(0);
+    a1 = ws.record(1);
+  }
   const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
   v4f acc[4];
+  // DIRECT: this wave's data quads (the zero "bias" quad of each output slice is skipped) form a cyclic
+  // sequence of nsol * NVB quads; ar[k] holds quad (cursor + k) of it
+  const rsrc_t rwd = make_rsrc(p.wpack[dir]);
+  const int dq_total = nsol * NVB;
+  int dq_next = 0;                       // next data quad to request
+  auto dq_load = [&](v4f* dst) {
+    const int sl = dq_next / NVB, qq = dq_next - sl * NVB;
+    const unsigned rec0 = (unsigned)(((part * nsol + sl) * p.quads_per_slice + 1 + qq) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = bld4(rwd, vlane, (rec0 + j) * 1024u);
+    dq_next = dq_next + 1 == dq_total ? 0 : dq_next + 1;
+  };
+  v4f ar0[4], ar1[4], ar2[4], ar3[4];
+  if (DIRECT) {
+    dq_load(ar0);
+    dq_load(ar1);
+    dq_load(ar2);
+    dq_load(ar3);
+  }
+#define DQUAD(AR, B0, B1, B2, B3) \
+  do {                            \
+    MFMA4(acc, AR[0], B0);        \
+    MFMA4(acc, AR[1], B1);        \
+    MFMA4(acc, AR[2], B2);        \
+    MFMA4(acc, AR[3], B3);        \
+    dq_load(AR);                  \
+  } while (0)
 
 #define QUAD(B0, B1, B2, B3)                          \
   do {                                                \
@@ -149,33 +183,49 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
         x3 = bld4(rda, vda, oa + 192);
     for (int sol = 0; sol < nsol; ++sol) {
       const int so = SPLIT > 1 ? part * nsol + sol : sol;
-      acc[0] = a0;   // "bias" quad of the stream: zeros
-      acc[1] = a1;
-      acc[2] = ws.record(2);
-      acc[3] = ws.record(3);
-      ws.peek_next(a0, a1);
-      if (ws.advance()) {
-        a0 = ws.record(0);
-        a1 = ws.record(1);
-      }
+      if (DIRECT) {
+        acc[0] = acc[1] = acc[2] = acc[3] = zero4;
 #pragma unroll 1
-      for (int v = 0; v < NVB; v += 4) {
-        // 4-deep operand ring; the blocks wrap around into the next output slice (same dA row)
-        const unsigned nx = oa + 64 * ((v + 4) & (NVB - 1));
-        QUAD(x0.x, x0.y, x0.z, x0.w);
-        x0 = bld4(rda, vda, nx);
-        QUAD(x1.x, x1.y, x1.z, x1.w);
-        x1 = bld4(rda, vda, nx + 64);
-        QUAD(x2.x, x2.y, x2.z, x2.w);
-        x2 = bld4(rda, vda, nx + 128);
-        QUAD(x3.x, x3.y, x3.z, x3.w);
-        x3 = bld4(rda, vda, nx + 192);
-      }
-      for (int u = 0; u < p.pad; ++u) {
+        for (int v = 0; v < NVB; v += 4) {
+          const unsigned nx = oa + 64 * ((v + 4) & (NVB - 1));
+          DQUAD(ar0, x0.x, x0.y, x0.z, x0.w);
+          x0 = bld4(rda, vda, nx);
+          DQUAD(ar1, x1.x, x1.y, x1.z, x1.w);
+          x1 = bld4(rda, vda, nx + 64);
+          DQUAD(ar2, x2.x, x2.y, x2.z, x2.w);
+          x2 = bld4(rda, vda, nx + 128);
+          DQUAD(ar3, x3.x, x3.y, x3.z, x3.w);
+          x3 = bld4(rda, vda, nx + 192);
+        }
+      } else {
+        acc[0] = a0;   // "bias" quad of the stream: zeros
+        acc[1] = a1;
+        acc[2] = ws.record(2);
+        acc[3] = ws.record(3);
         ws.peek_next(a0, a1);
         if (ws.advance()) {
           a0 = ws.record(0);
           a1 = ws.record(1);
+        }
+#pragma unroll 1
+        for (int v = 0; v < NVB; v += 4) {
+          // 4-deep operand ring; the blocks wrap around into the next output slice (same dA row)
+          const unsigned nx = oa + 64 * ((v + 4) & (NVB - 1));
+          QUAD(x0.x, x0.y, x0.z, x0.w);
+          x0 = bld4(rda, vda, nx);
+          QUAD(x1.x, x1.y, x1.z, x1.w);
+          x1 = bld4(rda, vda, nx + 64);
+          QUAD(x2.x, x2.y, x2.z, x2.w);
+          x2 = bld4(rda, vda, nx + 128);
+          QUAD(x3.x, x3.y, x3.z, x3.w);
+          x3 = bld4(rda, vda, nx + 192);
+        }
+        for (int u = 0; u < p.pad; ++u) {
+          ws.peek_next(a0, a1);
+          if (ws.advance()) {
+            a0 = ws.record(0);
+            a1 = ws.record(1);
+          }
         }
       }
 #pragma unroll
@@ -191,12 +241,13 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
     if (SPLIT > 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // carried dh visible to the group
   }
 #undef QUAD
+#undef DQUAD
 }
 
-template <int H, int NW, int M, int SPLIT = 1>
+template <int H, int NW, int M, int SPLIT = 1, bool DIRECT = false>
 int launch_bwd_k(const BwdParams& p, int nwg, hipStream_t st) {
-  const size_t lds = (size_t)2 * p.chq * SPLIT * 4096;
-  auto k = lstm_bwd_kernel<H, NW, M, SPLIT>;
+  const size_t lds = DIRECT ? 0 : (size_t)2 * p.chq * SPLIT * 4096;
+  auto k = lstm_bwd_kernel<H, NW, M, SPLIT, DIRECT>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -213,6 +264,11 @@ int launch_bwd(int nw, int split, const BwdParams& p, int nwg, hipStream_t st) {
       case 8: return launch_bwd_k<H, 8, 4>(p, nwg, st);
       case 12: return launch_bwd_k<H, 12, 4>(p, nwg, st);
     }
+  } else if (split == 4 && !env_int("FNSSL_BWD_RING", 1, 1)) {
+    // 4 waves per group: weights straight from L2 (narrow-band BPTT 31.8 -> 26.0 ms at config 4; with 2 waves
+    // per group the LDS ring is as fast, r01 f_train_layers)
+    if (nw == 4) return launch_bwd_k<H, 4, 1, 4, true>(p, nwg, st);
+    if (nw == 8) return launch_bwd_k<H, 8, 1, 4, true>(p, nwg, st);
   } else if (split == 2 && nw == 4) {
     return launch_bwd_k<H, 4, 8, 2>(p, nwg, st);
   } else if (split == 4 && nw == 4) {

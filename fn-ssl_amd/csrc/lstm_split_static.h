@@ -13,16 +13,22 @@
 
 namespace fnssl_lstm {
 
-template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE>
-__global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_kernel(const LstmParams p) {
+// DIRECT = true: no LDS ring — each wave streams its own quads of the weight stream straight from L2 through a
+// 4-quad-deep register pipeline (launches with few waves leave the L2 bandwidth to spare, and the ring's
+// workgroup barriers — one per CHQ quads — are what limits the split geometries); CHQ / PAD / M are unused.
+// NV2 = 16-channel blocks of the concatenated input (IPDnet), held in registers for the whole step.
+template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool DIRECT = false,
+          int NV2 = 0>
+__global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_split_static_kernel(const LstmParams p) {
   constexpr int NS = H / 16, NSL = NS / SPLIT;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SAVE = (MODE & kSave) != 0;
   static_assert(!(MODE & (kHas1 | kSum)), "single summed input, no fused residual");
-  static_assert(HAS2 == (NS2 > 0) && NS2 <= 1 && NS0 <= 1 && !(NS0 && NV0), "input segments");
-  static_assert(NS % SPLIT == 0 && NW % SPLIT == 0 && SPLIT > 1, "split geometry");
-  constexpr int QPS = 1 + NV0 + NS0 + NS2 + NS;        // real quads per slice
-  constexpr int VQ = QPS + PAD;                         // virtual quads per slice
-  static_assert(VQ % CHQ == 0, "chunks must tile the (padded) slice");
+  static_assert(HAS2 == (NS2 + NV2 > 0) && NS2 <= 1 && NS0 <= 1 && !(NS0 && NV0), "input segments");
+  static_assert(NS % SPLIT == 0 && NW % SPLIT == 0, "split geometry");
+  constexpr int QPS = 1 + NV0 + NS0 + NV2 + NS2 + NS;  // real quads per slice
+  constexpr int VQ = QPS + (DIRECT ? 0 : PAD);          // virtual quads per slice
+  static_assert(DIRECT || VQ % CHQ == 0, "chunks must tile the (padded) slice");
+  static_assert(!DIRECT || (NSL * QPS) % 4 == 0, "DIRECT: the 4-deep register pipeline must close once per step");
   constexpr int CH = 4 * CHQ * SPLIT;                   // records per chunk (CHQ super-quads)
   constexpr int QB = 4096 * SPLIT;                      // bytes per super-quad in the ring
   static_assert(CH <= NW * M, "chunk does not fit the staging registers");
@@ -46,6 +52,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
   unsigned vo0 = 0, vo2 = 0, voo = 0;
   const rsrc_t rx0 = split_addr(p.src0.p, qo * p.src0.so + qi * p.src0.si, 4 * g, vo0);
   const rsrc_t rx2 = HAS2 ? split_addr(p.src2.p, qo * p.src2.so + qi * p.src2.si, g, vo2) : rx0;
+  const unsigned vo2v = vo2 + 12 * g;   // 16-channel blocks of the concatenated input: lane (n, g) reads 4g..4g+3
   const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
   const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
                               ((size_t)dir * (p.ntasks + 16) + (tvalid ? task : p.ntasks + w)) * (NS * 1024));
@@ -89,15 +96,35 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
     wslot ^= 1;
   };
   auto sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  issue_loads();
-  stage_write();
-  sync();
-  issue_loads();
   const char* cb = lds_rd;
   auto rec = [&](auto ql, int j) {
     return *reinterpret_cast<const v4f*>(cb + decltype(ql)::value * QB + j * 1024);
   };
-  v4f a0 = rec(ic<0>{}, 0), a1 = rec(ic<0>{}, 1);
+  v4f a0, a1;
+  if constexpr (!DIRECT) {
+    issue_loads();
+    stage_write();
+    sync();
+    issue_loads();
+    a0 = rec(ic<0>{}, 0);
+    a1 = rec(ic<0>{}, 1);
+  }
+  // DIRECT: ar[k] holds quad (cursor + k) of this wave's cyclic share of the stream: local slices
+  // [part*NSL, (part+1)*NSL), QPS quads each, contiguous in the standard stream
+  v4f ar[4][4];
+  unsigned dq_off = 0;                                       // byte offset of the next quad to request
+  const unsigned dq_base = (unsigned)(part * NSL * QPS) * 4096u, dq_len = (unsigned)(NSL * QPS) * 4096u;
+  auto dq_load = [&](auto k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ar[decltype(k)::value][j] = bld4(rw, vlane, dq_base + dq_off + j * 1024u);
+    dq_off = dq_off + 4096u == dq_len ? 0u : dq_off + 4096u;
+  };
+  if constexpr (DIRECT) {
+    dq_load(ic<0>{});
+    dq_load(ic<1>{});
+    dq_load(ic<2>{});
+    dq_load(ic<3>{});
+  }
 
   v4f hold[NS];
 #pragma unroll
@@ -125,23 +152,39 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
       a1 = rec(ic<0>{}, 1);
     }
   };
-#define SQUAD(QI, B0, B1, B2, B3)                                               \
-  do {                                                                          \
-    const v4f a2_ = rec(ic<(QI) % CHQ>{}, 2), a3_ = rec(ic<(QI) % CHQ>{}, 3);   \
-    __builtin_amdgcn_sched_barrier(0);                                          \
-    MFMA4(acc, a0, B0);                                                         \
-    MFMA4(acc, a1, B1);                                                         \
-    ring_step(ic<(QI)>{});                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                          \
-    MFMA4(acc, a2_, B2);                                                        \
-    MFMA4(acc, a3_, B3);                                                        \
-    ring_end(ic<(QI)>{});                                                       \
+  // (SL = the local slice being unrolled; in DIRECT mode quad SL*QPS + QI of the step lives in ar[.. % 4])
+#define SQUAD(QI, B0, B1, B2, B3)                                                 \
+  do {                                                                            \
+    if constexpr (DIRECT) {                                                       \
+      constexpr int K_ = (SL * QPS + (QI)) % 4;                                   \
+      MFMA4(acc, ar[K_][0], B0);                                                  \
+      MFMA4(acc, ar[K_][1], B1);                                                  \
+      MFMA4(acc, ar[K_][2], B2);                                                  \
+      MFMA4(acc, ar[K_][3], B3);                                                  \
+      dq_load(ic<K_>{});                                                          \
+    } else {                                                                      \
+      const v4f a2_ = rec(ic<(QI) % CHQ>{}, 2), a3_ = rec(ic<(QI) % CHQ>{}, 3);   \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      MFMA4(acc, a0, B0);                                                         \
+      MFMA4(acc, a1, B1);                                                         \
+      ring_step(ic<(QI)>{});                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      MFMA4(acc, a2_, B2);                                                        \
+      MFMA4(acc, a3_, B3);                                                        \
+      ring_end(ic<(QI)>{});                                                       \
+    }                                                                             \
   } while (0)
-#define SQUAD1(QI, B0)         \
-  do {                         \
-    MFMA4(acc, a0, B0);        \
-    ring_step(ic<(QI)>{});     \
-    ring_end(ic<(QI)>{});      \
+#define SQUAD1(QI, B0)                          \
+  do {                                          \
+    if constexpr (DIRECT) {                     \
+      constexpr int K_ = (SL * QPS + (QI)) % 4; \
+      MFMA4(acc, ar[K_][0], B0);                \
+      dq_load(ic<K_>{});                        \
+    } else {                                    \
+      MFMA4(acc, a0, B0);                       \
+      ring_step(ic<(QI)>{});                    \
+      ring_end(ic<(QI)>{});                     \
+    }                                           \
   } while (0)
 
   v4f xr[XD];
@@ -158,7 +201,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
     const unsigned o0 = tt * st0, o2 = tt * st2, oo = tt * sto;
     float xs0 = 0.f, xs2 = 0.f;
     if (NS0) xs0 = bld1(rx0, vo0, o0);
-    if (NS2) xs2 = bld1(rx2, vo2, o2);
+    if (NS2) xs2 = bld1(rx2, vo2, o2 + 64 * NV2);
+    v4f xv2[NV2 > 0 ? NV2 : 1];   // the concatenated input is the same for every slice: held for the whole step
+    static_for<NV2>([&](auto v) { xv2[v.value] = bld4(rx2, vo2v, o2 + 64 * v.value); });
     if (step > 0) {
       const unsigned op = (rev ? tt + 1 : tt - 1) * sto;
 #pragma unroll
@@ -170,12 +215,21 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
       const unsigned sg = (unsigned)(part * NSL + SL);          // global hidden slice of this wave
       v4f cprev = zero4;
       const unsigned nx = (SL + 1 < NSL ? tt : ttn) * st0;      // x of the next slice / next step
-      acc[0] = a0;   // bias quad
-      acc[1] = a1;
-      acc[2] = rec(ic<0>{}, 2);
-      acc[3] = rec(ic<0>{}, 3);
-      ring_step(ic<0>{});
-      ring_end(ic<0>{});
+      if constexpr (DIRECT) {   // bias quad
+        constexpr int K0 = (SL * QPS) % 4;
+        acc[0] = ar[K0][0];
+        acc[1] = ar[K0][1];
+        acc[2] = ar[K0][2];
+        acc[3] = ar[K0][3];
+        dq_load(ic<K0>{});
+      } else {
+        acc[0] = a0;
+        acc[1] = a1;
+        acc[2] = rec(ic<0>{}, 2);
+        acc[3] = rec(ic<0>{}, 3);
+        ring_step(ic<0>{});
+        ring_end(ic<0>{});
+      }
       static_for<NV0>([&](auto v) {
         constexpr int V = decltype(v)::value;
         const v4f xb = xr[V % XD];
@@ -187,15 +241,20 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
       });
       if (step > 0) cprev = bld4(rc, vlane, sg * 1024);
       if constexpr (NS0 > 0) SQUAD1(1 + NV0, xs0);
-      if constexpr (NS2 > 0) SQUAD1(1 + NV0 + NS0, xs2);
+      static_for<NV2>([&](auto v) {
+        constexpr int V2 = decltype(v)::value;
+        SQUAD(1 + NV0 + NS0 + V2, xv2[V2].x, xv2[V2].y, xv2[V2].z, xv2[V2].w);
+      });
+      if constexpr (NS2 > 0) SQUAD1(1 + NV0 + NS0 + NV2, xs2);
       static_for<NS>([&](auto sp) {
         constexpr int SP = decltype(sp)::value;
-        SQUAD(1 + NV0 + NS0 + NS2 + SP, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
+        SQUAD(1 + NV0 + NS0 + NV2 + NS2 + SP, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
       });
-      static_for<PAD>([&](auto u) {
-        ring_step(ic<QPS + decltype(u)::value>{});
-        ring_end(ic<QPS + decltype(u)::value>{});
-      });
+      if constexpr (!DIRECT)
+        static_for<PAD>([&](auto u) {
+          ring_step(ic<QPS + decltype(u)::value>{});
+          ring_end(ic<QPS + decltype(u)::value>{});
+        });
       const v4f ig = sigmoid4(acc[0]);
       const v4f fg = sigmoid4(acc[1]);
       const v4f gg = tanh4(acc[2]);
@@ -214,17 +273,18 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_split_static_
       }
     });
     // the partner waves read my h slices at the start of the next step: stores performed, then meet
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (SPLIT > 1) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
 #undef SQUAD
 #undef SQUAD1
 }
 
-template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE>
+template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool DIRECT = false,
+          int NV2 = 0>
 int launch_split_static_k(const LstmParams& p, int nwg, hipStream_t st) {
-  const size_t lds = (size_t)2 * CHQ * SPLIT * 4096;
+  const size_t lds = DIRECT ? 0 : (size_t)2 * CHQ * SPLIT * 4096;
   static_assert(2 * CHQ * SPLIT * 4096 <= 160 * 1024, "ring does not fit the LDS");
-  auto k = lstm_split_static_kernel<H, NW, M, SPLIT, NV0, NS0, NS2, CHQ, PAD, MODE>;
+  auto k = lstm_split_static_kernel<H, NW, M, SPLIT, NV0, NS0, NS2, CHQ, PAD, MODE, DIRECT, NV2>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));

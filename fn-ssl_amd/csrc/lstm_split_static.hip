@@ -10,8 +10,18 @@ namespace fnssl_lstm {
       mode == (kSave | (NS2_ ? kHas2 : 0)))                                                                          \
     return launch_split_static_k<H_, NW_, M_, S_, NV0_, NS0_, NS2_, CHQ_, PAD_, kSave | (NS2_ ? kHas2 : 0)>(p, nwg, st);
 
+// ring-free variants (4 waves per group): weights straight from L2 through the register pipeline
+#define TRYD(H_, NW_, S_, NV0_, NS0_, NS2_)                                                                        \
+  if (H == H_ && nw == NW_ && split == S_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ &&                     \
+      mode == (kSave | (NS2_ ? kHas2 : 0)))                                                                          \
+    return launch_split_static_k<H_, NW_, 4, S_, NV0_, NS0_, NS2_, 1, 0, kSave | (NS2_ ? kHas2 : 0), true>(p, nwg, st);
+
 int launch_split_static(const LstmParams& p, int H, int nw, int split, int mode, int max_chq, int nwg, hipStream_t st) {
   if (max_chq <= 0) max_chq = 1 << 20;
+  if (!env_int("FNSSL_FWD_RING", 1, 1)) {
+    TRYD(256, 8, 4, 16, 0, 0)
+    TRYD(256, 8, 4, 16, 0, 1)
+  }
   // narrow-band H = 256: 33 quads per slice (34 with the 4 data channels of block 1)
   TRYS(256, 8, 8, 4, 16, 0, 0, 4, 3)
   TRYS(256, 8, 8, 4, 16, 0, 1, 4, 2)

@@ -254,7 +254,9 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   };
   {
     const long long total = (long long)tasks * d->ndir;
-    int split = total * 4 <= 4LL * ncu ? 4 : total * 2 <= 4LL * ncu ? 2 : 1;   // fewer waves than SIMDs even after the split
+    // up to 2 groups per CU: 4 waves per group (beyond that the unsplit shape-specialised kernels win: measured
+    // with 2 waves per group up to 4 and 6 groups per CU, profiles/r01/d_batch_scan.txt)
+    int split = total <= 2LL * ncu ? 4 : 1;
     if (const int f = env_int("FNSSL_LSTM_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
     if (split > 1) return launch_split(split, 0, tasks);
   }

@@ -24,6 +24,7 @@
 
 #include "lstm_static.h"
 #include "lstm_bf16.h"
+#include "lstm_split_static.h"
 
 using namespace fnssl_lstm;
 
@@ -242,7 +243,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
 
   const int ncu = fnssl::device_cus();
   // ---- few sequences (a single utterance, a streaming chunk): several waves per 16-sequence group ------
-  auto launch_split = [&](int split, int t0, int t1) -> int {
+  auto launch_split = [&](int split, int t0, int t1, bool static_only) -> int {
     const int nw = split == 4 ? 8 : 4, groups_per_wg = nw / split;
     p.task0 = t0;
     p.task1 = t1;
@@ -250,15 +251,28 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     const Variant vr{nw, split == 4 ? 8 : 4, 1};
     choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, split);
     const int nwg = p.wgs_per_dir * d->ndir;
+    if (!p.carry && !(mode & kHas1)) {   // shape-specialised (ring-free) kernels for the network's own shapes
+      const int rc = launch_split_static(p, H, nw, split, mode, 0, nwg, st);
+      if (rc != kNoStatic || static_only) return rc;
+    } else if (static_only) {
+      return kNoStatic;
+    }
     return H == 128 ? launch_split_h<128>(split, p, mode, nwg, st) : launch_split_h<256>(split, p, mode, nwg, st);
   };
   {
     const long long total = (long long)tasks * d->ndir;
-    // up to 2 groups per CU: 4 waves per group (beyond that the unsplit shape-specialised kernels win: measured
-    // with 2 waves per group up to 4 and 6 groups per CU, profiles/r01/d_batch_scan.txt)
-    int split = total <= 2LL * ncu ? 4 : 1;
-    if (const int f = env_int("FNSSL_LSTM_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
-    if (split > 1) return launch_split(split, 0, tasks);
+    if (const int f = env_int("FNSSL_LSTM_SPLIT", 1, 4)) {
+      if (f != 1) return launch_split(f == 3 ? 2 : f, 0, tasks, false);
+    } else {
+      // ring-free shape-specialised kernels (H = 256 layers of the network): 4 waves per group pay up to 6 groups
+      // per CU (16 utterances: 13.9 -> 15.6 k frames/s); generic split kernels up to 2 groups per CU
+      // (profiles/r01/d_batch_scan.txt)
+      if (H == 256 && total <= 6LL * ncu) {
+        const int rc = launch_split(4, 0, tasks, true);
+        if (rc != kNoStatic) return rc;
+      }
+      if (total <= 2LL * ncu) return launch_split(4, 0, tasks, false);
+    }
   }
 
   // ---- launch planner ---------------------------------------------------------------

@@ -21,8 +21,8 @@ template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, i
           int NV2 = 0>
 __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_split_static_kernel(const LstmParams p) {
   constexpr int NS = H / 16, NSL = NS / SPLIT;
-  constexpr bool HAS2 = (MODE & kHas2) != 0, SAVE = (MODE & kSave) != 0;
-  static_assert(!(MODE & (kHas1 | kSum)), "single summed input, no fused residual");
+  constexpr bool HAS2 = (MODE & kHas2) != 0, SAVE = (MODE & kSave) != 0, SUM = (MODE & kSum) != 0;
+  static_assert(!(MODE & kHas1), "single summed input");
   static_assert(HAS2 == (NS2 + NV2 > 0) && NS2 <= 1 && NS0 <= 1 && !(NS0 && NV0), "input segments");
   static_assert(NS % SPLIT == 0 && NW % SPLIT == 0, "split geometry");
   constexpr int QPS = 1 + NV0 + NS0 + NV2 + NS2 + NS;  // real quads per slice
@@ -49,11 +49,14 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_sp
   if (q >= p.nseq) q = p.nseq - 1;
   const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
 
-  unsigned vo0 = 0, vo2 = 0, voo = 0;
+  unsigned vo0 = 0, vo2 = 0, voo = 0, vok = 0, voo2 = 0;
   const rsrc_t rx0 = split_addr(p.src0.p, qo * p.src0.so + qi * p.src0.si, 4 * g, vo0);
   const rsrc_t rx2 = HAS2 ? split_addr(p.src2.p, qo * p.src2.so + qi * p.src2.si, g, vo2) : rx0;
   const unsigned vo2v = vo2 + 12 * g;   // 16-channel blocks of the concatenated input: lane (n, g) reads 4g..4g+3
   const rsrc_t ro = split_addr(p.out, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo);
+  const rsrc_t rsk = SUM ? split_addr(p.skip.p, qo * p.skip.so + qi * p.skip.si, dir * H + 4 * g, vok) : rx0;
+  const rsrc_t ro2 = SUM ? split_addr(p.out_sum, qo * p.out_so + qi * p.out_si, dir * H + 4 * g, voo2) : ro;
+  const unsigned stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
   const rsrc_t rc = make_rsrc(reinterpret_cast<const char*>(p.cscratch) +
                               ((size_t)dir * (p.ntasks + 16) + (tvalid ? task : p.ntasks + w)) * (NS * 1024));
   const rsrc_t rres = SAVE ? make_rsrc(reinterpret_cast<const char*>(p.reserve) +
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_sp
   for (int step = 0; step < p.nsteps; ++step) {
     const unsigned tt = rev ? p.nsteps - 1 - step : step;
     const unsigned ttn = step + 1 < p.nsteps ? (rev ? tt - 1 : tt + 1) : tt;
-    const unsigned o0 = tt * st0, o2 = tt * st2, oo = tt * sto;
+    const unsigned o0 = tt * st0, o2 = tt * st2, oo = tt * sto, ok = tt * stk;
     float xs0 = 0.f, xs2 = 0.f;
     if (NS0) xs0 = bld1(rx0, vo0, o0);
     if (NS2) xs2 = bld1(rx2, vo2, o2 + 64 * NV2);
@@ -240,6 +243,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_sp
           xr[V % XD] = bld4(rx0, vo0, nx + 64 * (V + XD - NV0));   // wraps into the next slice
       });
       if (step > 0) cprev = bld4(rc, vlane, sg * 1024);
+      v4f skipv = zero4;
+      if (SUM) skipv = bld4(rsk, vok, ok + 64 * sg);
       if constexpr (NS0 > 0) SQUAD1(1 + NV0, xs0);
       static_for<NV2>([&](auto v) {
         constexpr int V2 = decltype(v)::value;
@@ -260,9 +265,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_sp
       const v4f gg = tanh4(acc[2]);
       const v4f og = sigmoid4(acc[3]);
       const v4f cn = cell4(fg, cprev, ig, gg);
-      const v4f hn = mul_rn4(og, tanh4(cn));
+      v4f hn = mul_rn4(og, tanh4(cn));
+      asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
       bst4(cn, rc, vlane, sg * 1024);
-      if (valid) bst4(hn, ro, voo, oo + 64 * sg);
+      if (valid) {
+        bst4(hn, ro, voo, oo + 64 * sg);
+        if (SUM) bst4(add_rn4(hn, skipv), ro2, voo2, oo + 64 * sg);
+      }
       if (SAVE && tvalid) {
         const unsigned rb = (tt * NS + sg) * (kReserveRecs * 1024);
         bst4(ig, rres, vlane, rb);

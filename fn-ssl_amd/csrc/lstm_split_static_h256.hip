@@ -16,9 +16,18 @@ namespace fnssl_lstm {
       mode == (kSave | (NS2_ ? kHas2 : 0)))                                                                          \
     return launch_split_static_k<H_, NW_, 4, S_, NV0_, NS0_, NS2_, 1, 0, kSave | (NS2_ ? kHas2 : 0), true>(p, nwg, st);
 
+// inference (fused forward: residual output for the next layer), 4 waves per group, ring-free
+#define TRYI(NS2_, MODE_)                                                                                   \
+  if (H == 256 && nw == 8 && split == 4 && p.c0 == 256 && p.c2 == 4 * NS2_ && mode == (MODE_))              \
+    return launch_split_static_k<256, 8, 4, 4, 16, 0, NS2_, 1, 0, MODE_, true>(p, nwg, st);
+
 int launch_split_static_h256(const LstmParams& p, int H, int nw, int split, int mode, int max_chq, int nwg, hipStream_t st) {
   if (max_chq <= 0) max_chq = 1 << 20;
   if (!env_int("FNSSL_FWD_RING", 1, 1)) {
+    TRYI(0, kSum)
+    TRYI(1, kHas2 | kSum)
+    TRYI(0, 0)
+    TRYI(1, kHas2)
     TRYD(256, 8, 4, 16, 0, 0)
     TRYD(256, 8, 4, 16, 0, 1)
   }

@@ -28,6 +28,9 @@ int launch_split_static_h256(const LstmParams& p, int H, int nw, int split, int 
     TRYI(1, kHas2 | kSum)
     TRYI(0, 0)
     TRYI(1, kHas2)
+    // IPDnet narrow-band: [256 | 16-channel concatenated block]
+    if (H == 256 && nw == 8 && split == 4 && p.c0 == 256 && p.c2 == 16 && mode == kHas2)
+      return launch_split_static_k<256, 8, 4, 4, 16, 0, 0, 1, 0, kHas2, true, 1>(p, nwg, st);
     TRYD(256, 8, 4, 16, 0, 0)
     TRYD(256, 8, 4, 16, 0, 1)
   }

@@ -267,7 +267,8 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
       // ring-free shape-specialised kernels (H = 256 layers of the network): 4 waves per group pay up to 6 groups
       // per CU (16 utterances: 13.9 -> 15.6 k frames/s); generic split kernels up to 2 groups per CU
       // (profiles/r01/d_batch_scan.txt)
-      if (H == 256 && total <= 6LL * ncu) {
+      const int s4 = env_int("FNSSL_SPLIT4_MAX_H256", 1, 64) ? env_int("FNSSL_SPLIT4_MAX_H256", 1, 64) : 6;   // tuning knob
+      if (H == 256 && total <= (long long)s4 * ncu) {
         const int rc = launch_split(4, 0, tasks, true);
         if (rc != kNoStatic) return rc;
       }

@@ -31,11 +31,11 @@ static int lds_chunk_cap(int nwg, int split) {
 // groups than would give every SIMD two waves: ONE launch in which 2 or 4 waves share a group (split), so
 // the chip fills up with waves that each do a fraction of the per-step work.  FNSSL_TRAIN_SPLIT=1|2|4 forces.
 template <class F>
-static int plan_rounds(int tasks, int ndir, int max_split, F&& fn) {
+static int plan_rounds(int tasks, int ndir, int max_split, int split4_groups_per_cu, F&& fn) {
   const int ncu = device_cus();
   const long long total = (long long)tasks * ndir;
   int split = 1;
-  if (total * 4 <= 8LL * ncu)
+  if (total <= (long long)split4_groups_per_cu * ncu)   // 2, or 6 for the ring-free H = 256 kernels
     split = 4;
   else if (total * 2 <= 12LL * ncu)
     split = 2;
@@ -64,7 +64,7 @@ static int plan_rounds(int tasks, int ndir, int max_split, F&& fn) {
 
 // Training forward: called by fnssl_lstm_forward when the descriptor carries a reserve buffer.
 int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
-  return plan_rounds(p.ntasks, p.ndir, 4, [&](const Geometry& gm) {
+  return plan_rounds(p.ntasks, p.ndir, 4, H == 256 ? 6 : 2, [&](const Geometry& gm) {
     p.task0 = gm.t0;
     p.task1 = gm.t1;
     const int groups_per_wg = gm.nw / gm.split;
@@ -186,7 +186,7 @@ int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) {
   fnssl::TimedLaunch tl(H == 128 ? "lstm_bwd_h128" : "lstm_bwd_h256", st, flops);
   const int nso = p.co_pad / 64;
   const int max_split = nso % 4 == 0 ? 4 : nso % 2 == 0 ? 2 : 1;   // output slices divide among the waves
-  return plan_rounds(p.ntasks, p.ndir, max_split, [&](const Geometry& gm) {
+  return plan_rounds(p.ntasks, p.ndir, max_split, H == 256 ? 6 : 2, [&](const Geometry& gm) {
     p.task0 = gm.t0;
     p.task1 = gm.t1;
     const int groups_per_wg = gm.nw / gm.split;

@@ -125,3 +125,75 @@ def make_ipdnet_state(seed: int = 0, input_size: int = 4, hidden_size: int = 128
             b = 1.0 / np.sqrt(shape[1] * shape[2] * shape[3])
         sd[name] = rs.uniform(-b, b, size=shape).astype(np.float32)
     return sd
+
+
+# --------------------------------------------------------------------------- #
+# IPDnet2 (OnlineSpatialNet), reference IPDnet2/IPDnet2.py:85-136 (layer), :259-330 (network)
+# --------------------------------------------------------------------------- #
+def mamba_param_shapes(d_model: int, d_state: int = 16, d_conv: int = 4, expand: int = 2):
+    """(name, shape) list of one ``mamba_ssm.Mamba(d_model, d_state, d_conv)`` block (the names a real
+    checkpoint of the reference carries; call sites IPDnet2/IPDnet2.py:127,132)."""
+    d_inner = expand * d_model
+    dt_rank = -(-d_model // 16)
+    return [("in_proj.weight", (2 * d_inner, d_model)), ("conv1d.weight", (d_inner, 1, d_conv)),
+            ("conv1d.bias", (d_inner,)), ("x_proj.weight", (dt_rank + 2 * d_state, d_inner)),
+            ("dt_proj.weight", (d_inner, dt_rank)), ("dt_proj.bias", (d_inner,)),
+            ("A_log", (d_inner, d_state)), ("D", (d_inner,)), ("out_proj.weight", (d_model, d_inner))]
+
+
+def ipdnet2_param_shapes(dim_input: int = 10, dim_output: int = 16, num_layers: int = 8, dim_hidden: int = 96,
+                         dim_squeeze: int = 8, num_freqs: int = 256, encoder_kernel_size: int = 5,
+                         f_kernel_size: int = 5, f_groups: int = 8, d_state: int = 16, d_conv: int = 4,
+                         fre_compression_ratio: int = 16):
+    """(name, shape) list of OnlineSpatialNet with attention='mamba(d_state,d_conv)' and all-LN norms."""
+    H = dim_hidden
+    out = [("encoder.weight", (H, dim_input, encoder_kernel_size)), ("encoder.bias", (H,))]
+    for l in range(num_layers):
+        p = "layers.%d." % l
+        nfull = num_freqs // 2 if l == 0 else num_freqs // fre_compression_ratio
+        for fc in ("fconv1", "fconv2"):
+            out += [(p + fc + ".0.weight", (H,)), (p + fc + ".0.bias", (H,)),
+                    (p + fc + ".1.weight", (H, H // f_groups, f_kernel_size)), (p + fc + ".1.bias", (H,)),
+                    (p + fc + ".2.weight", (H,))]
+        out += [(p + "norm_full.weight", (H,)), (p + "norm_full.bias", (H,)),
+                (p + "squeeze.0.weight", (dim_squeeze, H, 1)), (p + "squeeze.0.bias", (dim_squeeze,)),
+                (p + "full.weight", (nfull, nfull)), (p + "full.bias", (nfull,)),
+                (p + "unsqueeze.0.weight", (H, dim_squeeze, 1)), (p + "unsqueeze.0.bias", (H,))]
+        for nm, mm in (("norm_mhsa", "mhsa"), ("norm_tconvffn", "tconvffn")):
+            out += [(p + nm + ".weight", (H,)), (p + nm + ".bias", (H,))]
+            out += [(p + mm + "." + n, s) for n, s in mamba_param_shapes(H, d_state, d_conv)]
+    out += [("freq_inverse.trans2.weight", (fre_compression_ratio * dim_output, H, 1)),
+            ("freq_inverse.trans2.bias", (fre_compression_ratio * dim_output,)),
+            ("decoder.weight", (dim_output, dim_output)), ("decoder.bias", (dim_output,))]
+    return out
+
+
+def make_ipdnet2_state(seed: int = 0, **cfg):
+    """Deterministic OnlineSpatialNet parameters: PyTorch-default-like ranges for conv / linear layers, norm
+    gains around 1, PReLU slopes around 0.25, and Mamba's own init ranges (A = -exp(A_log) in [-16, -0.5],
+    D around 1, softplus(dt bias) in [1e-3, 1e-1])."""
+    rs = np.random.RandomState(seed)
+    sd = collections.OrderedDict()
+    for name, shape in ipdnet2_param_shapes(**cfg):
+        leaf = name.split(".")[-1]
+        if name.endswith("A_log"):
+            v = np.log(rs.uniform(0.5, 16.0, size=shape))
+        elif leaf == "D":
+            v = rs.uniform(0.5, 1.5, size=shape)
+        elif name.endswith("dt_proj.bias"):
+            dt = np.exp(rs.uniform(np.log(1e-3), np.log(1e-1), size=shape))
+            v = dt + np.log(-np.expm1(-dt))                    # inverse softplus
+        elif name.endswith("dt_proj.weight"):
+            b = shape[1] ** -0.5
+            v = rs.uniform(-b, b, size=shape)
+        elif ".fconv" in name and name.endswith(".2.weight"):   # PReLU slope
+            v = rs.uniform(0.1, 0.4, size=shape)
+        elif len(shape) == 1 and leaf == "weight":              # LayerNorm gain
+            v = rs.uniform(0.7, 1.3, size=shape)
+        elif len(shape) == 1:                                   # biases
+            v = rs.uniform(-0.1, 0.1, size=shape)
+        else:                                                   # conv / linear weight: U(+-1/sqrt(fan_in))
+            b = 1.0 / np.sqrt(np.prod(shape[1:]))
+            v = rs.uniform(-b, b, size=shape)
+        sd[name] = np.asarray(v, dtype=np.float32)
+    return sd

@@ -103,6 +103,7 @@ class FNblock(nn.Module):
             self._packed, self._packed_key = (full, narr), key
         return self._packed
 
+    @ops.on_device
     def run(self, x_main, x_skip, x_in=None):
         """Full-band input = [x_main | x_in] (first block: x_in alone), narrow-band input = [full out | x_skip];
         x_in defaults to x_skip (IPDnet.forward feeds the network input to both).  All operands are logical
@@ -130,6 +131,7 @@ class FNblock(nn.Module):
         ops.lstm_layer("narrow", f, None, x_skip, narr_w, self.narr_hidden_size, n.permute(0, 2, 1, 3), bf16=bf)   # :34
         return n.permute(0, 2, 1, 3)
 
+    @ops.on_device
     def forward(self, x, fb_skip, nb_skip):
         """Reference signature: x [nb, nt, nf, C], fb_skip [nb*nt, nf, Cs], nb_skip [nb*nf, nt, Cs]
         -> [nb, nt, nf, Hn + Cs] (the concatenation is materialised only here, for API compatibility)."""
@@ -183,6 +185,7 @@ class CausCnnBlock(nn.Module):
             self._packed_key = key
         return self._packed
 
+    @ops.on_device
     def run(self, xa, xb):
         """Channel concatenation [xa | xb] of logical [nb, nf, nt, C] tensors -> [nb, nf, nt//12, ceil4(out_dim)]."""
         _require_eval(self)
@@ -200,6 +203,7 @@ class CausCnnBlock(nn.Module):
         y = ops.avgpool_time(y, 4)
         return ops.conv3x3_causal(y, None, w3, self.out_dim, "tanh", bf)
 
+    @ops.on_device
     def forward(self, x):
         """Reference signature: x [nb, inp_dim, nf, nt] -> [nb, out_dim, nf, nt // 12]."""
         in_dtype = x.dtype
@@ -231,6 +235,7 @@ class IPDnet(nn.Module):
         self.conv = CausCnnBlock(inp_dim=self.cnn_inp_dim, out_dim=self.cnn_out_dim)
         self.n = n_seg
 
+    @ops.on_device
     def forward(self, x, offline_inference=False):
         _require_eval(self)
         in_dtype = x.dtype
@@ -263,6 +268,7 @@ class IPDnet(nn.Module):
             return c[:, :ou_frame, :, :, :].to(in_dtype)
         return c.reshape(nb, nt2, 2, nf * 2, -1).permute(0, 1, 3, 4, 2).to(in_dtype)
 
+    @ops.on_device
     def forward_stream(self, x, state=None):
         """Streaming inference of the online model (the state carry SURVEY.md §8f rank 3 asks for; the reference's
         causality permits it but it has no such entry): x [nb, 2*nch, nf, T] = the NEXT T frames (T a positive

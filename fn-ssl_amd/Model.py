@@ -100,6 +100,7 @@ class FNblock(nn.Module):
             self._packed, self._packed_key = (full, narr), key
         return self._packed
 
+    @ops.on_device
     def forward(self, x, nb_skip=None, fb_skip=None):
         """x [nb, nt, nf, C] -> (x [nb, nt, nf, Hn], fb_skip [nb*nt, nf, 2Hf], nb_skip [nb*nf, nt, Hn]).
 
@@ -158,6 +159,7 @@ class FN_SSL(nn.Module):
             self._net_key = key
         return self._net
 
+    @ops.on_device
     def forward_seq(self, x0):
         """x0 [nb', nt, nf, input_size] (the layout the front-end kernels emit) -> DP-IPD."""
         _require_eval(self)
@@ -202,6 +204,7 @@ class FN_SSL(nn.Module):
             outs.append(y)
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
 
+    @ops.on_device
     def forward(self, x):
         """x [nb', input_size, nf, nt] -> [nb', nt//12, 2*nf]  (or [.., 180] with is_doa)."""
         _require_eval(self)
@@ -210,6 +213,7 @@ class FN_SSL(nn.Module):
         return self.forward_seq(ops.nchw_to_seq(x.float())).to(x.dtype)   # permute(0,3,2,1), Model.py:73
 
 
+    @ops.on_device
     def forward_stream(self, x, state=None):
         """Streaming inference of the online (causal) model — the state carry the reference's causality
         permits but does not implement.
@@ -221,6 +225,8 @@ class FN_SSL(nn.Module):
         their carried (h, c).
         """
         _require_eval(self)
+        if _is_bf16(self):
+            raise RuntimeError("FN_SSL.forward_stream: fp32 model only (the streaming kernels are the exact-fp32 ones)")
         if not self.is_online:
             raise RuntimeError("FN_SSL.forward_stream: only the online model (uni-directional narrow-band) streams")
         if x.ndim != 4 or x.shape[1] != self.input_size or x.shape[3] == 0 or x.shape[3] % ops.SEG_FRAMES:

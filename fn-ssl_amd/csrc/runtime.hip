@@ -10,12 +10,18 @@
 namespace fnssl {
 
 int device_cus() {
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
-  return ncu;
+  // per device: a process may drive any of the node's GPUs (one process per GPU picks its own ordinal)
+  static std::mutex mu;
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cache[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev] = n;
+  }
+  return cache[dev];
 }
 
 

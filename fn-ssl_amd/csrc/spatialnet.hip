@@ -1,0 +1,847 @@
+// IPDnet2 / OnlineSpatialNet on gfx950 (SURVEY.md 8 rows a13 + f4; reference IPDnet2/IPDnet2.py).
+//
+// The network is ~25 MFLOP per input frame spread over many SMALL dense layers (96 -> 96 grouped k5, 96 -> 8,
+// 96 -> 384, 192 -> 40, 192 -> 96 ...) plus LayerNorms, poolings and one sequential scan — nothing like the
+// LSTM recurrences next door.  fp32 MFMA is only 2x the packed-fp32 vector rate on CDNA4 and these layer
+// shapes (12-wide groups, K = 60) would waste a quarter of every 16x16 tile, so the formulation here is
+//
+//     one THREAD = one time-frequency point; the point's 96 channels live in its registers;
+//     weights are WAVE-UNIFORM: read through the scalar cache (s_load_dwordx8/16) and consumed as the
+//     SGPR operand of v_pk_fma_f32 — no LDS or vector-memory traffic for weights at all;
+//     LayerNorm is a reduction over the thread's own registers (no cross-lane step);
+//     neighbours along frequency (the k = 5 grouped conv, the Linear over F) are exchanged through small
+//     LDS tiles, one 12-channel group at a time, double-buffered (one barrier per group);
+//     along time only the selective scan is sequential: one thread per (sequence, inner channel) keeps the
+//     16 states in registers, B_t / C_t / dt_t arrive as wave-uniform scalars.
+//
+// Every kernel takes strided [B, T, F, 96] views (channels contiguous), so the reference's permutes
+// (:222-233, :235-253, :333-335, :355-364) are never materialised and the residual adds, the frequency /
+// time poolings and the activations are fused into the producing kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int H = 96;      // dim_hidden
+constexpr int HS = 8;      // dim_squeeze
+constexpr int NG = 8;      // f-conv groups
+constexpr int CG = 12;     // channels per group
+constexpr int KF = 5;      // f-conv taps
+constexpr int KE = 5;      // encoder taps
+constexpr int E = 192;     // Mamba d_inner
+constexpr int NST = 16;    // Mamba d_state
+constexpr int RK = 6;      // Mamba dt_rank
+constexpr int KC = 4;      // Mamba d_conv
+constexpr int XP = 40;     // x_proj outputs (6 + 16 + 16) padded to a float4 multiple
+constexpr int DO = 16;     // dim_output
+constexpr float kEps = 1e-5f;
+
+constexpr int kFconvTile = 4992;   // floats per buffer: max over nf in [8, 256] of (256/nf) * (nf + 4) * 13
+constexpr int kFullTile = 2304;    // max over nf of (256/nf) * (nf * 8 + 4)
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ void load_row(float (&x)[H], const float* __restrict__ p) {
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int i = 0; i < H / 4; ++i) {
+    const float4 v = p4[i];
+    x[4 * i] = v.x;
+    x[4 * i + 1] = v.y;
+    x[4 * i + 2] = v.z;
+    x[4 * i + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x)[H]) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+#pragma unroll
+  for (int i = 0; i < H / 4; ++i) p4[i] = make_float4(x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]);
+}
+
+// nn.LayerNorm statistics over the thread's own 96 channels (biased variance, eps inside the root).
+__device__ __forceinline__ void ln_stats(const float (&x)[H], float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < H; ++c) s += x[c];
+  mean = s * (1.f / H);
+  float v = 0.f;
+#pragma unroll
+  for (int c = 0; c < H; ++c) {
+    const float d = x[c] - mean;
+    v = fmaf(d, d, v);
+  }
+  rstd = 1.f / sqrtf(v * (1.f / H) + kEps);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm alone (arch/base/norm.py:11-27): one wave per row, wavefront reductions.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_layernorm_kernel(const float* __restrict__ x, long long rows, int h, const float* __restrict__ w,
+                    const float* __restrict__ b, float eps, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * h;
+  float s = 0.f;
+  for (int c = lane; c < h; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)h;
+  float v = 0.f;
+  for (int c = lane; c < h; c += 64) {
+    const float d = xr[c] - mean;
+    v = fmaf(d, d, v);
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(v) / (float)h + eps);
+  for (int c = lane; c < h; c += 64) y[row * h + c] = (xr[c] - mean) * rstd * w[c] + b[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Encoder: CausalConv1d(cin -> 96, k 5) along time (IPDnet2.py:66-76, :335).  Lanes run along t.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_encoder_kernel(const float* __restrict__ x, long long sb, long long sc, long long sf, long long st, int cin,
+                  int nf, int nt, long long npts, const float* __restrict__ wT, const float* __restrict__ bias,
+                  const float* __restrict__ state_in, float* __restrict__ out, long long o_sb, long long o_st,
+                  long long o_sf) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  const int t = (int)(p % nt);
+  const int f = (int)((p / nt) % nf);
+  const long long b = p / ((long long)nt * nf);
+  float acc[H];
+#pragma unroll
+  for (int o = 0; o < H; ++o) acc[o] = bias[o];
+  for (int c = 0; c < cin; ++c) {
+    const float* xc = x + b * sb + c * sc + f * sf;
+    const float* sc_in = state_in ? state_in + ((b * cin + c) * nf + f) * (KE - 1) : nullptr;
+    float v[KE];
+#pragma unroll
+    for (int k = 0; k < KE; ++k) {
+      const int tt = t + k - (KE - 1);
+      v[k] = tt >= 0 ? xc[tt * st] : (sc_in ? sc_in[(KE - 1) + tt] : 0.f);
+    }
+    const float* wc = wT + (long long)c * KE * H;
+#pragma unroll
+    for (int k = 0; k < KE; ++k)
+#pragma unroll
+      for (int o = 0; o < H; ++o) acc[o] = fmaf(wc[k * H + o], v[k], acc[o]);
+  }
+  store_row(out + b * o_sb + t * o_st + f * o_sf, acc);
+}
+
+// The carried state of the encoder: the last 4 input frames of every (b, c, f) row (in place is fine).
+__global__ void __launch_bounds__(256)
+sn_encoder_state_kernel(const float* __restrict__ x, long long sb, long long sc, long long sf, long long st,
+                        int cin, int nf, int nt, long long nrows, const float* state_in, float* state_out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, c, f)
+  if (r >= nrows) return;
+  const int f = (int)(r % nf);
+  const int c = (int)((r / nf) % cin);
+  const long long b = r / ((long long)nf * cin);
+  const float* xc = x + b * sb + c * sc + f * sf;
+  float v[KE - 1];
+#pragma unroll
+  for (int j = 0; j < KE - 1; ++j) {
+    const int src = nt - (KE - 1) + j;
+    v[j] = src >= 0 ? xc[src * st] : (state_in ? state_in[r * (KE - 1) + (KE - 1) + src] : 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < KE - 1; ++j) state_out[r * (KE - 1) + j] = v[j];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x (+)= PReLU(Conv1d_grouped_k5(LayerNorm(x))) along F, optional AvgPool over F (IPDnet2.py:146-153,222-233).
+// One block = 256 points = 256/nf whole frames; thread = point.
+// ---------------------------------------------------------------------------------------------------------
+template <int POOL>
+__global__ void __launch_bounds__(256)
+sn_fconv_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nframes, fnssl_sn_fconv_w w, int residual,
+                float* out, long long o_sb, long long o_st, long long o_sf) {
+  __shared__ float tile[2][kFconvTile];
+  const int tid = threadIdx.x;
+  const int fr = tid >> lg_nf, f = tid & (nf - 1);
+  const long long frame = (long long)blockIdx.x * (256 >> lg_nf) + fr;
+  const bool valid = frame < nframes;
+  const long long b = frame / nt;
+  const int t = (int)(frame % nt);
+  float x[H];
+  if (valid) {
+    load_row(x, xv.p + b * xv.sb + t * xv.st + f * xv.sf);
+  } else {
+#pragma unroll
+    for (int c = 0; c < H; ++c) x[c] = 0.f;
+  }
+  const int rows = nf + 4;                     // 2 zero rows either side = the 'same' padding
+  if (f < 2) {
+#pragma unroll
+    for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+      for (int ci = 0; ci < CG; ++ci) {
+        tile[buf][(fr * rows + f) * 13 + ci] = 0.f;
+        tile[buf][(fr * rows + nf + 2 + f) * 13 + ci] = 0.f;
+      }
+  }
+  float mean, rstd;
+  ln_stats(x, mean, rstd);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float* tb = tile[g & 1];
+    float* mine = tb + (fr * rows + f + 2) * 13;
+#pragma unroll
+    for (int ci = 0; ci < CG; ++ci)
+      mine[ci] = (x[g * CG + ci] - mean) * rstd * w.ln_w[g * CG + ci] + w.ln_b[g * CG + ci];
+    __syncthreads();   // also orders this buffer's previous readers (iteration g - 2) before the next writers
+    float acc[CG];
+#pragma unroll
+    for (int o = 0; o < CG; ++o) acc[o] = w.bias[g * CG + o];
+    const float* wg = w.wT + g * (KF * CG * CG);
+    const float* base = tb + (fr * rows + f) * 13;
+    // rolled on purpose: a fully unrolled body lets the scheduler hoist all 720 scalar weight loads of the group
+    // (5760 for the kernel) and spill SGPRs by the thousand; 48 weights per trip fit the scalar file
+#pragma unroll 1
+    for (int j = 0; j < KF * CG; j += 4) {
+      const int tap = j / CG, ci = j - tap * CG;
+      const float* bj = base + tap * 13 + ci;
+      const float v0 = bj[0], v1 = bj[1], v2 = bj[2], v3 = bj[3];
+      const float* wj = wg + j * CG;
+#pragma unroll
+      for (int o = 0; o < CG; ++o) acc[o] = fmaf(wj[o], v0, acc[o]);
+#pragma unroll
+      for (int o = 0; o < CG; ++o) acc[o] = fmaf(wj[CG + o], v1, acc[o]);
+#pragma unroll
+      for (int o = 0; o < CG; ++o) acc[o] = fmaf(wj[2 * CG + o], v2, acc[o]);
+#pragma unroll
+      for (int o = 0; o < CG; ++o) acc[o] = fmaf(wj[3 * CG + o], v3, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < CG; ++o) {
+      float a = acc[o];
+      a = a >= 0.f ? a : w.prelu[g * CG + o] * a;
+      x[g * CG + o] = residual ? x[g * CG + o] + a : a;
+    }
+  }
+  if (POOL > 1) {
+#pragma unroll
+    for (int c = 0; c < H; ++c) {
+      float v = x[c];
+      v += __shfl_xor(v, 1, 64);
+      if (POOL == 8) {
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+      }
+      x[c] = v * (1.f / POOL);
+    }
+  }
+  if (valid && (f & (POOL - 1)) == 0) store_row(out + b * o_sb + t * o_st + (f / POOL) * o_sf, x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x (+)= SiLU(unsqueeze(Linear_over_F(SiLU(squeeze(LayerNorm(x))))))   (IPDnet2.py:150,235-253)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_full_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nframes, fnssl_sn_full_w w, int residual,
+               float* out, long long o_sb, long long o_st, long long o_sf) {
+  __shared__ __attribute__((aligned(16))) float S[kFullTile];
+  const int tid = threadIdx.x;
+  const int fr = tid >> lg_nf, f = tid & (nf - 1);
+  const long long frame = (long long)blockIdx.x * (256 >> lg_nf) + fr;
+  const bool valid = frame < nframes;
+  const long long b = frame / nt;
+  const int t = (int)(frame % nt);
+  float x[H];
+  if (valid) {
+    load_row(x, xv.p + b * xv.sb + t * xv.st + f * xv.sf);
+  } else {
+#pragma unroll
+    for (int c = 0; c < H; ++c) x[c] = 0.f;
+  }
+  float mean, rstd;
+  ln_stats(x, mean, rstd);
+  float s[HS];
+#pragma unroll
+  for (int q = 0; q < HS; ++q) s[q] = w.bs[q];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float ln = (x[h] - mean) * rstd * w.ln_w[h] + w.ln_b[h];
+#pragma unroll
+    for (int q = 0; q < HS; ++q) s[q] = fmaf(w.wsT[h * HS + q], ln, s[q]);
+  }
+  const int fstride = nf * HS + 4;             // +4: frames of one wave land in different banks
+  float4* mine = reinterpret_cast<float4*>(S + fr * fstride + f * HS);
+  mine[0] = make_float4(silu_f(s[0]), silu_f(s[1]), silu_f(s[2]), silu_f(s[3]));
+  mine[1] = make_float4(silu_f(s[4]), silu_f(s[5]), silu_f(s[6]), silu_f(s[7]));
+  __syncthreads();
+  float y[HS];
+  const float bfv = w.bf[f];
+#pragma unroll
+  for (int q = 0; q < HS; ++q) y[q] = bfv;
+  const float4* sf = reinterpret_cast<const float4*>(S + fr * fstride);
+  for (int f2 = 0; f2 < nf; ++f2) {            // Linear over F: y[f] = sum_f2 W[f][f2] s[f2]
+    const float wv = w.wfT[f2 * nf + f];
+    const float4 a = sf[f2 * 2], c = sf[f2 * 2 + 1];
+    y[0] = fmaf(wv, a.x, y[0]);
+    y[1] = fmaf(wv, a.y, y[1]);
+    y[2] = fmaf(wv, a.z, y[2]);
+    y[3] = fmaf(wv, a.w, y[3]);
+    y[4] = fmaf(wv, c.x, y[4]);
+    y[5] = fmaf(wv, c.y, y[5]);
+    y[6] = fmaf(wv, c.z, y[6]);
+    y[7] = fmaf(wv, c.w, y[7]);
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float a = w.bu[h];
+#pragma unroll
+    for (int q = 0; q < HS; ++q) a = fmaf(w.wuT[q * H + h], y[q], a);
+    a = silu_f(a);
+    x[h] = residual ? x[h] + a : a;
+  }
+  if (valid) store_row(out + b * o_sb + t * o_st + f * o_sf, x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mamba, phase 1: xz[s, t, 0:384] = in_proj(LayerNorm(x))   (sequence s = b*nf + f; lanes run along t)
+// blockIdx.y = output quarter (96 of the 384 outputs), so the weights stay wave-uniform.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const float* __restrict__ ln_w,
+                   const float* __restrict__ ln_b, const float* __restrict__ winT, float* __restrict__ xz) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  const int t = (int)(p % nt);
+  const int f = (int)((p / nt) % nf);
+  const long long b = p / ((long long)nt * nf);
+  float x[H];
+  load_row(x, xv.p + b * xv.sb + t * xv.st + f * xv.sf);
+  float mean, rstd;
+  ln_stats(x, mean, rstd);
+#pragma unroll
+  for (int h = 0; h < H; ++h) x[h] = (x[h] - mean) * rstd * ln_w[h] + ln_b[h];
+  const int q = blockIdx.y;
+  float4* dst = reinterpret_cast<float4*>(xz + p * (2 * E) + q * 96);
+#pragma unroll 1
+  for (int j = 0; j < 6; ++j) {
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    const float* wj = winT + q * 96 + j * 16;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int o = 0; o < 16; ++o) acc[o] = fmaf(wj[h * (2 * E) + o], x[h], acc[o]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[j * 4 + i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mamba, phase 2: dbl[s, t, 0:40] = x_proj(SiLU(causal_depthwise_conv4(xi)))  — (dt 6 | B 16 | C 16 | pad)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_mamba_xproj_kernel(const float* __restrict__ xz, int nt, long long npts, const float* __restrict__ conv_w,
+                      const float* __restrict__ conv_b, const float* __restrict__ wxT,
+                      const float* __restrict__ conv_state, float* __restrict__ dbl) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  const int t = (int)(p % nt);
+  const long long s = p / nt;
+  float acc[XP];
+#pragma unroll
+  for (int j = 0; j < XP; ++j) acc[j] = 0.f;
+  for (int e4 = 0; e4 < E / 4; ++e4) {
+    float xi[KC][4];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int tt = t - (KC - 1) + k;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tt >= 0) {
+        v = *reinterpret_cast<const float4*>(xz + (s * nt + tt) * (2 * E) + e4 * 4);
+      } else if (conv_state) {
+        v = *reinterpret_cast<const float4*>(conv_state + (s * (KC - 1) + (KC - 1) + tt) * E + e4 * 4);
+      }
+      xi[k][0] = v.x;
+      xi[k][1] = v.y;
+      xi[k][2] = v.z;
+      xi[k][3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = e4 * 4 + i;
+      float u = conv_b[e];
+#pragma unroll
+      for (int k = 0; k < KC; ++k) u = fmaf(conv_w[e * KC + k], xi[k][i], u);
+      u = silu_f(u);
+#pragma unroll
+      for (int j = 0; j < XP; ++j) acc[j] = fmaf(wxT[e * XP + j], u, acc[j]);
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(dbl + p * XP);
+#pragma unroll
+  for (int i = 0; i < XP / 4; ++i) dst[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mamba, phase 3: the selective scan.  One block (3 waves) per sequence, one thread per inner channel e:
+//   u_t = SiLU(conv4(xi)),  dt_t = softplus(dt_proj(dbl_t[0:6])),  h = exp(dt A) h + dt B_t u,  y = C_t.h + D u,
+//   y *= SiLU(z_t).  The 16 states, A[e, :], dt_proj row and the conv taps stay in registers; dbl_t is wave-uniform.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(E)
+sn_mamba_scan_kernel(const float* __restrict__ xz, const float* __restrict__ dbl, int nt,
+                     const float* __restrict__ conv_w, const float* __restrict__ conv_b,
+                     const float* __restrict__ wdt, const float* __restrict__ bdt, const float* __restrict__ a,
+                     const float* __restrict__ dpar, float* conv_state, float* ssm_state, int carry,
+                     float* __restrict__ ybuf) {
+  const long long s = blockIdx.x;
+  const int e = threadIdx.x;
+  float A[NST], h[NST], wd[RK], cw[KC];
+#pragma unroll
+  for (int n = 0; n < NST; ++n) {
+    A[n] = a[e * NST + n];
+    h[n] = (carry && ssm_state) ? ssm_state[(s * E + e) * NST + n] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < RK; ++r) wd[r] = wdt[e * RK + r];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) cw[k] = conv_w[e * KC + k];
+  const float cb = conv_b[e], bd = bdt[e], dp = dpar[e];
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  if (carry && conv_state) {
+    x0 = conv_state[(s * 3 + 0) * E + e];
+    x1 = conv_state[(s * 3 + 1) * E + e];
+    x2 = conv_state[(s * 3 + 2) * E + e];
+  }
+  const float* xrow = xz + s * nt * (2 * E) + e;
+  const float* drow = dbl + s * nt * XP;
+  float* yrow = ybuf + s * nt * E + e;
+  float xi_n = nt > 0 ? xrow[0] : 0.f, z_n = nt > 0 ? xrow[E] : 0.f;
+  for (int t = 0; t < nt; ++t) {
+    const float xi = xi_n, z = z_n;
+    if (t + 1 < nt) {                                    // next step's operands are in flight during this one
+      xi_n = xrow[(long long)(t + 1) * (2 * E)];
+      z_n = xrow[(long long)(t + 1) * (2 * E) + E];
+    }
+    const float* row = drow + (long long)t * XP;         // wave-uniform: scalar loads
+    float u = cb;
+    u = fmaf(cw[0], x0, u);
+    u = fmaf(cw[1], x1, u);
+    u = fmaf(cw[2], x2, u);
+    u = fmaf(cw[3], xi, u);
+    u = silu_f(u);
+    x0 = x1;
+    x1 = x2;
+    x2 = xi;
+    float dtv = bd;
+#pragma unroll
+    for (int r = 0; r < RK; ++r) dtv = fmaf(wd[r], row[r], dtv);
+    const float dt = dtv > 20.f ? dtv : log1pf(__expf(dtv));
+    const float dtu = dt * u;
+    float y = 0.f;
+#pragma unroll
+    for (int n = 0; n < NST; ++n) {
+      const float dA = __expf(dt * A[n]);
+      h[n] = fmaf(dA, h[n], dtu * row[RK + n]);
+      y = fmaf(h[n], row[RK + NST + n], y);
+    }
+    y = fmaf(dp, u, y) * silu_f(z);
+    yrow[(long long)t * E] = y;
+  }
+  if (ssm_state) {
+#pragma unroll
+    for (int n = 0; n < NST; ++n) ssm_state[(s * E + e) * NST + n] = h[n];
+  }
+  if (conv_state) {
+    conv_state[(s * 3 + 0) * E + e] = x0;
+    conv_state[(s * 3 + 1) * E + e] = x1;
+    conv_state[(s * 3 + 2) * E + e] = x2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Mamba, phase 4: out = pool_T(x) + out_proj(pool_T(y))   (out_proj is linear, so the time pooling of
+// IPDnet2.py:345-349 is applied to its operand).  blockIdx.y = output half (48 channels).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_mamba_out_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, int nt2, int nf, int tp,
+                    long long nout, const float* __restrict__ woT, int residual, float* out, long long o_sb,
+                    long long o_st, long long o_sf) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= nout) return;
+  const int t2 = (int)(p % nt2);
+  const long long s = p / nt2;
+  const int f = (int)(s % nf);
+  const long long b = s / nf;
+  const int half = blockIdx.y;
+  const float inv = 1.f / (float)tp;
+  float acc[48];
+#pragma unroll
+  for (int o = 0; o < 48; ++o) acc[o] = 0.f;
+  const float* yb = ybuf + (s * nt + (long long)t2 * tp) * E;
+  for (int e4 = 0; e4 < E / 4; ++e4) {
+    float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < tp; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(yb + (long long)i * E + e4 * 4);
+      yv.x += v.x;
+      yv.y += v.y;
+      yv.z += v.z;
+      yv.w += v.w;
+    }
+    const float yy[4] = {yv.x * inv, yv.y * inv, yv.z * inv, yv.w * inv};
+    const float* we = woT + (e4 * 4) * H + half * 48;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int o = 0; o < 48; ++o) acc[o] = fmaf(we[i * H + o], yy[i], acc[o]);
+  }
+  if (residual) {
+    const float* xb = xv.p + b * xv.sb + (long long)t2 * tp * xv.st + f * xv.sf + half * 48;
+#pragma unroll
+    for (int o4 = 0; o4 < 12; ++o4) {
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < tp; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (long long)i * xv.st + o4 * 4);
+        r.x += v.x;
+        r.y += v.y;
+        r.z += v.z;
+        r.w += v.w;
+      }
+      acc[4 * o4] = fmaf(r.x, inv, acc[4 * o4]);
+      acc[4 * o4 + 1] = fmaf(r.y, inv, acc[4 * o4 + 1]);
+      acc[4 * o4 + 2] = fmaf(r.z, inv, acc[4 * o4 + 2]);
+      acc[4 * o4 + 3] = fmaf(r.w, inv, acc[4 * o4 + 3]);
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(out + b * o_sb + t2 * o_st + f * o_sf + half * 48);
+#pragma unroll
+  for (int o4 = 0; o4 < 12; ++o4) dst[o4] = make_float4(acc[4 * o4], acc[4 * o4 + 1], acc[4 * o4 + 2], acc[4 * o4 + 3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Head: FreqInverse (1x1 conv 96 -> 16 x 16 per compressed bin, scattered to the 16 fine bins it covers), tanh,
+// decoder Linear(16, 16) and the output re-ordering of IPDnet2.py:355-364:
+//   out[b, t, 2 f + gg, m, a] = dec[b, f, t, a*8 + gg*4 + m]
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+sn_head_kernel(fnssl_btf_view xv, int nt2, int nfc, long long npts, const float* __restrict__ wfiP,
+               const float* __restrict__ bfiP, const float* __restrict__ wdT, const float* __restrict__ bd,
+               float* __restrict__ out) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  const int fc = (int)(p % nfc);
+  const int t2 = (int)((p / nfc) % nt2);
+  const long long b = p / ((long long)nfc * nt2);
+  float x[H];
+  load_row(x, xv.p + b * xv.sb + t2 * xv.st + fc * xv.sf);
+  const int nf = nfc * 16;
+  float* orow = out + ((b * nt2 + t2) * (2LL * nf) + 2LL * fc * 16) * 8;
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+    float dec[DO];
+#pragma unroll
+    for (int j = 0; j < DO; ++j) dec[j] = bd[j];
+#pragma unroll 1
+    for (int o = 0; o < DO; ++o) {                 // rolled: 96 + 16 scalar weights per trip
+      const float* wr = wfiP + (r * DO + o) * H;
+      float a0 = bfiP[r * DO + o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; h += 4) {
+        a0 = fmaf(wr[h], x[h], a0);
+        a1 = fmaf(wr[h + 1], x[h + 1], a1);
+        a2 = fmaf(wr[h + 2], x[h + 2], a2);
+        a3 = fmaf(wr[h + 3], x[h + 3], a3);
+      }
+      const float v = tanhf((a0 + a1) + (a2 + a3));
+#pragma unroll
+      for (int j = 0; j < DO; ++j) dec[j] = fmaf(wdT[o * DO + j], v, dec[j]);
+    }
+    float4* dst = reinterpret_cast<float4*>(orow + r * 16);
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {          // element gg*8 + m*2 + a  <-  dec[a*8 + gg*4 + m]
+      dst[gg * 2] = make_float4(dec[gg * 4], dec[8 + gg * 4], dec[gg * 4 + 1], dec[8 + gg * 4 + 1]);
+      dst[gg * 2 + 1] = make_float4(dec[gg * 4 + 2], dec[8 + gg * 4 + 2], dec[gg * 4 + 3], dec[8 + gg * 4 + 3]);
+    }
+  }
+}
+
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+inline bool view_ok(const fnssl_btf_view* v) {
+  return v && v->p && (reinterpret_cast<size_t>(v->p) % 16 == 0) && v->sb % 4 == 0 && v->st % 4 == 0 && v->sf % 4 == 0;
+}
+inline bool out_ok(const float* p, long long sb, long long st, long long sf) {
+  return p && (reinterpret_cast<size_t>(p) % 16 == 0) && sb % 4 == 0 && st % 4 == 0 && sf % 4 == 0;
+}
+inline unsigned blocks_of(long long n) { return (unsigned)((n + 255) / 256); }
+
+struct MambaWs {
+  float *xz, *dbl, *y;
+};
+inline size_t mamba_ws_floats(long long npts) { return (size_t)npts * (2 * E + XP + E); }
+inline MambaWs carve_mamba(float* ws, long long npts) {
+  MambaWs m;
+  m.xz = ws;
+  m.dbl = ws + npts * (2 * E);
+  m.y = m.dbl + npts * XP;
+  return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, const float* b, float eps, float* y,
+                       void* stream) {
+  FNSSL_REQUIRE(x && w && b && y, "sn_layernorm: null pointer");
+  FNSSL_REQUIRE(rows >= 0 && h > 0 && h <= 1024, "sn_layernorm: bad shape (rows %lld, h %d)", rows, h);
+  if (rows == 0) return FNSSL_OK;
+  FNSSL_REQUIRE((rows + 3) / 4 < (1ll << 31), "sn_layernorm: too many rows");
+  fnssl::TimedLaunch tl("sn_layernorm", fnssl::as_stream(stream));
+  hipLaunchKernelGGL(sn_layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, fnssl::as_stream(stream), x,
+                     rows, h, w, b, eps, y);
+  FNSSL_CHECK_LAUNCH("sn_layernorm_kernel");
+  return FNSSL_OK;
+}
+
+int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x_sf, long long x_st, int nb, int cin,
+                     int nf, int nt, const float* wT, const float* bias, const float* state_in, float* state_out,
+                     float* out, long long o_sb, long long o_st, long long o_sf, void* stream) {
+  FNSSL_REQUIRE(x && wT && bias, "sn_encoder: null pointer");
+  FNSSL_REQUIRE(nb > 0 && cin > 0 && nf > 0 && nt > 0, "sn_encoder: empty problem");
+  FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_encoder: output must be 16-byte aligned with strides %% 4 == 0");
+  const long long npts = (long long)nb * nf * nt;
+  FNSSL_REQUIRE(blocks_of(npts) < (1u << 31), "sn_encoder: too many points");
+  hipStream_t s = fnssl::as_stream(stream);
+  {
+    fnssl::TimedLaunch tl("sn_encoder", s, 2.0 * npts * cin * KE * H);
+    hipLaunchKernelGGL(sn_encoder_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, x, x_sb, x_sc, x_sf, x_st, cin, nf, nt,
+                       npts, wT, bias, state_in, out, o_sb, o_st, o_sf);
+    FNSSL_CHECK_LAUNCH("sn_encoder_kernel");
+  }
+  if (state_out) {
+    const long long nrows = (long long)nb * cin * nf;
+    hipLaunchKernelGGL(sn_encoder_state_kernel, dim3(blocks_of(nrows)), dim3(256), 0, s, x, x_sb, x_sc, x_sf, x_st, cin,
+                       nf, nt, nrows, state_in, state_out);
+    FNSSL_CHECK_LAUNCH("sn_encoder_state_kernel");
+  }
+  return FNSSL_OK;
+}
+
+int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_fconv_w* w, int residual, int pool,
+                   float* out, long long o_sb, long long o_st, long long o_sf, void* stream) {
+  FNSSL_REQUIRE(view_ok(x), "sn_fconv: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(w && w->ln_w && w->ln_b && w->wT && w->bias && w->prelu, "sn_fconv: null weights");
+  FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_fconv: output must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(nb > 0 && nt > 0, "sn_fconv: empty problem");
+  FNSSL_REQUIRE(pow2(nf) && nf >= 8 && nf <= 256, "sn_fconv: nf must be a power of two in [8, 256], got %d", nf);
+  FNSSL_REQUIRE(pool == 1 || pool == 2 || pool == 8, "sn_fconv: pool must be 1, 2 or 8");
+  const long long nframes = (long long)nb * nt;
+  const int lg = ilog2(nf);
+  const long long nblk = (nframes + (256 >> lg) - 1) / (256 >> lg);
+  FNSSL_REQUIRE(nblk < (1ll << 31), "sn_fconv: too many frames");
+  hipStream_t s = fnssl::as_stream(stream);
+  fnssl::TimedLaunch tl(nf > 128 ? "sn_fconv_f256" : (nf > 16 ? "sn_fconv_f128" : "sn_fconv_f16"), s,
+                        2.0 * nframes * nf * H * CG * KF);
+#define FNSSL_SN_FCONV(P)                                                                                         \
+  hipLaunchKernelGGL(sn_fconv_kernel<P>, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, \
+                     out, o_sb, o_st, o_sf)
+  if (pool == 1) {
+    FNSSL_SN_FCONV(1);
+  } else if (pool == 2) {
+    FNSSL_SN_FCONV(2);
+  } else {
+    FNSSL_SN_FCONV(8);
+  }
+#undef FNSSL_SN_FCONV
+  FNSSL_CHECK_LAUNCH("sn_fconv_kernel");
+  return FNSSL_OK;
+}
+
+int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_full_w* w, int residual, float* out,
+                  long long o_sb, long long o_st, long long o_sf, void* stream) {
+  FNSSL_REQUIRE(view_ok(x), "sn_full: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(w && w->ln_w && w->ln_b && w->wsT && w->bs && w->wfT && w->bf && w->wuT && w->bu, "sn_full: null weights");
+  FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_full: output must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(nb > 0 && nt > 0, "sn_full: empty problem");
+  FNSSL_REQUIRE(pow2(nf) && nf >= 8 && nf <= 256, "sn_full: nf must be a power of two in [8, 256], got %d", nf);
+  const long long nframes = (long long)nb * nt;
+  const int lg = ilog2(nf);
+  const long long nblk = (nframes + (256 >> lg) - 1) / (256 >> lg);
+  FNSSL_REQUIRE(nblk < (1ll << 31), "sn_full: too many frames");
+  hipStream_t s = fnssl::as_stream(stream);
+  fnssl::TimedLaunch tl("sn_full", s, 2.0 * nframes * nf * (2.0 * H * HS + (double)HS * nf));
+  hipLaunchKernelGGL(sn_full_kernel, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, out,
+                     o_sb, o_st, o_sf);
+  FNSSL_CHECK_LAUNCH("sn_full_kernel");
+  return FNSSL_OK;
+}
+
+size_t fnssl_sn_mamba_workspace_bytes(int nb, int nt, int nf) {
+  if (nb <= 0 || nt <= 0 || nf <= 0) return 0;
+  return mamba_ws_floats((long long)nb * nt * nf) * sizeof(float);
+}
+
+int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_mamba_w* w, int residual,
+                   int time_pool, float* conv_state, float* ssm_state, int carry, float* out, long long o_sb,
+                   long long o_st, long long o_sf, void* workspace, size_t workspace_bytes, void* stream) {
+  FNSSL_REQUIRE(view_ok(x), "sn_mamba: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(w && w->ln_w && w->ln_b && w->winT && w->conv_w && w->conv_b && w->wxT && w->wdt && w->bdt && w->a &&
+                    w->d && w->woT, "sn_mamba: null weights");
+  FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_mamba: output must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(nb > 0 && nt > 0 && nf > 0, "sn_mamba: empty problem");
+  FNSSL_REQUIRE(time_pool >= 1 && time_pool <= 16, "sn_mamba: time_pool must be in [1, 16]");
+  FNSSL_REQUIRE(!carry || (conv_state && ssm_state), "sn_mamba: carry needs both state buffers");
+  const long long npts = (long long)nb * nt * nf, nseq = (long long)nb * nf;
+  if (workspace_bytes < fnssl_sn_mamba_workspace_bytes(nb, nt, nf) || !workspace) {
+    fnssl::set_error("sn_mamba: workspace %zu < %zu bytes", workspace_bytes, fnssl_sn_mamba_workspace_bytes(nb, nt, nf));
+    return FNSSL_E_WORKSPACE;
+  }
+  FNSSL_REQUIRE(blocks_of(npts) < (1u << 31) && nseq < (1ll << 31), "sn_mamba: too many points");
+  const MambaWs m = carve_mamba(static_cast<float*>(workspace), npts);
+  hipStream_t s = fnssl::as_stream(stream);
+  {
+    fnssl::TimedLaunch tl("sn_mamba_in", s, 2.0 * npts * H * 2 * E);
+    hipLaunchKernelGGL(sn_mamba_in_kernel, dim3(blocks_of(npts), 4), dim3(256), 0, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
+                       w->winT, m.xz);
+    FNSSL_CHECK_LAUNCH("sn_mamba_in_kernel");
+  }
+  {
+    fnssl::TimedLaunch tl("sn_mamba_xproj", s, 2.0 * npts * E * (XP - 2 + KC));
+    hipLaunchKernelGGL(sn_mamba_xproj_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
+                       w->wxT, carry ? conv_state : nullptr, m.dbl);
+    FNSSL_CHECK_LAUNCH("sn_mamba_xproj_kernel");
+  }
+  {
+    fnssl::TimedLaunch tl("sn_mamba_scan", s, (double)npts * E * (7.0 * NST + 2 * RK + 2 * KC));
+    hipLaunchKernelGGL(sn_mamba_scan_kernel, dim3((unsigned)nseq), dim3(E), 0, s, m.xz, m.dbl, nt, w->conv_w, w->conv_b,
+                       w->wdt, w->bdt, w->a, w->d, conv_state, ssm_state, carry, m.y);
+    FNSSL_CHECK_LAUNCH("sn_mamba_scan_kernel");
+  }
+  {
+    const int nt2 = nt / time_pool;
+    const long long nout = nseq * nt2;
+    if (nout > 0) {
+      fnssl::TimedLaunch tl("sn_mamba_out", s, 2.0 * nout * E * H);
+      hipLaunchKernelGGL(sn_mamba_out_kernel, dim3(blocks_of(nout), 2), dim3(256), 0, s, m.y, *x, nt, nt2, nf, time_pool,
+                         nout, w->woT, residual, out, o_sb, o_st, o_sf);
+      FNSSL_CHECK_LAUNCH("sn_mamba_out_kernel");
+    }
+  }
+  return FNSSL_OK;
+}
+
+int fnssl_sn_head(const fnssl_btf_view* x, int nb, int nt2, int nfc, const float* wfiP, const float* bfiP,
+                  const float* wdT, const float* bd, float* out, void* stream) {
+  FNSSL_REQUIRE(view_ok(x), "sn_head: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(wfiP && bfiP && wdT && bd && out && reinterpret_cast<size_t>(out) % 16 == 0, "sn_head: null / unaligned pointer");
+  FNSSL_REQUIRE(nb > 0 && nfc > 0 && nt2 >= 0, "sn_head: empty problem");
+  if (nt2 == 0) return FNSSL_OK;
+  const long long npts = (long long)nb * nt2 * nfc;
+  hipStream_t s = fnssl::as_stream(stream);
+  fnssl::TimedLaunch tl("sn_head", s, 2.0 * npts * 16 * (DO * H + DO * DO));
+  hipLaunchKernelGGL(sn_head_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, *x, nt2, nfc, npts, wfiP, bfiP, wdT, bd, out);
+  FNSSL_CHECK_LAUNCH("sn_head_kernel");
+  return FNSSL_OK;
+}
+
+// ---- whole network ------------------------------------------------------------------------------------------
+
+static size_t sn_act_floats(int nb, int nf, int nt, int ratio) {
+  const size_t fr = (size_t)nb * nt;
+  const int nfc = nf / 16, nt2 = nt / ratio;
+  return fr * nf * H + fr * (nf / 2) * H + fr * nfc * H + (size_t)nb * (nt2 > 0 ? nt2 : 1) * nfc * H;
+}
+
+size_t fnssl_sn_forward_workspace_bytes(int nb, int nf, int nt) {
+  if (nb <= 0 || nf <= 0 || nt <= 0) return 0;
+  return (sn_act_floats(nb, nf, nt, 5) + mamba_ws_floats((long long)nb * nt * (nf / 16))) * sizeof(float) + 256;
+}
+
+size_t fnssl_sn_state_floats(const fnssl_sn_net* net, int nb, int nf) {
+  if (!net || nb <= 0 || nf <= 0) return 0;
+  const size_t nseq = (size_t)nb * (nf / 16);
+  return (size_t)nb * net->dim_input * nf * (KE - 1) + (size_t)net->num_layers * 2 * nseq * (3 * E + E * NST);
+}
+
+int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, long long x_sc, long long x_sf,
+                     long long x_st, int nb, int nf, int nt, float* state, int carry, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  FNSSL_REQUIRE(net && x && out, "sn_forward: null pointer");
+  FNSSL_REQUIRE(net->num_layers >= 1 && net->num_layers <= FNSSL_SN_MAX_LAYERS, "sn_forward: 1..%d layers", FNSSL_SN_MAX_LAYERS);
+  FNSSL_REQUIRE(net->time_ratio >= 1 && net->time_ratio <= 16, "sn_forward: time_ratio in [1, 16]");
+  FNSSL_REQUIRE(nb > 0 && nt > 0, "sn_forward: empty problem");
+  FNSSL_REQUIRE(nf == 128 || nf == 256, "sn_forward: num_freqs must be 128 or 256 (got %d)", nf);
+  FNSSL_REQUIRE(!carry || state, "sn_forward: carry needs the state buffer");
+  FNSSL_REQUIRE(!state || nt % net->time_ratio == 0, "sn_forward: streaming chunks must be multiples of %d frames", net->time_ratio);
+  const int ratio = net->time_ratio, nfc = nf / 16, nt2 = nt / ratio;
+  const size_t need = (sn_act_floats(nb, nf, nt, ratio) + mamba_ws_floats((long long)nb * nt * nfc)) * sizeof(float) + 256;
+  if (!workspace || workspace_bytes < need) {
+    fnssl::set_error("sn_forward: workspace %zu < %zu bytes", workspace_bytes, need);
+    return FNSSL_E_WORKSPACE;
+  }
+  float* base = reinterpret_cast<float*>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
+  const size_t fr = (size_t)nb * nt;
+  float* a0 = base;                              // [nb, nt, nf, H]
+  float* a1 = a0 + fr * nf * H;                  // [nb, nt, nf/2, H]
+  float* a2 = a1 + fr * (nf / 2) * H;            // [nb, nt, nfc, H]
+  float* a3 = a2 + fr * nfc * H;                 // [nb, nt2, nfc, H]
+  float* mws = a3 + (size_t)nb * (nt2 > 0 ? nt2 : 1) * nfc * H;
+  const size_t mws_bytes = mamba_ws_floats((long long)nb * nt * nfc) * sizeof(float);
+  const size_t nseq = (size_t)nb * nfc;
+  float* st_enc = state;
+  float* st_m = state ? state + (size_t)nb * net->dim_input * nf * (KE - 1) : nullptr;
+  auto conv_st = [&](int l, int j) { return st_m ? st_m + ((size_t)l * 2 + j) * nseq * (3 * E + E * NST) : nullptr; };
+  auto ssm_st = [&](int l, int j) { return st_m ? conv_st(l, j) + nseq * 3 * E : nullptr; };
+  int rc;
+#define FNSSL_SN_TRY(call) \
+  do {                     \
+    rc = (call);           \
+    if (rc != FNSSL_OK) return rc; \
+  } while (0)
+  auto strides = [&](int f, long long& sb, long long& st, long long& sf, int t) {
+    sf = H;
+    st = (long long)f * H;
+    sb = (long long)t * f * H;
+  };
+  long long sb, st, sf, sb2, st2, sf2;
+  strides(nf, sb, st, sf, nt);
+  FNSSL_SN_TRY(fnssl_sn_encoder(x, x_sb, x_sc, x_sf, x_st, nb, net->dim_input, nf, nt, net->enc_wT, net->enc_b,
+                                carry ? st_enc : nullptr, st_enc, a0, sb, st, sf, stream));
+  const fnssl_sn_layer* L = &net->layers[0];
+  fnssl_btf_view v0 = {a0, sb, st, sf};
+  strides(nf / 2, sb2, st2, sf2, nt);
+  FNSSL_SN_TRY(fnssl_sn_fconv(&v0, nb, nt, nf, &L->fconv1, 1, 2, a1, sb2, st2, sf2, stream));
+  fnssl_btf_view v1 = {a1, sb2, st2, sf2};
+  FNSSL_SN_TRY(fnssl_sn_full(&v1, nb, nt, nf / 2, &L->full, 1, a1, sb2, st2, sf2, stream));
+  strides(nfc, sb, st, sf, nt);
+  FNSSL_SN_TRY(fnssl_sn_fconv(&v1, nb, nt, nf / 2, &L->fconv2, 1, 8, a2, sb, st, sf, stream));
+  fnssl_btf_view v2 = {a2, sb, st, sf};
+  FNSSL_SN_TRY(fnssl_sn_mamba(&v2, nb, nt, nfc, &L->mamba[0], 1, 1, conv_st(0, 0), ssm_st(0, 0), carry, a2, sb, st, sf,
+                              mws, mws_bytes, stream));
+  if (nt2 == 0) return FNSSL_OK;                 // fewer frames than one pooled step: empty output (AvgPool floor)
+  strides(nfc, sb2, st2, sf2, nt2);
+  FNSSL_SN_TRY(fnssl_sn_mamba(&v2, nb, nt, nfc, &L->mamba[1], 1, ratio, conv_st(0, 1), ssm_st(0, 1), carry, a3, sb2, st2,
+                              sf2, mws, mws_bytes, stream));
+  fnssl_btf_view v3 = {a3, sb2, st2, sf2};
+  for (int l = 1; l < net->num_layers; ++l) {
+    L = &net->layers[l];
+    FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv1, 1, 1, a3, sb2, st2, sf2, stream));
+    FNSSL_SN_TRY(fnssl_sn_full(&v3, nb, nt2, nfc, &L->full, 1, a3, sb2, st2, sf2, stream));
+    FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv2, 1, 1, a3, sb2, st2, sf2, stream));
+    for (int j = 0; j < 2; ++j)
+      FNSSL_SN_TRY(fnssl_sn_mamba(&v3, nb, nt2, nfc, &L->mamba[j], 1, 1, conv_st(l, j), ssm_st(l, j), carry, a3, sb2, st2,
+                                  sf2, mws, mws_bytes, stream));
+  }
+#undef FNSSL_SN_TRY
+  return fnssl_sn_head(&v3, nb, nt2, nfc, net->wfiP, net->bfiP, net->wdT, net->bd, out, stream);
+}
+
+}  // extern "C"

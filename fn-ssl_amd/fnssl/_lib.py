@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -34,6 +34,8 @@ SYMBOLS = [
     "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
+    "fnssl_sn_layernorm", "fnssl_sn_encoder", "fnssl_sn_fconv", "fnssl_sn_full", "fnssl_sn_mamba_workspace_bytes",
+    "fnssl_sn_mamba", "fnssl_sn_head", "fnssl_sn_forward_workspace_bytes", "fnssl_sn_state_floats", "fnssl_sn_forward",
 ]
 
 
@@ -82,6 +84,33 @@ class Net(C.Structure):
         ("doa_wt", C.c_void_p), ("doa_b", C.c_void_p),
         ("input_size", C.c_int), ("is_online", C.c_int),
     ]
+
+
+SN_MAX_LAYERS = 16
+
+
+class SnFconvW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_w", "ln_b", "wT", "bias", "prelu")]
+
+
+class SnFullW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_w", "ln_b", "wsT", "bs", "wfT", "bf", "wuT", "bu")]
+
+
+class SnMambaW(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln_w", "ln_b", "winT", "conv_w", "conv_b", "wxT", "wdt", "bdt", "a", "d",
+                                          "woT")]
+
+
+class SnLayer(C.Structure):
+    _fields_ = [("fconv1", SnFconvW), ("fconv2", SnFconvW), ("full", SnFullW), ("mamba", SnMambaW * 2)]
+
+
+class SnNet(C.Structure):
+    _fields_ = [("dim_input", C.c_int), ("num_layers", C.c_int), ("time_ratio", C.c_int),
+                ("enc_wT", C.c_void_p), ("enc_b", C.c_void_p),
+                ("layers", SnLayer * SN_MAX_LAYERS),
+                ("wfiP", C.c_void_p), ("bfiP", C.c_void_p), ("wdT", C.c_void_p), ("bd", C.c_void_p)]
 
 
 _lib = None
@@ -162,6 +191,20 @@ def load():
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz
     lib.fnssl_forward.argtypes = [C.POINTER(Net), vp, i, i, i, vp, vp, sz, i, vp]
+    PV = C.POINTER(BtfView)
+    lib.fnssl_sn_layernorm.argtypes = [vp, ll, i, vp, vp, f, vp, vp]
+    lib.fnssl_sn_encoder.argtypes = [vp, ll, ll, ll, ll, i, i, i, i, vp, vp, vp, vp, vp, ll, ll, ll, vp]
+    lib.fnssl_sn_fconv.argtypes = [PV, i, i, i, C.POINTER(SnFconvW), i, i, vp, ll, ll, ll, vp]
+    lib.fnssl_sn_full.argtypes = [PV, i, i, i, C.POINTER(SnFullW), i, vp, ll, ll, ll, vp]
+    lib.fnssl_sn_mamba_workspace_bytes.argtypes = [i, i, i]
+    lib.fnssl_sn_mamba_workspace_bytes.restype = sz
+    lib.fnssl_sn_mamba.argtypes = [PV, i, i, i, C.POINTER(SnMambaW), i, i, vp, vp, i, vp, ll, ll, ll, vp, sz, vp]
+    lib.fnssl_sn_head.argtypes = [PV, i, i, i, vp, vp, vp, vp, vp, vp]
+    lib.fnssl_sn_forward_workspace_bytes.argtypes = [i, i, i]
+    lib.fnssl_sn_forward_workspace_bytes.restype = sz
+    lib.fnssl_sn_state_floats.argtypes = [C.POINTER(SnNet), i, i]
+    lib.fnssl_sn_state_floats.restype = sz
+    lib.fnssl_sn_forward.argtypes = [C.POINTER(SnNet), vp, ll, ll, ll, ll, i, i, i, vp, i, vp, vp, sz, vp]
     lib.fnssl_timing_enable.argtypes = [i]
     lib.fnssl_timing_collect.argtypes = [i, vp, vp, vp, vp]
     if lib.fnssl_abi_version() != ABI_VERSION:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import _need_dev, _ptr, _stream
+from .ops import _need_dev, _ptr, _stream, on_device
 
 
 def pair_list(nmic: int, ch_mode: str):
@@ -53,6 +53,7 @@ def template_bank(template: np.ndarray):
     return np.ascontiguousarray(t), cand
 
 
+@on_device
 def localize(pred: torch.Tensor, bank: torch.Tensor, nb: int, max_num_sources: int = 1,
              source_num_mode: str = "kNum"):
     """Iterative detection/localisation on device.

@@ -7,6 +7,7 @@ rejected (``RuntimeError``), mirroring how the reference surfaces shape errors.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 
 import numpy as np
 import torch
@@ -30,7 +31,35 @@ def _need_dev(*tensors):
             raise RuntimeError("fnssl: expected float32, got %s" % t.dtype)
 
 
+def _first_device(objs):
+    for a in objs:
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, (list, tuple)):
+            d = _first_device(a)
+            if d is not None:
+                return d
+    return None
+
+
+def on_device(fn):
+    """Run ``fn`` with the HIP current device set to the device of its first ROCm tensor argument, so that the
+    kernels launch on that device and ``_stream()`` is that device's current stream (a model on ``cuda:1`` must
+    not launch on device 0's stream).  Without a device tensor the call goes through unchanged (and the op's own
+    ``_need_dev`` raises)."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = _first_device(args) or _first_device(kwargs.values())
+        if dev is None:
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
+
+
 def _stream():
+    """The current HIP stream of the current device (ops run under ``on_device``)."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -49,6 +78,7 @@ def num_pairs(nch: int, ch_mode: str) -> int:
     return _lib.load().fnssl_num_pairs(int(nch), CH_MODE[ch_mode])
 
 
+@on_device
 def stft(sig: torch.Tensor):
     """sig [nb, ns, nch] -> (spec [nb, nch, nt, 257, 2], magsum [nb, nch, nt]).  Module.py:48-68."""
     _need_dev(sig)
@@ -82,6 +112,7 @@ def forgetting_coefs(nt: int, sample_length: int, device):
     return _coef_cache[key]
 
 
+@on_device
 def pair_features(spec, magsum, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int = 298,
                   layout: int = 0):
     """main.py:207-225.  Returns (x, mu); x is [nb', nt, 256, 4] (layout 0) or [nb', 4, 256, nt] (layout 1)."""
@@ -107,6 +138,7 @@ def preprocess(sig, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int =
     return x
 
 
+@on_device
 def array_features(spec, magsum, eps: float = 1e-6, sample_length: int = 280, layout: int = 1):
     """IPDnet's all-channel features (runIPDnetOn.py:246-254).  Returns (x, mu); x is
     [nb, 2*nch, 256, nt] (layout 1, the reference's tensor) or [nb, nt, 256, 2*nch] (layout 0)."""
@@ -128,6 +160,7 @@ def preprocess_array(sig, eps: float = 1e-6, sample_length: int = 280, layout: i
     return x
 
 
+@on_device
 def nchw_to_seq(x):
     """[n, c, nf, nt] -> [n, nt, nf, c] (Model.py:73) as a contiguous tensor."""
     _need_dev(x)
@@ -205,7 +238,14 @@ _ws_cache = {}
 
 
 def _workspace(nbytes: int, device, tag: str):
-    key = (str(device), tag)
+    """Scratch buffer for one op, cached per (device, stream, tag): two forwards issued on different HIP streams
+    never share scratch, and on one stream the ops that use a tag are ordered anyway.  A buffer that has to
+    grow is replaced; the old one goes back to torch's caching allocator, which keeps it reserved for this
+    stream's pending work."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -217,6 +257,7 @@ def release_workspaces():
     _ws_cache.clear()
 
 
+@on_device
 def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
                reserve=None, carry_workspace=None, carry=False, bf16=False):
     """One (bi)LSTM layer over strided views.
@@ -321,6 +362,7 @@ def pack_lstm_bwd_host(w_ih, w_hh, c0g: int) -> np.ndarray:
     return out
 
 
+@on_device
 def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: int):
     """Back-propagation through time of one (bi)LSTM layer.
 
@@ -380,6 +422,7 @@ def pack_conv3x3(weight, ca: int, cb: int, device, bf16: bool = False) -> torch.
     return torch.from_numpy(out).to(device)
 
 
+@on_device
 def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none", bf16: bool = False):
     """Causal 3x3 conv over (bin, time) of the channel concatenation [xa | xb].
 
@@ -407,6 +450,7 @@ def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none", bf16: bool = Fa
     return out
 
 
+@on_device
 def avgpool_time(x, k: int):
     """[nb, nf, nt, C] channels-last -> [nb, nf, nt // k, C] (AvgPool2d((1, k)) of the NCHW view)."""
     _need_dev(x)
@@ -421,6 +465,7 @@ def avgpool_time(x, k: int):
 # --------------------------------------------------------------------------- #
 # head / whole network
 # --------------------------------------------------------------------------- #
+@on_device
 def head(x, w, b):
     """x [nb, nf, nt, 256] -> [nb, nt//12, 2*nf]  (Model.py:79-87)."""
     _need_dev(x, w, b)
@@ -434,6 +479,7 @@ def head(x, w, b):
     return out
 
 
+@on_device
 def linear(x, wt, b):
     """y = x @ wt + b with wt = weight^T [k, n_out]."""
     _need_dev(x, wt, b)
@@ -483,6 +529,7 @@ class DeviceNet:
         t = a.detach() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a, dtype=np.float32))
         return t.to(self.device, torch.float32).contiguous()
 
+    @on_device
     def forward(self, x0: torch.Tensor, chunk_pairs: int = 0) -> torch.Tensor:
         """x0 [nb', nt, nf, input_size] -> [nb', nt//12, 2*nf] (or [.., 180] with the DOA layer)."""
         _need_dev(x0)

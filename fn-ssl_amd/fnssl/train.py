@@ -55,6 +55,7 @@ def _btf(t):
     return BtfView(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
 
 
+@ops.on_device
 def combine(out, masked=(), plain=(), seed32=None, b0=0):
     """out = keep_scale(seed32) * sum(masked) + sum(plain); all logical [b, t, f, C]."""
     nb, nt, nf, c = out.shape
@@ -74,8 +75,9 @@ def dropout_scale(shape, seed32, device, b0=0):
     """The keep-scale tensor itself, logical [b, t, f, C] contiguous (tests / debugging)."""
     nb, nt, nf, c = shape
     out = torch.empty(shape, dtype=torch.float32, device=device)
-    check(_lib.load().fnssl_dropout_scale(out.data_ptr(), out.numel(), seed32, b0 * nt * nf * c, ops._stream()),
-          "dropout_scale")
+    with torch.cuda.device(out.device):
+        check(_lib.load().fnssl_dropout_scale(out.data_ptr(), out.numel(), seed32, b0 * nt * nf * c, ops._stream()),
+              "dropout_scale")
     return out
 
 
@@ -345,6 +347,7 @@ class TrainEngine:
         return pred
 
     # ------------------------------------------------------------------ public API
+    @ops.on_device
     def step(self, x, gt_ipd, sync_loss=True):
         """One optimisation step.  x [nb*np, 4, nf, nt] features (data_preprocess output), gt_ipd
         [nb, nt//12, 2*nf, np] targets, both on the device.  Returns the loss (float, or the device scalar when

@@ -57,6 +57,7 @@ class MyModel(_Base):
         loss = self._engine().step(x, gt_batch['ipd'].to(self.dev), sync_loss=False)
         return {"loss": loss.detach().clone().reshape(())}
 
+    @ops.on_device
     def cal_loss(self, pred_batch=None, gt_batch=None):
         """main.py:191-198 on device: MSE of the re-batched prediction (no gradient is recorded)."""
         pred = pred_batch.contiguous()
@@ -94,6 +95,7 @@ class MyModel(_Base):
         return data
 
     @torch.no_grad()
+    @ops.on_device
     def predict_step(self, batch, batch_idx: int = 0):
         """batch [nb, nch, ns] -> preds [nb*np, nt//12, 512]  (main.py:184-189).
 

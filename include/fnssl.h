@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 3
+#define FNSSL_ABI_VERSION 4
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -372,6 +372,142 @@ size_t fnssl_forward_workspace_bytes(int nb, int nf, int nt, int is_online, int 
 int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
                   float* out, void* workspace, size_t workspace_bytes, int chunk_pairs,
                   void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* IPDnet2 / OnlineSpatialNet (SURVEY.md 8 rows a13 + f4; reference IPDnet2/IPDnet2.py) */
+/* ------------------------------------------------------------------------- */
+/*
+ * Built for the network the reference ships (run_IPDnet2.py:103-119): dim_hidden H = 96, dim_squeeze 8,
+ * f-conv kernel 5 / 8 groups, encoder kernel 5, attention 'mamba(16,4)' (d_inner E = 192, d_state 16,
+ * d_conv 4, dt_rank 6), dim_output 16, frequency compression 2 then 8 (= 16), time compression in layer 0.
+ * dim_input (2 x mics) and the numbers of bins / frames / layers are free.
+ *
+ * Activations are logical [B, T, F, H] tensors given as fnssl_btf_view structs: element (b, t, f, h) at
+ * p[b*sb + t*st + f*sf + h], H contiguous, strides in floats, multiples of 4, 16-byte aligned base; the
+ * reference's [B, F, T, H] tensors are the same thing with other strides.  Every kernel maps one THREAD to one
+ * time-frequency point; the weights of the small dense layers are read as wave-uniform scalars, so they are
+ * passed TRANSPOSED ([in][out], noted per field) — fnssl.spatialnet does the transposes once per model.
+ */
+
+/* y[row, :] = LayerNorm(x[row, :]) * w + b over h channels (arch/base/norm.py:11-27); one wave per row,
+ * mean / variance by wavefront reduction.  h <= 1024. */
+int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, const float* b, float eps,
+                       float* y, void* stream);
+
+/*
+ * Replaces OnlineSpatialNet.encoder = CausalConv1d(cin -> 96, k = 5, look_ahead 0) along time
+ * (IPDnet2.py:45-82, call :335).
+ *   x          network input, element (b, c, f, t) at x[b*x_sb + c*x_sc + f*x_sf + t*x_st]
+ *              (the reference's [B, C, F, T] tensor: x_st = 1)
+ *   wT         [cin][5][96] = weight[o, c, k] transposed;  bias [96]
+ *   state_in   [nb, cin, nf, 4]: the 4 input frames before this chunk (NULL: zero left padding, :69)
+ *   state_out  [nb, cin, nf, 4]: written with the last 4 input frames (NULL: not wanted)
+ *   out        view [nb, nt, nf, 96]
+ */
+int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x_sf, long long x_st,
+                     int nb, int cin, int nf, int nt, const float* wT, const float* bias,
+                     const float* state_in, float* state_out,
+                     float* out, long long o_sb, long long o_st, long long o_sf, void* stream);
+
+/* One f-conv branch (IPDnet2.py:105-109): LayerNorm(96) -> Conv1d(96, 96, k 5, groups 8, 'same' zero padding)
+ * along F -> PReLU(96). */
+typedef struct {
+  const float *ln_w, *ln_b;   /* [96]                                                              */
+  const float* wT;            /* [8 groups][5 taps][12 in][12 out] = weight[g*12+o, ci, tap]         */
+  const float* bias;          /* [96]                                                              */
+  const float* prelu;         /* [96]                                                              */
+} fnssl_sn_fconv_w;
+
+/*
+ * Replaces `x + self._fconv(ml, x)` (IPDnet2.py:146,151,222-233) and, with pool > 1, the AvgPool over
+ * frequency that follows in the first layer (:147-148, :152-153).
+ *   x [nb, nt, nf, 96] (nf a power of two, 8 <= nf <= 256);  residual 0: only the branch
+ *   pool 1, 2 or 8;  out view [nb, nt, nf / pool, 96] (may alias x when pool == 1)
+ */
+int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_fconv_w* w,
+                   int residual, int pool, float* out, long long o_sb, long long o_st, long long o_sf,
+                   void* stream);
+
+/* The full-band branch (IPDnet2.py:111-118): LayerNorm -> Conv1d(96 -> 8, 1) + SiLU -> Linear(nf, nf) over F ->
+ * Conv1d(8 -> 96, 1) + SiLU. */
+typedef struct {
+  const float *ln_w, *ln_b;   /* [96]                          */
+  const float *wsT, *bs;      /* [96][8] = squeeze weight^T, [8] */
+  const float *wfT, *bf;      /* [nf][nf] = full.weight^T, [nf]  */
+  const float *wuT, *bu;      /* [8][96] = unsqueeze weight^T, [96] */
+} fnssl_sn_full_w;
+
+/* Replaces `x + self._full(x)` (IPDnet2.py:150,235-253; dropout_full off).  nf a power of two, 8 <= nf <= 256.
+ * out may alias x. */
+int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_full_w* w, int residual,
+                  float* out, long long o_sb, long long o_st, long long o_sf, void* stream);
+
+/* One Mamba block with its LayerNorm (IPDnet2.py:126-132; mamba_ssm.Mamba(d_model 96, d_state 16, d_conv 4)). */
+typedef struct {
+  const float *ln_w, *ln_b;   /* [96]                                                   */
+  const float* winT;          /* [96][384]  = in_proj.weight^T  (x half first, then z)    */
+  const float *conv_w, *conv_b; /* [192][4], [192]   depthwise causal conv                */
+  const float* wxT;           /* [192][40]  = x_proj.weight^T, columns (dt 6 | B 16 | C 16 | 2 zero) */
+  const float *wdt, *bdt;     /* [192][6], [192]   dt_proj                              */
+  const float* a;             /* [192][16]  = -exp(A_log)                               */
+  const float* d;             /* [192]                                                  */
+  const float* woT;           /* [192][96]  = out_proj.weight^T                         */
+} fnssl_sn_mamba_w;
+
+size_t fnssl_sn_mamba_workspace_bytes(int nb, int nt, int nf);
+
+/*
+ * Replaces `x + self._mamba(x, mamba, norm, dropout)` (IPDnet2.py:155-162, 166-181) and, with time_pool > 1, the
+ * time pooling after the layer (:345-349; applied to x + branch, using that out_proj is linear):
+ * LayerNorm, in_proj, causal depthwise conv + SiLU, x_proj, dt_proj + softplus, selective scan
+ *   h_t = exp(dt_t A) h_{t-1} + dt_t B_t u_t,  y_t = C_t . h_t + D u_t,  gate by SiLU(z), out_proj
+ * along T for each of the nb*nf sequences.  (PARITY UNPINNED: the published algorithm, see oracle/ipdnet2_oracle.py.)
+ *   conv_state [nb*nf, 3, 192], ssm_state [nb*nf, 192, 16]: NULL, or carried state — read when carry != 0,
+ *   always written (sequence index = b*nf + f)
+ *   out view [nb, nt / time_pool, nf, 96] (may alias x when time_pool == 1)
+ */
+int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_mamba_w* w, int residual,
+                   int time_pool, float* conv_state, float* ssm_state, int carry,
+                   float* out, long long o_sb, long long o_st, long long o_sf,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Replaces FreqInverse + tanh + decoder + the output re-ordering (IPDnet2.py:23-43, 355-364).
+ *   x     [nb, nt2, nfc, 96] (nfc compressed bins; nf = 16 * nfc)
+ *   wfiP  [16 r][16 o][96] = trans2.weight[o*16 + r, h];  bfiP [16 r][16 o] = trans2.bias[o*16 + r]
+ *   wdT   [16][16] = decoder.weight^T ([in][out]), bd [16]
+ *   out   [nb, nt2, 2*nf, 4, 2] contiguous
+ */
+int fnssl_sn_head(const fnssl_btf_view* x, int nb, int nt2, int nfc, const float* wfiP, const float* bfiP,
+                  const float* wdT, const float* bd, float* out, void* stream);
+
+#define FNSSL_SN_MAX_LAYERS 16
+typedef struct {
+  fnssl_sn_fconv_w fconv1, fconv2;
+  fnssl_sn_full_w full;
+  fnssl_sn_mamba_w mamba[2];       /* mhsa, tconvffn */
+} fnssl_sn_layer;
+
+typedef struct {
+  int dim_input, num_layers, time_ratio;   /* time_ratio: 5 (time_compression_layer = 0)  */
+  const float *enc_wT, *enc_b;
+  fnssl_sn_layer layers[FNSSL_SN_MAX_LAYERS];
+  const float *wfiP, *bfiP, *wdT, *bd;
+} fnssl_sn_net;
+
+size_t fnssl_sn_forward_workspace_bytes(int nb, int nf, int nt);
+/* floats of the carried state of a whole network (encoder frames + per Mamba block conv / ssm state) */
+size_t fnssl_sn_state_floats(const fnssl_sn_net* net, int nb, int nf);
+
+/*
+ * Replaces OnlineSpatialNet.forward (IPDnet2.py:331-368).
+ *   x [nb, dim_input, nf, nt] with the given strides -> out [nb, nt / 5, 2*nf, 4, 2]
+ *   state: NULL (whole utterance), or fnssl_sn_state_floats() floats carried between chunks (read when
+ *   carry != 0, always written); streaming chunks must be multiples of time_ratio frames.
+ */
+int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, long long x_sc, long long x_sf,
+                     long long x_st, int nb, int nf, int nt, float* state, int carry, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Measurement hooks (bench.py: per-kernel HIP-event timing on the launch stream) */

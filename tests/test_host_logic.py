@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.fnssl_abi_version() == 3
+    assert lib.fnssl_abi_version() == 4
 
 
 def test_shape_helpers_match_reference_formulas():
@@ -118,3 +118,45 @@ def test_ipdnet_dropin_state_dict_matches_reference_names():
         assert got == want
     with __import__("pytest").raises(RuntimeError, match="eval"):
         net(__import__("torch").zeros(1, 8, 4, 12))
+
+
+def test_spatialnet_entry_points_validate_before_touching_the_device():
+    """fnssl_sn_* (IPDnet2 row): bad shapes / null pointers are refused with a message, no launch."""
+    lib = _lib.load()
+    v = _lib.BtfView(0, 0, 0, 0)
+    w = _lib.SnFconvW()
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 1, None, 0, 0, 0, None) == -1
+    assert b"aligned" in lib.fnssl_last_error() or b"null" in lib.fnssl_last_error()
+    buf = np.zeros(64, np.float32)
+    v = _lib.BtfView(buf.ctypes.data // 16 * 16, 96, 96, 96)
+    for name in ("ln_w", "ln_b", "wT", "bias", "prelu"):
+        setattr(w, name, buf.ctypes.data)
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 24, C.byref(w), 1, 1, v.p, 96, 96, 96, None) == -1   # nf not 2^k
+    assert b"power of two" in lib.fnssl_last_error()
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 3, v.p, 96, 96, 96, None) == -1   # pool 3
+    assert lib.fnssl_sn_mamba_workspace_bytes(2, 10, 16) == 2 * 10 * 16 * (384 + 40 + 192) * 4
+    assert lib.fnssl_sn_forward_workspace_bytes(0, 256, 10) == 0
+    net = _lib.SnNet()
+    net.dim_input, net.num_layers, net.time_ratio = 10, 8, 5
+    assert lib.fnssl_sn_state_floats(C.byref(net), 2, 256) == 2 * 10 * 256 * 4 + 8 * 2 * 32 * (3 * 192 + 192 * 16)
+    assert lib.fnssl_sn_forward(C.byref(net), buf.ctypes.data, 0, 0, 0, 1, 1, 200, 10, None, 0, buf.ctypes.data, None, 0,
+                                None) == -1
+    assert b"num_freqs" in lib.fnssl_last_error()
+
+
+def test_ipdnet2_dropin_keeps_reference_names_and_rejects_cpu():
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("fnssl_ipdnet2_dropin_cpu",
+                                                  os.path.join(ROOT, "fn-ssl_amd", "IPDnet2", "IPDnet2.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    net = M.OnlineSpatialNet(dim_input=10, dim_output=16, num_layers=2, dim_hidden=96, num_heads=4, dim_squeeze=8,
+                             num_freqs=256, attention="mamba(16,4)", time_compression_layer=0).eval()
+    names = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert names == dict(W.ipdnet2_param_shapes(num_layers=2))   # = the reference's keys (G14 was loaded strictly)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 10, 256, 10))                         # no CPU path
+    with pytest.raises(NotImplementedError):
+        M.OnlineSpatialNet(dim_input=10, dim_output=16, num_layers=2, dim_hidden=96, dim_squeeze=8, num_freqs=256,
+                           attention="mhsa(251)")

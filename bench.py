@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
-"""Headline benchmark: DP-IPD forward throughput on BASELINE config 2
+"""Driver benchmark.  Default = the headline: DP-IPD forward throughput on BASELINE config 2
 (4 mics, 257 bins x 300 frames, 32 utterances = 192 mic pairs per GPU, fp32).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path over one synthetic batch already
-resident in HBM: waveforms -> STFT -> pair features -> 3 x (full-band BiLSTM,
-narrow-band LSTM) -> DP-IPD head.  Every rank runs the same per-GPU batch (weak
-scaling; utterances are independent, so there is no data-path collective).
-Rank 0 prints ONE JSON line; `value` is utterance-frames per second over all
-ranks.  The line also carries
-  roofline     : fp32-MFMA roofline of the dominant kernel (narrow-band LSTM),
-                 timed with HIP events on the launch stream inside the timed region;
-  cpu_baseline : the PyTorch-CPU restatement of the reference (oracle/torch_ref.py)
-                 timed on this host on a bounded sample (N=1, rank 0 only).
+--config picks the BASELINE.json configuration (configs[1] = 2 is the metric the headline is quoted on; 1 is the
+reference's own CPU case and only a parity test):
+  2  FN-SSL 4-mic forward, batch 32, fp32                (waveforms -> STFT -> features -> 3 FN blocks -> DP-IPD)
+  3  IPDnet fixed-array 8-mic forward, batch 64, bf16    (waveforms -> features -> 2 FN blocks -> causal conv head)
+  4  FN-SSL training step, 32 two-mic utterances / GPU   (features -> forward -> MSE -> BPTT -> all-reduce -> Adam)
+  5  IPDnet2 (OnlineSpatialNet) 15-mic online forward    (features [B, 30, 256, T] -> DP-IPD; parity unpinned: Mamba)
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM.  Every rank runs the same
+per-GPU batch (weak scaling; utterances are independent: no data-path collective, config 4 has the one gradient
+all-reduce).  K steps are timed between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line whose
+`value` is utterance-frames per second over all ranks.  The line also carries
+  roofline     : the dominant kernel against its roof, timed with HIP events on the launch stream inside the timed
+                 region (`frontend`: the STFT + feature kernels against the HBM roof, config 2);
+  cpu_baseline : the CPU restatement of the reference (oracle/) timed on this host on a bounded sample
+                 (N = 1, rank 0 only), and `parity`: the same sample through the HIP path vs that CPU output.
+A failed parity check nulls `value` and exits 1.
 """
 import argparse
+import importlib.util
 import json
 import os
 import sys
@@ -31,7 +38,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
+PEAK_HBM_GBS = 8000.0
 FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only, by is_online
+TRAFFIC_JSON = os.path.join("profiles", "r01", "hbm_traffic_lstm_h256.json")
 
 
 def log(msg):
@@ -53,23 +63,391 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+def load_module(name, *path):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, *path))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def kernel_roof(kern, name, label, peak, unit_scale=1e12, traffic=None, traffic_source=None):
+    k = kern.get(name)
+    if not k or k["ms"] <= 0 or not k["flops"]:
+        return None
+    achieved = k["flops"] / (k["ms"] * 1e-3) / unit_scale
+    return {"bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+            "launches": k["count"], "avg_ms": round(k["ms"] / max(1, k["count"]), 3),
+            "flop_per_launch": k["flops"] / max(1, k["count"])}
+
+
+def parity_of(got, want, rtol, atol, what):
+    err = (got - want).abs()
+    p = {"max_abs_err": float(err.max()), "rtol": rtol, "atol": atol, "sample": what,
+         "ok": bool((err <= atol + rtol * want.abs()).all())}
+    log("parity vs CPU reference (%s): max abs err %.3g ok=%s" % (what, p["max_abs_err"], p["ok"]))
+    return p
+
+
+# ------------------------------------------------------------------------------------------------------------ #
+# config 2: FN-SSL forward (the headline)
+# ------------------------------------------------------------------------------------------------------------ #
+class FnsslForward:
+    def __init__(self, args, dev, rank, world):
+        import predict_step as ps
+        from fnssl import ops
+        from fnssl import weights as W
+        self.args, self.dev, self.ops, self.world = args, dev, ops, world
+        self.online = not args.offline
+        self.nb = args.nb or 32
+        self.sd = W.make_fnssl_state(0, is_online=self.online)
+        model = ps.MyModel(ch_mode=args.ch_mode, device=str(dev))
+        if not self.online:
+            import Model as at_model
+            model.arch = at_model.FN_SSL(is_online=False)
+        model.arch.load_state_dict({k: torch.from_numpy(v) for k, v in self.sd.items()})
+        model.arch.chunk_pairs = args.chunk_pairs
+        self.model = model.to(dev).eval()
+        if args.bf16:
+            self.model.arch.bfloat16()          # optional fast mode, see --bf16
+        ns = 512 + (args.frames - 1) * 256
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234 + rank)
+        self.batch = torch.randn((self.nb, args.nch, ns), generator=gen, device=dev, dtype=torch.float32)
+        self.n_pairs = ops.num_pairs(args.nch, args.ch_mode)
+        self.nt = ops.num_frames(ns)
+        self.frames_per_step = self.nb * self.nt
+        self.flop_per_utt_frame = FLOP_PER_TF_POINT[self.online] * 256 * self.n_pairs
+        self.dtype = "bf16" if args.bf16 else "f32"
+        self.metric = "TF-frames/sec DP-IPD forward, 4-mic 257-bin x 300-frame" + \
+            (" [optional bf16 fast mode: NOT the BASELINE fp32 metric]" if args.bf16 else "")
+        log("rank %d/%d on %s: %d utt x %d mics x %d frames, %d pairs" % (rank, world, torch.cuda.get_device_name(dev),
+                                                                        self.nb, args.nch, self.nt, self.nb * self.n_pairs))
+
+    def step(self):
+        return self.model.predict_step(self.batch, 0)
+
+    def check(self, out):
+        assert tuple(out.shape) == (self.nb * self.n_pairs, self.nt // 12, 512) and bool(torch.isfinite(out).all())
+
+    def config(self):
+        a = self.args
+        return {"workload": "BASELINE configs[1]: FN-SSL (%s) DP-IPD forward, waveform->STFT->features->"
+                            "3x(full-band BiLSTM + narrow-band LSTM)->head; %d utterances/GPU x %d mics ('%s' = %d pairs) "
+                            "x 257 bins x %d frames, fp32; frame = one STFT frame of one utterance"
+                            % ("online" if self.online else "offline", self.nb, a.nch, a.ch_mode, self.n_pairs, self.nt),
+                "utterances_per_gpu": self.nb, "mics": a.nch, "pairs_per_utterance": self.n_pairs, "frames": self.nt,
+                "bins": 257, "parallelism": "dp%d (utterance shards, no collective)" % self.world,
+                "chunk_pairs": a.chunk_pairs, "gflop_per_frame": round(self.flop_per_utt_frame / 1e9, 3)}
+
+    def extra(self, value, kern, steps):
+        ex = {"whole_path_tflops": round(value * self.flop_per_utt_frame / 1e12 / self.world, 2)}
+        # front end against ITS roof (HBM): 4 KB read + 24 KB written per 4-mic 'MM' utterance-frame
+        fe = [kern.get(k) for k in ("stft", "ema", "pack")]
+        if all(fe):
+            ms = sum(k["ms"] for k in fe) / steps
+            by = self.frames_per_step * (self.args.nch * 256 * 4 + self.n_pairs * 4 * 256 * 4)
+            gbs = by / (ms * 1e-3) / 1e9
+            ex["frontend"] = {"bound": "hbm", "kernel": "stft + ema + pack (3 launches: launch-latency sized)",
+                              "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "ms_per_step": round(ms, 4),
+                              "algorithmic_bytes_per_step": by}
+        return ex
+
+    def roofline(self, kern):
+        if not self.online:
+            return kernel_roof(kern, "lstm_h128", "lstm_rec_kernel<H=128> (offline: every layer)", PEAK_FP32_MFMA_TFLOPS)
+        if self.args.bf16:
+            return kernel_roof(kern, "lstm_h256", "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
+                               PEAK_BF16_MFMA_TFLOPS)
+        traffic, src = None, None
+        tpath = os.path.join(ROOT, TRAFFIC_JSON)
+        if os.path.exists(tpath):   # PMC passes cannot run inside the timed region: measured by rocprofv3, committed
+            with open(tpath) as f:
+                traffic = json.load(f).get("bytes_per_launch")
+            src = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, not this run)"
+        return kernel_roof(kern, "lstm_h256", "lstm_rec_kernel<H=256> (narrow-band LSTM)", PEAK_FP32_MFMA_TFLOPS,
+                           traffic=traffic, traffic_source=src)
+
+    def cpu_baseline(self):
+        from oracle import torch_ref as R
+        a = self.args
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        net = R.build(self.sd, self.online)
+        sample = self.batch[:a.cpu_utts].cpu()
+        R.predict_step(net, sample[:, :, :512 + 11 * 256], a.ch_mode)       # warm-up (12 frames)
+        p0 = time.perf_counter()
+        R.predict_step(net, sample[:, :, :512 + 23 * 256], a.ch_mode)
+        per_frame = (time.perf_counter() - p0) / 24.0
+        cpu_frames = int(min(self.nt, max(24, (a.cpu_seconds / max(per_frame, 1e-9)) // 12 * 12)))
+        log("cpu baseline: %d threads, probe %.3f s/frame -> timing %d frames" % (cores, per_frame, cpu_frames))
+        cns = 512 + (cpu_frames - 1) * 256
+        c0 = time.perf_counter()
+        ref_out = R.predict_step(net, sample[:, :, :cns], a.ch_mode)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(a.cpu_utts * cpu_frames / cdt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d utterance(s) x %d mics x %d frames ('%s', %d pairs), PyTorch CPU restatement of the "
+                         "reference (torch.stft + oneDNN nn.LSTM), %d threads, %.1f s"
+                         % (a.cpu_utts, a.nch, cpu_frames, a.ch_mode, a.cpu_utts * self.n_pairs, cores, cdt)}
+        # same-run parity gate on the same waveforms: the narrow-band LSTM is causal, the forgetting-norm recursive
+        # and the full-band BiLSTM runs along frequency only, so a frame prefix is an exact sub-problem
+        got = self.model.predict_step(self.batch[:a.cpu_utts, :, :cns], 0).cpu()
+        rt, at = (2e-2, 4e-3) if a.bf16 else (1e-4, 1e-5)
+        return cpu, parity_of(got, ref_out, rt, at, "%d frames" % cpu_frames)
+
+
+# ------------------------------------------------------------------------------------------------------------ #
+# config 3: IPDnet fixed-array 8-mic, batch 64, bf16
+# ------------------------------------------------------------------------------------------------------------ #
+class IpdnetForward:
+    def __init__(self, args, dev, rank, world):
+        from fnssl import ops
+        from fnssl import weights as W
+        M = load_module("fnssl_ipdnet_dropin", "fn-ssl_amd", "IPDnet", "FixedAarryIPDnet.py")
+        self.args, self.dev, self.ops, self.world = args, dev, ops, world
+        self.nb, self.mics, self.hidden = args.nb or 64, 8, 256
+        self.fp32 = args.fp32
+        isz = 2 * self.mics
+        self.sd = W.make_ipdnet_state(7, isz, self.hidden, 2, True)
+        net = M.IPDnet(input_size=isz, hidden_size=self.hidden, max_track=2, is_online=True).eval()
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.sd.items()})
+        self.net = net.to(dev)
+        if not self.fp32:
+            self.net.bfloat16()
+        g = torch.Generator(device=dev)
+        g.manual_seed(2000 + rank)
+        self.nt = args.frames
+        self.sig = torch.randn((self.nb, 256 * (self.nt + 1), self.mics), generator=g, device=dev) * 0.1
+        self.frames_per_step = self.nb * self.nt
+        self.dtype = "f32" if self.fp32 else "bf16"
+        self.metric = "TF-frames/sec IPDnet DP-IPD forward, 8-mic 257-bin x 300-frame"
+        log("rank %d/%d: IPDnet %d utt x %d mics x %d frames, %s" % (rank, world, self.nb, self.mics, self.nt, self.dtype))
+
+    def step(self):
+        return self.net(self.ops.preprocess_array(self.sig))
+
+    def check(self, out):
+        assert tuple(out.shape) == (self.nb, self.nt // 12, 512, self.mics - 1, 2) and bool(torch.isfinite(out.float()).all())
+
+    def config(self):
+        return {"workload": "BASELINE configs[2]: IPDnet fixed-array %d-mic (input 16 ch, hidden 256, online, 2 tracks) "
+                            "DP-IPD forward, waveform->STFT->array features->2x(full-band BiLSTM + narrow-band LSTM, "
+                            "concat skips)->causal 3x3 conv head; %d utterances/GPU x 257 bins x %d frames; %s"
+                            % (self.mics, self.nb, self.nt,
+                               "fp32" if self.fp32 else "bf16 weights / MFMA operands, fp32 accumulate, fp32 tensors in HBM"),
+                "utterances_per_gpu": self.nb, "mics": self.mics, "frames": self.nt, "bins": 257,
+                "parallelism": "dp%d (utterance shards, no collective)" % self.world}
+
+    def extra(self, value, kern, steps):
+        fl = sum(v["flops"] for v in kern.values()) / steps
+        return {"tflop_per_step": round(fl / 1e12, 2),
+                "whole_path_tflops": round(value / self.frames_per_step / self.world * fl / 1e12, 2)}
+
+    def roofline(self, kern):
+        if self.fp32:
+            return kernel_roof(kern, "lstm_h256", "narrow-band LSTM H=256 (fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS)
+        return kernel_roof(kern, "lstm_h256", "lstm_bf16 kernel H=256 (narrow-band LSTM, bf16 MFMA operands)",
+                           PEAK_BF16_MFMA_TFLOPS)
+
+    def cpu_baseline(self):
+        from oracle import fnssl_oracle as O
+        frames = 24
+        sig = self.sig[:1, :256 * (frames + 1)].cpu().numpy()
+        c0 = time.perf_counter()
+        want = O.ipdnet_forward(self.sd, O.array_preprocess(sig), True)            # fp32 oracle
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "1 utterance x 8 mics x %d frames, numpy restatement of the reference (oracle/fnssl_oracle.py), "
+                         "%.1f s" % (frames, cdt)}
+        got = self.net(self.ops.preprocess_array(self.sig[:1, :256 * (frames + 1)])).float().cpu()
+        rt, at = (1e-4, 2e-5) if self.fp32 else (2e-2, 4e-3)                      # SURVEY 8d config-3 tolerance
+        return cpu, parity_of(got, torch.from_numpy(want), rt, at, "%d frames vs the fp32 oracle" % frames)
+
+
+# ------------------------------------------------------------------------------------------------------------ #
+# config 4: FN-SSL training step
+# ------------------------------------------------------------------------------------------------------------ #
+class FnsslTrain:
+    def __init__(self, args, dev, rank, world):
+        import Model
+        from fnssl import ops, train
+        from fnssl import weights as W
+        self.args, self.dev, self.ops, self.world, self.rank = args, dev, ops, world, rank
+        self.nb, self.mics, self.nt = args.nb or 32, 2, args.frames
+        self.sd = W.make_fnssl_state(3, 4, 256, True)
+        net = Model.FN_SSL(is_online=True)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.sd.items()})
+        self.net = net.to(dev)
+        self.eng = train.TrainEngine(self.net, seed=1, chunk_pairs=args.chunk_pairs or None)
+        g = torch.Generator(device=dev)
+        g.manual_seed(100 + rank)
+        self.npair = self.mics * (self.mics - 1) // 2
+        self.sig = torch.randn((self.nb, 256 * (self.nt + 1), self.mics), generator=g, device=dev) * 0.1
+        self.gt = torch.tanh(torch.randn((self.nb, self.nt // 12, 512, self.npair), generator=g, device=dev))
+        self.frames_per_step = self.nb * self.nt
+        self.dtype = "f32"
+        self.metric = "utt-frames/sec FN-SSL training step (forward + MSE + BPTT + gradient all-reduce + Adam)"
+        self.flops = 3.0 * FLOP_PER_TF_POINT[True] * self.nb * self.npair * 256.0 * self.nt   # fwd + BPTT + dW GEMMs
+        log("rank %d/%d: training step, %d utt x %d mics x %d frames per GPU" % (rank, world, self.nb, self.mics, self.nt))
+
+    def step(self):
+        x = self.ops.preprocess(self.sig, "MM", layout=1)
+        return self.eng.step(x, self.gt, sync_loss=False)
+
+    def check(self, out):
+        assert bool(torch.isfinite(out).all())
+
+    def config(self):
+        return {"workload": "BASELINE configs[3]: FN-SSL (online) training step, global batch %d two-mic utterances = %d per "
+                            "GPU x %d GPU(s), 257 bins x %d frames, fp32; waveforms->features->forward (dropout on)->MSE->"
+                            "BPTT + weight gradients->RCCL sum all-reduce of the flat 10 MB gradient->Adam"
+                            % (self.nb * self.world, self.nb, self.world, self.nt),
+                "utterances_per_gpu": self.nb, "global_batch": self.nb * self.world, "mics": self.mics, "frames": self.nt,
+                "parallelism": "dp%d (utterance shards; one gradient all-reduce per step)" % self.world,
+                "chunk_pairs": self.args.chunk_pairs}
+
+    def extra(self, value, kern, steps):
+        ex = {"tflop_per_step_per_gpu": round(self.flops / 1e12, 2),
+              "whole_path_tflops": round(value / self.frames_per_step / self.world * self.flops / 1e12, 2),
+              "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+        # the exchange step alone: the same flat gradient, timed outside the step (inside it overlaps the backward)
+        if self.world > 1:
+            import torch.distributed as dist
+            buf = torch.zeros_like(self.eng.grad)
+            dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            ex["comm_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        else:
+            ex["comm_ms"] = 0.0
+        ex["comm_bytes"] = int(self.eng.grad.numel() * 4)
+        ex["comm_exposed_ms"] = round(getattr(self.eng, "last_comm_wait_ms", 0.0), 3)
+        return ex
+
+    def roofline(self, kern):
+        return kernel_roof(kern, "lstm_bwd_h256", "lstm_bwd_kernel<H=256> (narrow-band BPTT)", PEAK_FP32_MFMA_TFLOPS)
+
+    def cpu_baseline(self):
+        from oracle import train_ref as TR
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        frames, utts = 24, 1
+        x = self.ops.preprocess(self.sig[:utts, :256 * (frames + 1)], "MM", layout=1).cpu().numpy()
+        gt = self.gt[:utts, :frames // 12].cpu().numpy()
+        c0 = time.perf_counter()
+        loss, *_ = TR.train_step(self.sd, x, gt, seed=12345)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(utts * frames / cdt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d utterance x 2 mics x %d frames, PyTorch CPU autograd restatement of training_step "
+                         "(oracle/train_ref.py: forward + backward + Adam), %d threads, %.1f s" % (utts, frames, cores, cdt)}
+        # same-step parity on that sample: a fresh engine with the oracle's seed -> compare the loss
+        import Model
+        from fnssl import train
+        net = Model.FN_SSL(is_online=True)
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.sd.items()})
+        eng = train.TrainEngine(net.to(self.dev), seed=0, process_group=False)
+        eng.force_seed = 12345
+        got = eng.step(torch.from_numpy(x).to(self.dev), torch.from_numpy(gt).to(self.dev), sync_loss=True)
+        par = parity_of(torch.tensor([got]), torch.tensor([loss]), 1e-4, 1e-6, "loss of one step, %d frames" % frames)
+        return cpu, par
+
+
+# ------------------------------------------------------------------------------------------------------------ #
+# config 5: IPDnet2 (OnlineSpatialNet), 15-mic input, online / causal
+# ------------------------------------------------------------------------------------------------------------ #
+class Ipdnet2Forward:
+    def __init__(self, args, dev, rank, world):
+        from fnssl import ops
+        from fnssl import weights as W
+        M = load_module("fnssl_ipdnet2_dropin", "fn-ssl_amd", "IPDnet2", "IPDnet2.py")
+        self.args, self.dev, self.ops, self.world = args, dev, ops, world
+        self.nb, self.mics, self.layers = args.nb or 64, 15, 8
+        self.nt = args.frames if args.frames != 300 else 250            # 4 s at hop 320 (run_IPDnet2.py:93)
+        self.sd = W.make_ipdnet2_state(7, dim_input=2 * self.mics, num_layers=self.layers)
+        net = M.OnlineSpatialNet(dim_input=2 * self.mics, dim_output=16, num_layers=self.layers, dim_hidden=96, num_heads=4,
+                                 kernel_size=(5, 3), conv_groups=(8, 8), norms=["LN", "LN", "GN", "LN", "LN", "LN"],
+                                 dim_squeeze=8, num_freqs=256, attention="mamba(16,4)", rope=False,
+                                 time_compression_layer=0, fre_compression_ratio=16, time_compression_ratio=5).eval()
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.sd.items()})
+        self.net = net.to(dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(3000 + rank)
+        self.x = torch.randn((self.nb, 2 * self.mics, 256, self.nt), generator=g, device=dev)
+        self.frames_per_step = self.nb * self.nt
+        self.dtype = "f32"
+        self.metric = "utt-frames/sec IPDnet2 (OnlineSpatialNet) DP-IPD forward, 15-mic input, 512 outputs per frame"
+        from oracle import ipdnet2_oracle as O2
+        self.flop_per_frame = O2.flops_per_frame(dim_input=2 * self.mics, num_layers=self.layers)
+        log("rank %d/%d: IPDnet2 %d utt x %d input channels x 256 bins x %d frames" % (rank, world, self.nb, 2 * self.mics, self.nt))
+
+    def step(self):
+        return self.net(self.x)
+
+    def check(self, out):
+        assert tuple(out.shape) == (self.nb, self.nt // 5, 512, 4, 2) and bool(torch.isfinite(out).all())
+
+    def config(self):
+        return {"workload": "BASELINE configs[4]: IPDnet2 OnlineSpatialNet (8 layers, hidden 96, mamba(16,4)), 15-mic "
+                            "mapping dim_input 30 (SURVEY 8d), 256 bins -> 2F = 512 outputs, online / causal path; features "
+                            "[B, 30, 256, T] resident in HBM -> [B, T/5, 512, 4, 2]; %d utterances/GPU x %d frames; fp32 "
+                            "(the bf16 variant is not built); parity: non-Mamba blocks pinned to the reference, Mamba unpinned"
+                            % (self.nb, self.nt),
+                "utterances_per_gpu": self.nb, "mics": self.mics, "frames": self.nt, "bins": 256,
+                "parallelism": "dp%d (utterance shards, no collective)" % self.world,
+                "mflop_per_frame": round(self.flop_per_frame / 1e6, 2)}
+
+    def extra(self, value, kern, steps):
+        return {"whole_path_tflops": round(value * self.flop_per_frame / 1e12 / self.world, 2)}
+
+    def roofline(self, kern):
+        # every kernel of this network is a small dense contraction: the roof is the fp32 matrix peak even though
+        # the kernels run on the packed-fp32 vector pipe (IPDnet2 section)
+        dom = max((k for k in kern if k.startswith("sn_")), key=lambda k: kern[k]["ms"], default=None)
+        return kernel_roof(kern, dom, "%s (dominant kernel of the step)" % dom, PEAK_FP32_MFMA_TFLOPS) if dom else None
+
+    def cpu_baseline(self):
+        from oracle import ipdnet2_oracle as O2
+        frames = 20
+        x = self.x[:1, :, :, :frames].cpu().numpy()
+        c0 = time.perf_counter()
+        want = O2.forward(self.sd, x)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "1 utterance x 30 channels x %d frames, numpy restatement (oracle/ipdnet2_oracle.py; Mamba block = "
+                         "published algorithm, parity unpinned), %.1f s" % (frames, cdt)}
+        got = self.net(self.x[:1, :, :, :frames].contiguous()).cpu()
+        return cpu, parity_of(got, torch.from_numpy(want), 1e-4, 5e-5, "%d frames" % frames)
+
+
+WORKLOADS = {2: FnsslForward, 3: IpdnetForward, 4: FnsslTrain, 5: Ipdnet2Forward}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nb", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE.json configuration")
+    ap.add_argument("--nb", type=int, default=0, help="utterances per GPU (default: the configuration's batch)")
     ap.add_argument("--nch", type=int, default=4)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--ch-mode", default="MM")
     ap.add_argument("--chunk-pairs", type=int, default=0)
-    ap.add_argument("--offline", action="store_true", help="is_online=False (bidirectional narrow-band LSTM)")
+    ap.add_argument("--offline", action="store_true", help="config 2: is_online=False (bidirectional narrow-band LSTM)")
     ap.add_argument("--bf16", action="store_true",
-                    help="NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, fp32 "
-                         "accumulate/tensors); reported with dtype 'bf16' and its measured deviation")
+                    help="config 2, NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, "
+                         "fp32 accumulate/tensors); reported with dtype 'bf16' and its measured deviation")
+    ap.add_argument("--fp32", action="store_true", help="config 3 in fp32 instead of bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample")
+    ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample (config 2)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample (config 2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,30 +463,11 @@ def main():
     if world > 1 or "RANK" in os.environ:       # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        log("rank %d: RCCL process group up, world size %d" % (rank, dist.get_world_size()))
 
-    import predict_step as ps
     from fnssl import ops
-    from fnssl import weights as W
-
-    online = not args.offline
-    sd = W.make_fnssl_state(0, is_online=online)
-    model = ps.MyModel(ch_mode=args.ch_mode, device=str(dev))
-    if not online:
-        import Model as at_model
-        model.arch = at_model.FN_SSL(is_online=False)
-    model.arch.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    model.arch.chunk_pairs = args.chunk_pairs
-    model = model.to(dev).eval()
-    if args.bf16:
-        model.arch.bfloat16()          # optional fast mode, see --bf16
-
-    ns = 512 + (args.frames - 1) * 256
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    batch = torch.randn((args.nb, args.nch, ns), generator=gen, device=dev, dtype=torch.float32)   # [nb, nch, ns]
-    n_pairs = ops.num_pairs(args.nch, args.ch_mode)
-    nt = ops.num_frames(ns)
+    wl = WORKLOADS[args.config](args, dev, rank, world)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -116,113 +475,63 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log("rank %d/%d on %s: %d utt x %d mics x %d frames, %d pairs" % (rank, world, torch.cuda.get_device_name(dev),
-                                                                    args.nb, args.nch, nt, args.nb * n_pairs))
     out = None
     for _ in range(args.warmup):
-        out = model.predict_step(batch, 0)
+        out = wl.step()
     sync_all()
-    ops.timing_enable(True)
+    ops.timing_enable(True)                      # per-kernel HIP events on the launch stream, in the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = model.predict_step(batch, 0)
+    for i in range(args.steps):
+        ev[i][0].record()
+        out = wl.step()
+        ev[i][1].record()
     sync_all()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     ops.timing_enable(False)
     kern = ops.timing_collect()
-    log("timed %d steps in %.3f s" % (args.steps, dt))
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    log("rank %d: timed %d steps in %.3f s (median step %.3f ms by HIP events)" % (rank, args.steps, dt_local,
+                                                                                 step_ms[len(step_ms) // 2]))
+    dt, per_rank = dt_local, [round(dt_local / args.steps * 1e3, 3)]
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt_local], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert out is not None and tuple(out.shape) == (args.nb * n_pairs, nt // 12, 512)
-    assert bool(torch.isfinite(out).all())
+        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt_local], dtype=torch.float64, device=dev))
+        per_rank = [round(float(t.item()) / args.steps * 1e3, 3) for t in allt]
+    assert out is not None
+    wl.check(out)
 
-    utt_frames = args.nb * nt * args.steps * world
-    value = utt_frames / dt
-    flop_per_utt_frame = FLOP_PER_TF_POINT[online] * 256 * n_pairs
-
-    # ---- roofline of the dominant kernel (narrow-band LSTM, H = 256) ------------------
-    roof = None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_lstm_h256.json")
-    if os.path.exists(tpath):       # PMC passes cannot run inside the timed region: measured by rocprofv3, committed
-        with open(tpath) as f:
-            traffic = json.load(f).get("bytes_per_launch")
-    dom = kern.get("lstm_h256") if online else None
-    if dom and dom["ms"] > 0 and args.bf16:
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
-                "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-                "traffic": None, "launches": dom["count"], "avg_ms": round(dom["ms"] / max(1, dom["count"]), 3),
-                "flop_per_launch": dom["flops"] / max(1, dom["count"])}
-    elif dom and dom["ms"] > 0:
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "lstm_rec_kernel<H=256> (narrow-band LSTM)",
-                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "launches": dom["count"], "avg_ms": round(dom["ms"] / max(1, dom["count"]), 3),
-                "flop_per_launch": dom["flops"] / max(1, dom["count"])}
+    value = wl.frames_per_step * args.steps * world / dt
+    roof = wl.roofline(kern)
     breakdown = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["count"] / args.steps,
                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None}
                  for k, v in sorted(kern.items())}
+    extra = wl.extra(value, kern, args.steps)
 
-    # ---- CPU baseline + same-run parity gate (rank 0, N = 1 only) ---------------------
-    cpu = None
-    parity = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import torch_ref as R
-        cores = usable_cores()
-        torch.set_num_threads(cores)
-        net = R.build(sd, online)
-        sample = batch[:args.cpu_utts].cpu()
-        R.predict_step(net, sample[:, :, :512 + 11 * 256], args.ch_mode)       # warm-up (12 frames)
-        # probe on 24 frames, then size the timed sample to ~args.cpu_seconds of CPU work
-        p0 = time.perf_counter()
-        R.predict_step(net, sample[:, :, :512 + 23 * 256], args.ch_mode)
-        per_frame = (time.perf_counter() - p0) / 24.0
-        cpu_frames = int(min(nt, max(24, (args.cpu_seconds / max(per_frame, 1e-9)) // 12 * 12)))
-        log("cpu baseline: %d threads, probe %.3f s/frame -> timing %d frames" % (cores, per_frame, cpu_frames))
-        cns = 512 + (cpu_frames - 1) * 256
-        c0 = time.perf_counter()
-        ref_out = R.predict_step(net, sample[:, :, :cns], args.ch_mode)
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(args.cpu_utts * cpu_frames / cdt, 2), "unit": "frames/s", "cores": cores,
-               "kind": "port",
-               "sample": "%d utterance(s) x %d mics x %d frames ('%s', %d pairs), PyTorch CPU restatement of the "
-                         "reference (torch.stft + oneDNN nn.LSTM), %d threads, %.1f s"
-                         % (args.cpu_utts, args.nch, cpu_frames, args.ch_mode, args.cpu_utts * n_pairs, cores, cdt)}
-        # same-run parity gate on the same waveforms (the narrow-band LSTM is causal and the
-        # forgetting-norm is recursive, so the first cpu_frames frames do not depend on later ones
-        # ... except through the full-band BiLSTM, which runs along frequency only: exact prefix)
-        got = model.predict_step(batch[:args.cpu_utts, :, :cns], 0).cpu()
-        err = (got - ref_out).abs()
-        rt, at = (2e-2, 4e-3) if args.bf16 else (1e-4, 1e-5)
-        parity = {"max_abs_err": float(err.max()), "rtol": rt, "atol": at, "frames": cpu_frames,
-                  "ok": bool((err <= at + rt * ref_out.abs()).all())}
-        log("parity vs CPU reference: max abs err %.3g ok=%s" % (parity["max_abs_err"], parity["ok"]))
+        cpu, parity = wl.cpu_baseline()
+    failed = parity is not None and not parity["ok"]
 
     if rank == 0:
         line = {
-            "metric": "TF-frames/sec DP-IPD forward, 4-mic 257-bin x 300-frame" +
-                      (" [optional bf16 fast mode: NOT the BASELINE fp32 metric]" if args.bf16 else ""),
-            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: FN-SSL (%s) DP-IPD forward," % ("online" if online else "offline") + " waveform->STFT->features->"
-                                   "3x(full-band BiLSTM + narrow-band LSTM)->head; %d utterances/GPU x %d mics "
-                                   "('%s' = %d pairs) x 257 bins x %d frames, fp32; frame = one STFT frame of one "
-                                   "utterance" % (args.nb, args.nch, args.ch_mode, n_pairs, nt),
-                       "utterances_per_gpu": args.nb, "mics": args.nch, "pairs_per_utterance": n_pairs,
-                       "frames": nt, "bins": 257, "parallelism": "dp%d (utterance shards, no collective)" % world,
-                       "chunk_pairs": args.chunk_pairs,
-                       "gflop_per_frame": round(flop_per_utt_frame / 1e9, 3)},
-            "whole_path_tflops": round(value * flop_per_utt_frame / 1e12 / world, 2),
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "kernels": breakdown,
+            "metric": wl.metric, "value": None if failed else round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+            "config": wl.config(), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "ms_per_step_median_hip_events": round(step_ms[len(step_ms) // 2], 3), "ms_per_step_per_rank": per_rank,
+            "rccl_world_size": dist.get_world_size() if dist is not None else 1, "kernels": breakdown,
         }
+        line.update(extra)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        log("PARITY FAILED: value withheld")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

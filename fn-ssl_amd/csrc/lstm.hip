@@ -172,7 +172,11 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.nsteps = d->nsteps;
   p.ndir = d->ndir;
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
-  p.ablate = env_int("FNSSL_ABLATE", 1, 63);
+#ifdef FNSSL_BUILD_ABLATE
+  p.ablate = env_int("FNSSL_ABLATE", 1, 63);   // timing experiments: twin kernels that skip work (wrong results)
+#else
+  p.ablate = 0;                                 // the shipping library contains no ablation twins (make ABLATE=1)
+#endif
   const int tasks = (d->nseq + 15) / 16;
   const int mode = ((d->src1.p != nullptr && d->c0 > 0) ? kHas1 : 0) | (d->c2 > 0 ? kHas2 : 0) |
                    (d->out_sum ? kSum : 0);

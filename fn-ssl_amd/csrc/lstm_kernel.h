@@ -575,7 +575,9 @@ int launch_t(const LstmParams& p, int mode, int nwg, hipStream_t st) {
     case kHas2: return launch_k<H, NW, M, WMODE, kHas2>(p, nwg, st);
     case kSum:
       if constexpr (H >= 128 && WMODE == 1 && ((NW == 12 && M == 4) || (NW == 16 && M == 2))) {
+#ifdef FNSSL_BUILD_ABLATE
         if (p.ablate) return launch_k<H, NW, M, WMODE, kSum, true>(p, nwg, st);
+#endif
       }
       return launch_k<H, NW, M, WMODE, kSum>(p, nwg, st);
     case kHas2 | kSum: return launch_k<H, NW, M, WMODE, kHas2 | kSum>(p, nwg, st);

@@ -42,8 +42,10 @@ int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream
   TRY(14, 2, 0, 1, 0, 5, 0, 0)
   TRY(13, 2, 0, 1, 0, 5, 0, 0)
   // blocks 2/3 full-band (and offline narrow-band 2/3): 256 channels, 25 quads (+3 pad = 4 x 7)
+#ifdef FNSSL_BUILD_ABLATE   // timing-ablation twin (wrong results by construction): only in `make ABLATE=1` builds
   if (p.ablate && NW == 16 && p.c0 == 256 && p.c2 == 0 && mode == kSum)
     return launch_static_k<128, 16, 2, 16, 0, 0, 7, 3, kSum, true>(p, nwg, st);
+#endif
   if (!env_int("FNSSL_STATIC_SMALLCHUNK", 1, 1)) {   // 26 virtual quads = 2 chunks of 13
     TRY(16, 4, 16, 0, 0, 13, 1, kSum)
     TRY(15, 4, 16, 0, 0, 13, 1, kSum)

@@ -28,8 +28,10 @@ int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream
   // block 1: 256 + 4 channels, 34 quads (+2 pad = 3 x 12)
   TRY(12, 4, 16, 0, 1, 12, 2, kHas2 | kSum)
   // blocks 2/3: 256 channels, 33 quads = 3 x 11
+#ifdef FNSSL_BUILD_ABLATE   // timing-ablation twin (wrong results by construction): only in `make ABLATE=1` builds
   if (p.ablate && NW == 12 && p.c0 == 256 && p.c2 == 0 && mode == kSum)
     return launch_static_k<256, 12, 4, 16, 0, 0, 11, 0, kSum, true>(p, nwg, st);
+#endif
   TRY(12, 4, 16, 0, 0, 11, 0, kSum)
   TRY(12, 4, 16, 0, 0, 11, 0, 0)
   // smaller launches: 8 / 4 waves per workgroup

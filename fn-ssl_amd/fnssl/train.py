@@ -14,8 +14,12 @@ gradient all-reduce (main.py:286-288):
     optimizer              fnssl_adam_step on the flat parameter vector (grad / world_size folded in)
 
 PyTorch provides memory, streams, the GEMM library call and torch.distributed; there is no autograd
-graph and no CPU fallback.  Dropout masks are a pure function of (seed, step, rank, layer, element), so
-the backward regenerates them instead of storing them (oracle/train_ref.py restates the hash).
+graph and no CPU fallback.  Dropout masks are a pure function of (seed, step, layer, GLOBAL element index) — the
+element index counts pairs over the whole job (rank r's pairs start at r * pairs_per_rank), so an N-rank step
+draws exactly the masks the 1-rank step on the concatenated batch draws — and the backward regenerates them
+instead of storing them (oracle/train_ref.py restates the hash).  The gradient exchange is asynchronous: each
+layer's slice of the flat gradient is all-reduced as soon as its weight gradients are final, i.e. under the
+BPTT of the layers below it; the optimizer waits for the last slice.
 
 Tensor naming: logical [pairs, nt, nf, C]; "F" tensors are stored [b, t, f, C] (full-band natural order:
 one sequence per (b, t), steps along f), "N" tensors [b, f, t, C] (narrow-band natural order).
@@ -145,7 +149,9 @@ class TrainEngine:
         self.model = model
         self.lr, self.betas, self.eps, self.seed = lr, betas, eps, seed
         self.chunk_pairs = chunk_pairs
-        self.pg = process_group
+        self.pg = process_group          # None: the default group (if initialised); False: never distributed
+        self.force_seed = None           # tests / bench parity: use exactly this base seed for the next steps
+        self._pending, self._wait_events, self._reduce_now = [], None, False
         self.step_count = 0
         self.online = bool(model.is_online)
         dev = next(model.parameters()).device
@@ -178,6 +184,48 @@ class TrainEngine:
         self._build_index_maps()
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = {}
+
+    # ------------------------------------------------------------------ distributed plumbing
+    def _world_rank(self):
+        dist = torch.distributed
+        if self.pg is False or not (dist.is_available() and dist.is_initialized()):
+            return 1, 0
+        return dist.get_world_size(self.pg), dist.get_rank(self.pg)
+
+    def _bucket(self, prefix):
+        """[lo, hi) of the flat vector covered by the parameters whose name starts with ``prefix`` (contiguous:
+        the flat order is named_parameters order)."""
+        offs = [(self.offset[k][0], int(np.prod(self.offset[k][1]))) for k in self.names if k.startswith(prefix)]
+        return min(o for o, _ in offs), max(o + n for o, n in offs)
+
+    def _reduce_async(self, prefix):
+        """Start the sum all-reduce of one layer's gradient slice (RCCL runs it on its own stream, ordered after
+        everything enqueued so far on the compute stream)."""
+        world, _ = self._world_rank()
+        if world <= 1 or not self._reduce_now:
+            return
+        lo, hi = self._bucket(prefix)
+        self._pending.append(torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                          group=self.pg or None, async_op=True))
+
+    def _wait_reductions(self):
+        if not self._pending:
+            self._wait_events = None
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for w in self._pending:
+            w.wait()
+        e1.record()
+        self._pending, self._wait_events = [], (e0, e1)
+
+    @property
+    def last_comm_wait_ms(self):
+        """GPU time the compute stream spent waiting for the gradient all-reduces of the last step."""
+        if self._wait_events is None:
+            return 0.0
+        self._wait_events[1].synchronize()
+        return float(self._wait_events[0].elapsed_time(self._wait_events[1]))
 
     # ------------------------------------------------------------------ parameter plumbing
     def gview(self, name):
@@ -267,6 +315,7 @@ class TrainEngine:
             db = a.sum(dim=0)
             self.gview("%s.bias_ih_l0%s" % (L.name, s)).add_(db)
             self.gview("%s.bias_hh_l0%s" % (L.name, s)).add_(db)
+        self._reduce_async(L.name + ".")
 
     def _chunk(self, x, gt, b0, n_total, fw, bw, seeds):
         """Forward + backward of pairs [b0, b0 + nbp) (x [nbp, 4, nf, nt]); accumulates grads and the loss."""
@@ -316,6 +365,7 @@ class TrainEngine:
                                       nbp, nf, nt, G.data_ptr(), self.gview(wname).data_ptr(),
                                       self.gview(bname).data_ptr(), 1, ws.data_ptr(), ws.numel() * 4, ops._stream()),
               "head_backward")
+        self._reduce_async("emb2ipd.")
         gx = (G.permute(0, 2, 1, 3),)                     # operands whose sum is dL/dX_{k+1}
         dfb = ()                                           # operands whose sum is dL/dF_k through fb_skip
         for k in (3, 2, 1):
@@ -348,20 +398,20 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ public API
     @ops.on_device
-    def step(self, x, gt_ipd, sync_loss=True):
+    def step(self, x, gt_ipd, sync_loss=True, pair_offset=None):
         """One optimisation step.  x [nb*np, 4, nf, nt] features (data_preprocess output), gt_ipd
-        [nb, nt//12, 2*nf, np] targets, both on the device.  Returns the loss (float, or the device scalar when
-        ``sync_loss`` is False)."""
+        [nb, nt//12, 2*nf, np] targets, both on the device.  Returns the loss of THIS rank's shard (float, or the
+        device scalar when ``sync_loss`` is False).  ``pair_offset``: index of this rank's first pair in the global
+        batch (default rank * pairs_per_rank, i.e. equal contiguous shards) — it only keys the dropout masks."""
         ops._need_dev(x, gt_ipd)
         nbp, cin, nf, nt = x.shape
         nb, nt2, nf2, npair = gt_ipd.shape
         if cin != 4 or nb * npair != nbp or nt2 != nt // 12 or nf2 != 2 * nf or nt2 == 0:
             raise RuntimeError("fnssl.train.step: x %s does not match gt_ipd %s" % (tuple(x.shape), tuple(gt_ipd.shape)))
         self.step_count += 1
-        world = torch.distributed.get_world_size(self.pg) if (torch.distributed.is_available() and
-                                                              torch.distributed.is_initialized()) else 1
-        rank = torch.distributed.get_rank(self.pg) if world > 1 else 0
-        base = (self.seed * 1000003 + self.step_count * 8191 + rank * 131071) & 0xFFFFFFFF
+        world, rank = self._world_rank()
+        base = (self.seed * 1000003 + self.step_count * 8191) & 0xFFFFFFFF if self.force_seed is None else self.force_seed
+        pair0 = rank * nbp if pair_offset is None else int(pair_offset)      # this rank's first GLOBAL pair index
         seeds = [layer_seed(base, l) for l in range(6)]
         self.last_seed = base
         fw, bw = self._pack_all()
@@ -373,8 +423,11 @@ class TrainEngine:
         gt_ipd = gt_ipd.contiguous()
         for b0 in range(0, nbp, cp):
             b1 = min(nbp, b0 + cp)
-            self._chunk(x[b0:b1].contiguous(), gt_ipd[b0 // npair:b1 // npair], b0, n_total, fw, bw, seeds)
-        gscale = sync_gradients(self.grad, self.pg)
+            self._reduce_now = b1 == nbp          # gradients are final only in the last chunk's backward
+            self._chunk(x[b0:b1].contiguous(), gt_ipd[b0 // npair:b1 // npair], pair0 + b0, n_total, fw, bw, seeds)
+        self._reduce_now = False
+        self._wait_reductions()
+        gscale = 1.0 / world
         check(_lib.load().fnssl_adam_step(self.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                           self.exp_avg_sq.data_ptr(), self.theta.numel(), self.lr, self.betas[0],
                                           self.betas[1], self.eps, self.step_count, gscale, ops._stream()),

@@ -33,6 +33,11 @@ class MyModel(_Base):
         if (win_len, nfft, win_shift_ratio) != (512, 512, 0.5):
             raise ValueError("the MI355X path is built for win_len = nfft = 512, hop 256 (main.py:38-44)")
         self.arch = at_model.FN_SSL()
+        # Under Lightning the optimisation runs inside the HIP engine (training_step = one complete step and
+        # returns a detached loss): manual optimisation, or Lightning 2.x would call backward() on that loss.
+        if hasattr(self, "automatic_optimization") or _Base is not torch.nn.Module:
+            self.automatic_optimization = False
+        self.method_mode, self.source_num_mode, self.max_num_sources = method_mode, source_num_mode, max_num_sources
         self.ch_mode = ch_mode
         self.nfft = nfft
         self.dev = device

@@ -1,0 +1,117 @@
+"""Multi-GPU equivalence proved on ONE GPU: two processes share cuda:0, talk over the gloo
+backend (it accepts device tensors) and run the real HIP path.
+  * inference: fnssl.dist.predict_sharded over the HIP predict_step == the single-process output, bit for bit;
+  * training: TrainEngine.step on two 1-utterance shards (async per-layer gradient all-reduce, 1/world in Adam)
+    leaves the same parameters as one process on the 2-utterance batch — possible because the dropout masks are
+    keyed on the GLOBAL pair index, not on the rank.
+The 1 -> 8 GPU curve itself can only come from the driver (RCCL over xGMI); this pins the logic it runs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close, rs_randn
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+NT = 24
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make(dev, seed=31):
+    import Model
+    from fnssl import weights as W
+    sd = W.make_fnssl_state(seed, 4, 256, True)
+    net = Model.FN_SSL(is_online=True)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return net.to(dev)
+
+
+def _data():
+    sig = rs_randn(41, (2, 256 * (NT + 1), 2), 0.1)               # 2 two-mic utterances
+    gt = np.tanh(rs_randn(42, (2, NT // 12, 512, 1)))
+    return sig, gt
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "fn-ssl_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import predict_step as ps
+    from fnssl import dist as fd
+    from fnssl import ops, train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sig, gt = _data()
+    # ---- inference: sharded predict, gathered on every rank
+    model = ps.MyModel(ch_mode="MM", device=str(dev))
+    model.arch = _make(dev)
+    model = model.to(dev).eval()
+    batch = torch.from_numpy(sig).to(dev).permute(0, 2, 1).contiguous()      # [nb, nch, ns]
+    got = fd.predict_sharded(lambda shard: model.predict_step(shard, 0), batch)
+    np.save(os.path.join(out_dir, "pred_rank%d.npy" % rank), got.cpu().numpy())
+    # ---- training: one step on this rank's utterance
+    net = _make(dev)
+    eng = train.TrainEngine(net, seed=3)
+    lo, hi = train.shard_utterances(2, rank, world)
+    x = ops.preprocess(torch.from_numpy(sig[lo:hi]).to(dev), "MM", layout=1)
+    loss = eng.step(x, torch.from_numpy(gt[lo:hi]).to(dev))
+    np.save(os.path.join(out_dir, "theta_rank%d.npy" % rank), eng.theta.cpu().numpy())
+    np.save(os.path.join(out_dir, "grad_rank%d.npy" % rank), eng.grad.cpu().numpy())
+    np.save(os.path.join(out_dir, "loss_rank%d.npy" % rank), np.array([loss, eng.last_comm_wait_ms]))
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_match_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm device")
+    import torch.multiprocessing as mp
+    import predict_step as ps
+    from fnssl import ops, train
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    sig, gt = _data()
+    # single-process references through the same HIP path
+    model = ps.MyModel(ch_mode="MM", device=str(dev))
+    model.arch = _make(dev)
+    model = model.to(dev).eval()
+    want = model.predict_step(torch.from_numpy(sig).to(dev).permute(0, 2, 1).contiguous(), 0).cpu().numpy()
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "pred_rank%d.npy" % r)), want)
+    net = _make(dev)
+    eng = train.TrainEngine(net, seed=3, process_group=False)
+    loss = eng.step(ops.preprocess(torch.from_numpy(sig).to(dev), "MM", layout=1), torch.from_numpy(gt).to(dev))
+    theta = eng.theta.cpu().numpy()
+    th = [np.load(os.path.join(str(tmp_path), "theta_rank%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(th[0], th[1])                   # replicas stay in lockstep
+    # all-reduced sum of the two shard gradients / world == the gradient of one pass over both utterances, up to
+    # fp32 summation order (the masks are the same because they are keyed on the global pair index)
+    g2 = np.load(os.path.join(str(tmp_path), "grad_rank0.npy")) / world
+    g1 = eng.grad.cpu().numpy()
+    scale = np.abs(g1).max()
+    assert np.abs(g2 - g1).max() <= 2e-5 * scale, (np.abs(g2 - g1).max(), scale)
+    # Adam's first step is lr * g / (|g| + eps): identical wherever |g| is not down at eps
+    big = np.abs(g1) > 1e-4 * scale
+    assert_close(th[0][big], theta[big], 0, 2e-6, "parameters after one step (2 ranks vs 1)")
+    assert np.abs(th[0] - theta).mean() < 1e-6
+    sd0 = _make(torch.device("cpu"))
+    moved = np.abs(theta[1:] - np.concatenate([p.detach().numpy().ravel() for p in sd0.parameters()]))
+    assert moved.max() > 5e-4                                     # the step did move the parameters
+    losses = [np.load(os.path.join(str(tmp_path), "loss_rank%d.npy" % r))[0] for r in range(world)]
+    assert abs(0.5 * (losses[0] + losses[1]) - loss) < 1e-5 * max(1.0, abs(loss))   # mean of shard losses = batch loss

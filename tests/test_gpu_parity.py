@@ -6,6 +6,8 @@ Tolerance (north_star): fp32, rtol 1e-4 (+ atol 1e-5 because the outputs are tan
 of small numbers, SURVEY.md §7 "hard parts").  Integer/index work (pair order,
 shapes) is exact.  Nothing here reads /root/reference.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -908,3 +910,36 @@ def test_ipdnet_forward_stream_equals_whole_signal(dev, isz, hid):
     off = M.IPDnet(input_size=isz, hidden_size=hid, is_online=False).eval().to(dev)
     with pytest.raises(RuntimeError, match="online"):
         off.forward_stream(x[..., :12].contiguous())
+
+
+# --------------------------------------------------------------------------- config 2 at its real batch
+def test_config2_full_batch_independence_and_oracle(dev):
+    """BASELINE config 2 as benchmarked: 32 utterances x 4 mics x 77 056 samples -> 192 pairs x 300 frames through
+    the full-chip launch geometry (lstm_static_kernel<256,12,..>, the 15 + 14 wave H = 128 rounds) that the small
+    cases never reach.  (i) pairs are independent: three utterances of the batch run alone (different launch
+    geometry: the several-waves-per-group kernels) give bit-identical rows; (ii) one 4-mic utterance's 6 pairs match
+    the PyTorch-CPU restatement of Lightning/main.py:184-189 at rtol 1e-4 / atol 1e-5."""
+    import predict_step as ps
+    from fnssl import weights as W
+    from oracle import torch_ref as R
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 100 * 2 ** 30:
+        pytest.skip("needs ~90 GB of free HBM for the 192-pair activation plan, %.0f GB free" % (free / 2 ** 30))
+    sd = W.make_fnssl_state(0)
+    model = ps.MyModel(ch_mode="MM", device=str(dev))
+    model.arch.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    batch = torch.randn((32, 4, 77056), generator=gen, device=dev)
+    out = model.predict_step(batch, 0)
+    assert tuple(out.shape) == (192, 25, 512) and bool(torch.isfinite(out).all())
+    for u in (0, 13, 31):
+        alone = model.predict_step(batch[u:u + 1], 0)
+        assert torch.equal(alone, out[6 * u:6 * u + 6]), "utterance %d differs when run alone" % u
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    want = R.predict_step(R.build(sd, True), batch[13:14].cpu(), "MM")
+    assert_close(out[78:84].cpu().numpy(), want.numpy(), RTOL, ATOL, "config-2 utterance vs CPU reference")
+    from fnssl import ops
+    ops.release_workspaces()
+    torch.cuda.empty_cache()

@@ -81,11 +81,24 @@ class FNblock(nn.Module):
         self._packed = None
         self._packed_key = None
 
+    def _wide(self):
+        """bf16 model at the hidden-256 (more than two microphones) layer shapes the 32-sequences-per-wave kernels
+        (csrc/lstm_bf16w.h) are built for; FNSSL_NO_BF16W=1 keeps the 16-sequence kernels (A/B)."""
+        return (_is_bf16(self) and not os.environ.get("FNSSL_NO_BF16W") and self.full_hidden_size == 128 and
+                self.narr_hidden_size == 256 and self.is_online and _ceil16(self.add_skip_dim) == 16 and
+                (self.input_size == 256 or (self.is_first and _ceil16(self.input_size) == 16)))
+
     def _streams(self, device):
-        key = (_param_key(self), str(device))
+        key = (_param_key(self), str(device), self._wide())
         if self._packed is None or self._packed_key != key:
             fh2 = 2 * self.full_hidden_size
-            if _is_bf16(self):
+            if self._wide():
+                if self.is_first:
+                    full = _lstm_streams(self.fullLstm, 16, 0, device, True, 16, wide=True)
+                else:
+                    full = _lstm_streams(self.fullLstm, self.input_size, 16, device, True, self.input_size + 16, wide=True)
+                narr = _lstm_streams(self.narrLstm, fh2, 16, device, True, fh2 + 16, wide=True)
+            elif _is_bf16(self):
                 # the skip / network-input segment is zero-padded to whole 16-channel blocks
                 cs = _ceil16(self.add_skip_dim)
                 if self.is_first:
@@ -118,6 +131,19 @@ class FNblock(nn.Module):
             x_in = _pad_channels(x_in, _ceil16(x_in.shape[-1]))
         nb, nt, nf, _ = x_skip.shape
         full_w, narr_w = self._streams(x_skip.device)
+        if self._wide():
+            # activations travel as bf16 between the layers (what the next MFMA would round them to anyway)
+            if x_main is not None and x_main.dtype != torch.bfloat16:
+                x_main = x_main.to(torch.bfloat16)        # API-compat path (FNblock.forward) hands in fp32
+            f = torch.empty((nb, nt, nf, 2 * self.full_hidden_size), dtype=torch.bfloat16, device=x_skip.device)
+            if self.is_first:
+                ops.lstm_layer("full", x_in, None, None, full_w, self.full_hidden_size, f, bf16=True, wide=True)
+            else:
+                ops.lstm_layer("full", x_main, None, x_in, full_w, self.full_hidden_size, f, bf16=True, wide=True)
+            n = torch.empty((nb, nf, nt, self.narr_hidden_size), dtype=torch.bfloat16, device=x_skip.device)
+            ops.lstm_layer("narrow", f, None, x_skip, narr_w, self.narr_hidden_size, n.permute(0, 2, 1, 3), bf16=True,
+                           wide=True)
+            return n.permute(0, 2, 1, 3)
         f = torch.empty((nb, nt, nf, 2 * self.full_hidden_size), dtype=torch.float32, device=x_skip.device)
         if self.is_first:
             if bf or _split16(self.input_size)[0]:
@@ -146,7 +172,7 @@ class FNblock(nn.Module):
                 raise RuntimeError("FNblock: %d input channels, expected %d" % (nc, self.input_size + self.add_skip_dim))
             n = self.run(x[..., :self.input_size], skip, x[..., self.input_size:])
         nbs = nb_skip.reshape(nb, nf, nt, -1).permute(0, 2, 1, 3)
-        return torch.cat((n, nbs), dim=-1).to(in_dtype)
+        return torch.cat((n.float(), nbs), dim=-1).to(in_dtype)
 
 
 class CausCnnBlock(nn.Module):

@@ -21,9 +21,10 @@ import torch.nn as nn
 from fnssl import ops
 
 
-def _lstm_streams(lstm: nn.LSTM, c0: int, c2: int, device, bf16: bool = False, pad_to: int = 0):
+def _lstm_streams(lstm: nn.LSTM, c0: int, c2: int, device, bf16: bool = False, pad_to: int = 0, wide: bool = False):
     """Pack an nn.LSTM's parameters into per-direction device weight streams.  ``bf16``: the bf16-MFMA
-    stream; ``pad_to`` zero-pads the input columns (the last c2 ones are the skip segment) to that width."""
+    stream (``wide``: the tile-ordered stream of the 32-sequences-per-wave kernels); ``pad_to`` zero-pads the input
+    columns (the last c2 ones are the skip segment) to that width."""
     out = []
     for sfx in [""] + (["_reverse"] if lstm.bidirectional else []):
         w_ih = getattr(lstm, "weight_ih_l0" + sfx).detach().float()
@@ -32,7 +33,7 @@ def _lstm_streams(lstm: nn.LSTM, c0: int, c2: int, device, bf16: bool = False, p
         args = (w_ih, getattr(lstm, "weight_hh_l0" + sfx).detach().float(),
                 getattr(lstm, "bias_ih_l0" + sfx).detach().float(), getattr(lstm, "bias_hh_l0" + sfx).detach().float(),
                 c0, c2, device)
-        out.append(ops.pack_lstm_bf16(*args) if bf16 else ops.pack_lstm(*args))
+        out.append((ops.pack_lstm_bf16w(*args) if wide else ops.pack_lstm_bf16(*args)) if bf16 else ops.pack_lstm(*args))
     return out
 
 

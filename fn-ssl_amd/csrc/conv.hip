@@ -32,6 +32,7 @@ struct ConvParams {
   int ntiles, tiles_t;    // tiles = nb * nf * tiles_t, tiles_t = ceil(nt / 16)
   int passes;             // per workgroup
   int quads_per_pass, chq, pad;
+  int a_bf16;             // bf16 kernels: segment A holds bf16 (xa addresses 2-byte elements, a_s* count elements)
 };
 
 // Stream per pass: for tap (df-major, dt-minor): segment A blocks, segment B blocks (16-channel
@@ -170,7 +171,11 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_kernel(const ConvParams p) {
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
 
-template <int NT, int NW, int M>
+typedef unsigned int v2uc __attribute__((ext_vector_type(2)));
+
+// ABF: segment A arrives as bf16 (the wide bf16 LSTM kernels write bf16 activations): its blocks are ready-made
+// operand halves, no conversion and half the bytes.
+template <int NT, int NW, int M, bool ABF = false>
 __global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams p) {
   static_assert(NT == 4 || NT == 8, "4 or 8 output-channel tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,7 +197,8 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams 
     const int bf = tile / p.tiles_t;
     const int f = bf % p.nf;
     const int b = __builtin_amdgcn_readfirstlane(bf / p.nf);
-    const rsrc_t ra = make_rsrc(p.xa + (long long)b * p.a_sb);
+    const rsrc_t ra = ABF ? make_rsrc(reinterpret_cast<const unsigned short*>(p.xa) + (long long)b * p.a_sb)
+                          : make_rsrc(p.xa + (long long)b * p.a_sb);
     const rsrc_t rb = make_rsrc(p.xb ? p.xb + (long long)b * p.b_sb : p.xa);
     const rsrc_t ro = make_rsrc(p.out + (long long)b * p.nf * p.nt * p.cout_stride);
     int tpos = tt * 16 + n;
@@ -209,22 +215,29 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams 
         int ts = tpos + dt - 2;
         const bool live = frow && ts >= 0;
         ts = ts < 0 ? 0 : (ts >= p.nt ? p.nt - 1 : ts);
-        const unsigned offa = (unsigned)(((long long)fc * p.a_sf + (long long)ts * p.a_st) * 4) + 16 * g;
+        const unsigned offa = (unsigned)(((long long)fc * p.a_sf + (long long)ts * p.a_st) * (ABF ? 2 : 4)) +
+                              (ABF ? 8 : 16) * g;
         const unsigned offb = (unsigned)(((long long)fc * p.b_sf + (long long)ts * p.b_st) * 4) + 16 * g;
-        auto block = [&](int v) -> v4f {   // 16-channel block v of [xa | xb]; zeros past the end
-          if (v >= nv) return zero4;
-          return v < nva ? bld4(ra, offa, 64 * v) : bld4(rb, offb, 64 * (v - nva));
+        // 16-channel block v of [xa | xb] as the lane's 4 bf16 operand values (channels 16 v + 4 g + 0..3)
+        auto block = [&](int v) -> v4bf {
+          if (v >= nv) return v4bf{0, 0, 0, 0};
+          if (v < nva) {
+            if constexpr (ABF)
+              return __builtin_bit_cast(v4bf, __builtin_amdgcn_raw_buffer_load_b64(ra, offa, 32 * v, 0));
+            else
+              return __builtin_convertvector(bld4(ra, offa, 64 * v), v4bf);
+          }
+          return __builtin_convertvector(bld4(rb, offb, 64 * (v - nva)), v4bf);
         };
-        v4f n0 = block(0), n1 = block(1);
+        v4bf n0 = block(0), n1 = block(1);
         for (int pi = 0; pi < npairs; ++pi) {
-          v4f c0 = n0, c1 = n1;
+          v4bf lo = n0, hi = n1;
           if (!live) {
-            c0 = zero4;
-            c1 = zero4;
+            lo = v4bf{0, 0, 0, 0};
+            hi = v4bf{0, 0, 0, 0};
           }
           n0 = block(2 * pi + 2);   // operands of the next pair: in flight behind this pair's MFMAs
           n1 = block(2 * pi + 3);
-          const v4bf lo = __builtin_convertvector(c0, v4bf), hi = __builtin_convertvector(c1, v4bf);
           const v8bf bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int qd = 0; qd < NT / 4; ++qd) {
@@ -379,7 +392,7 @@ int fnssl_conv3x3_pack_bf16(const float* w, int cout, int ca, int cb, float* pac
   return FNSSL_OK;
 }
 
-static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
+static int conv_run(int bf, const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
                     long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout, int nb,
                     int nf, int nt, int act, float* out, int cout_stride, void* stream) {
   FNSSL_REQUIRE(xa && wpack && out, "conv3x3: null pointer");
@@ -393,6 +406,7 @@ static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, lo
     return sb >= 0 && sf >= 0 && st >= 0 && ((long double)nf * sf + (long double)nt * st + c) * 4 < 4.0e9L &&
            !(sb & 3) && !(sf & 3) && !(st & 3);
   };
+  FNSSL_REQUIRE(bf != 2 || (reinterpret_cast<uintptr_t>(xa) % 8 == 0), "conv3x3: bf16 segment A must be 8-byte aligned");
   FNSSL_REQUIRE(fits(a_sb, a_sf, a_st, ca) && (cb == 0 || fits(b_sb, b_sf, b_st, cb)) &&
                     (long double)nf * nt * cout_stride * 4 < 4.0e9L,
                 "conv3x3: one utterance must be addressable with 32-bit byte offsets; strides multiples of 4 floats");
@@ -415,6 +429,7 @@ static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, lo
   p.nf = nf;
   p.nt = nt;
   p.act = act;
+  p.a_bf16 = bf == 2;
   p.tiles_t = (nt + 15) / 16;
   p.ntiles = nb * nf * p.tiles_t;
   const int NT = conv_nt_tiles(cout);
@@ -430,7 +445,19 @@ static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, lo
   const size_t lds = (size_t)2 * p.chq * 4096;
   const double flops = 2.0 * 9 * (ca + cb) * (double)cout * nb * nf * (double)nt;
   fnssl::TimedLaunch tl(bf ? "conv3x3_bf16" : "conv3x3", fnssl::as_stream(stream), flops);
-  if (bf) {
+  if (bf == 2) {
+    if (NT == 8) {
+      auto k = conv3x3_bf16_kernel<8, NW, M, true>;
+      if (lds > 48 * 1024)
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, fnssl::as_stream(stream), p);
+    } else {
+      auto k = conv3x3_bf16_kernel<4, NW, M, true>;
+      if (lds > 48 * 1024)
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, fnssl::as_stream(stream), p);
+    }
+  } else if (bf) {
     if (NT == 8) {
       auto k = conv3x3_bf16_kernel<8, NW, M>;
       if (lds > 48 * 1024)
@@ -460,15 +487,23 @@ static int conv_run(bool bf, const float* xa, long long a_sb, long long a_sf, lo
 int fnssl_conv3x3_causal(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
                          long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout,
                          int nb, int nf, int nt, int act, float* out, int cout_stride, void* stream) {
-  return conv_run(false, xa, a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf, nt, act, out,
+  return conv_run(0, xa, a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf, nt, act, out,
                   cout_stride, stream);
 }
 
 int fnssl_conv3x3_causal_bf16(const float* xa, long long a_sb, long long a_sf, long long a_st, int ca, const float* xb,
                               long long b_sb, long long b_sf, long long b_st, int cb, const float* wpack, int cout,
                               int nb, int nf, int nt, int act, float* out, int cout_stride, void* stream) {
-  return conv_run(true, xa, a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf, nt, act, out,
+  return conv_run(1, xa, a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf, nt, act, out,
                   cout_stride, stream);
+}
+
+int fnssl_conv3x3_causal_bf16a(const void* xa_bf16, long long a_sb, long long a_sf, long long a_st, int ca,
+                               const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
+                               const float* wpack, int cout, int nb, int nf, int nt, int act, float* out,
+                               int cout_stride, void* stream) {
+  return conv_run(2, static_cast<const float*>(xa_bf16), a_sb, a_sf, a_st, ca, xb, b_sb, b_sf, b_st, cb, wpack, cout, nb, nf,
+                  nt, act, out, cout_stride, stream);
 }
 
 int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y, void* stream) {

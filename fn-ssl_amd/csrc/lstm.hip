@@ -24,6 +24,7 @@
 
 #include "lstm_static.h"
 #include "lstm_bf16.h"
+#include "lstm_bf16w.h"
 #include "lstm_split_static.h"
 
 using namespace fnssl_lstm;
@@ -195,6 +196,17 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     p.chq = 0;
     p.pad = 0;
     return forward_bf16(p, H, st);
+  }
+  if (d->precision == FNSSL_PRECISION_BF16W) {   // wide bf16 kernels: 32 sequences per wave, bf16 / fp32 activation tensors
+    FNSSL_REQUIRE(!(mode & (kHas1 | kSum)) && !d->reserve && !d->carry_state && d->c0 % 16 == 0 && d->c2 % 16 == 0,
+                  "lstm_forward: the wide bf16 path takes 16-channel input blocks, no fused residual / reserve / carry");
+    auto mult8 = [](long long v) { return (v & 7) == 0; };
+    const int fm = d->f32_mask & 7;
+    FNSSL_REQUIRE(((fm & 1) || !d->c0 || (mult8(d->src0.so) && mult8(d->src0.si) && mult8(d->src0.st))) &&
+                      ((fm & 2) || !d->c2 || (mult8(d->src2.so) && mult8(d->src2.si) && mult8(d->src2.st))) &&
+                      ((fm & 4) || (mult8(d->out_so) && mult8(d->out_si) && mult8(d->out_st))),
+                  "lstm_forward: strides of bf16 tensors must be multiples of 8 elements");
+    return forward_bf16w(p, H, fm, st);
   }
   FNSSL_REQUIRE(d->precision == FNSSL_PRECISION_FP32, "lstm_forward: unknown precision %d", d->precision);
   if (d->reserve) {   // training forward: also save the gate activations (lstm_train.hip)

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -29,11 +29,12 @@ SYMBOLS = [
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features", "fnssl_conv3x3_packed_floats_bf16", "fnssl_conv3x3_pack_bf16",
-    "fnssl_conv3x3_causal_bf16",
+    "fnssl_conv3x3_causal_bf16", "fnssl_conv3x3_causal_bf16a",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
     "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
+    "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
     "fnssl_sn_layernorm", "fnssl_sn_encoder", "fnssl_sn_fconv", "fnssl_sn_full", "fnssl_sn_mamba_workspace_bytes",
     "fnssl_sn_mamba", "fnssl_sn_head", "fnssl_sn_forward_workspace_bytes", "fnssl_sn_state_floats", "fnssl_sn_forward",
 ]
@@ -57,6 +58,7 @@ class LstmDesc(C.Structure):
         ("reserve", C.c_void_p), ("reserve_bytes", C.c_size_t),
         ("carry_state", C.c_int),
         ("precision", C.c_int),
+        ("f32_mask", C.c_int),
     ]
 
 
@@ -162,6 +164,9 @@ def load():
     lib.fnssl_lstm_packed_floats_bf16.argtypes = [i, i, i]
     lib.fnssl_lstm_packed_floats_bf16.restype = sz
     lib.fnssl_lstm_pack_bf16.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    lib.fnssl_lstm_packed_floats_bf16w.argtypes = [i, i, i]
+    lib.fnssl_lstm_packed_floats_bf16w.restype = sz
+    lib.fnssl_lstm_pack_bf16w.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.fnssl_lstm_reserve_bytes.argtypes = [i, i, i, i]
     lib.fnssl_lstm_reserve_bytes.restype = sz
     lib.fnssl_lstm_bwd_packed_floats.argtypes = [i, i]
@@ -187,6 +192,7 @@ def load():
     lib.fnssl_conv3x3_packed_floats_bf16.restype = sz
     lib.fnssl_conv3x3_pack_bf16.argtypes = [vp, i, i, i, vp]
     lib.fnssl_conv3x3_causal_bf16.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
+    lib.fnssl_conv3x3_causal_bf16a.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
     lib.fnssl_avgpool_time.argtypes = [vp, i, i, i, i, vp, vp]
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz

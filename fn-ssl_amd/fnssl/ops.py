@@ -58,6 +58,18 @@ def on_device(fn):
     return wrapped
 
 
+def _need_dev_act(*tensors):
+    """Activation tensors of the wide bf16 path: ROCm tensors of float32 or bfloat16."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError("fnssl: expected a ROCm device tensor (this path has no CPU implementation), got %s"
+                               % (t.device if isinstance(t, torch.Tensor) else type(t)))
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("fnssl: expected float32 or bfloat16, got %s" % t.dtype)
+
+
 def _stream():
     """The current HIP stream of the current device (ops run under ``on_device``)."""
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -215,6 +227,25 @@ def pack_lstm_bf16(w_ih, w_hh, b_ih, b_hh, c0: int, c2: int, device) -> torch.Te
     return torch.from_numpy(out).to(device)
 
 
+def pack_lstm_bf16w(w_ih, w_hh, b_ih, b_hh, c0: int, c2: int, device) -> torch.Tensor:
+    """Weight stream of the WIDE bf16 kernels (32 sequences per wave, lstm_bf16w.h): gate-row tiles of bf16
+    A operands, the bias as three bf16 terms of a constant-one block.  c0, c2, hidden multiples of 16."""
+    arrs = [np.ascontiguousarray(a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else a, dtype=np.float32)
+            for a in (w_ih, w_hh, b_ih, b_hh)]
+    hidden = arrs[1].shape[1]
+    if arrs[0].shape != (4 * hidden, c0 + c2) or arrs[1].shape != (4 * hidden, hidden):
+        raise RuntimeError("fnssl.pack_lstm_bf16w: weight shapes %s / %s do not match c0+c2=%d, H=%d"
+                           % (arrs[0].shape, arrs[1].shape, c0 + c2, hidden))
+    lib = _lib.load()
+    n = lib.fnssl_lstm_packed_floats_bf16w(c0, c2, hidden)
+    if n == 0:
+        raise RuntimeError("fnssl.pack_lstm_bf16w: unsupported sizes c0=%d c2=%d H=%d (multiples of 16)" % (c0, c2, hidden))
+    out = np.empty(n, dtype=np.float32)
+    check(lib.fnssl_lstm_pack_bf16w(*[a.ctypes.data_as(C.c_void_p) for a in arrs], c0, c2, hidden,
+                                    out.ctypes.data_as(C.c_void_p)), "lstm_pack_bf16w")
+    return torch.from_numpy(out).to(device)
+
+
 def _view(t, mode):
     """4-D logical [nb, nt, nf, C] tensor -> (View, q_inner) for 'full' (seq=(b,t), step=f) or
     'narrow' (seq=(b,f), step=t)."""
@@ -227,10 +258,11 @@ def _view(t, mode):
 
 
 def _conform(t):
-    """Channel-contiguous, 16-byte aligned, strides multiples of 4 floats — else copy (plumbing only)."""
+    """Channel-contiguous, 16-byte aligned, strides multiples of 4 floats (8 bf16) — else copy (plumbing only)."""
     if t is None:
         return None
-    ok = t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % 4 == 0 for s in t.stride()[:-1])
+    m = 8 if t.dtype == torch.bfloat16 else 4
+    ok = t.stride(-1) == 1 and t.data_ptr() % 16 == 0 and all(s % m == 0 for s in t.stride()[:-1])
     return t if ok else t.contiguous()
 
 
@@ -259,7 +291,7 @@ def release_workspaces():
 
 @on_device
 def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
-               reserve=None, carry_workspace=None, carry=False, bf16=False):
+               reserve=None, carry_workspace=None, carry=False, bf16=False, wide=False):
     """One (bi)LSTM layer over strided views.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
@@ -275,8 +307,15 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     ``out`` in memory (the caller's buffer holds the previous call's last h there).
     ``bf16=True``: ``packed`` comes from ``pack_lstm_bf16`` and the matrix product runs on bf16 MFMAs (operands
     rounded to bf16, fp32 accumulate; all tensors stay fp32).
+    ``wide=True`` (with bf16): the 32-sequences-per-wave kernels — ``packed`` from ``pack_lstm_bf16w``; x0 / x2 /
+    out may each be float32 or bfloat16 tensors (bf16 between layers: the values are rounded to bf16 on entry to
+    the next MFMA anyway), no x1 / skip / reserve / carry.
     """
-    _need_dev(x0, x1, x2, out, skip, out_sum, *packed)
+    if wide:
+        _need_dev_act(x0, x2, out)
+        _need_dev(x1, skip, out_sum, *packed)
+    else:
+        _need_dev(x0, x1, x2, out, skip, out_sum, *packed)
     if mode not in ("full", "narrow"):
         raise RuntimeError("fnssl.lstm_layer: mode must be 'full' or 'narrow'")
     ref = x0 if x0 is not None else x2
@@ -328,7 +367,13 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
         ws = _workspace(wsb, out.device, "lstm")
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.variant = variant
-    d.precision = 1 if bf16 else 0
+    d.precision = (2 if wide else 1) if bf16 else 0
+    if wide:
+        if not bf16:
+            raise RuntimeError("fnssl.lstm_layer: wide=True is a bf16 mode")
+        d.f32_mask = ((1 if (x0 is not None and x0.dtype == torch.float32) else 0) |
+                      (2 if (x2 is not None and x2.dtype == torch.float32) else 0) |
+                      (4 if out.dtype == torch.float32 else 0))
     if reserve is not None:
         _need_dev(reserve)
         d.reserve, d.reserve_bytes = reserve.data_ptr(), reserve.numel() * 4
@@ -429,7 +474,11 @@ def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none", bf16: bool = Fa
     xa / xb: logical [nb, nf, nt, C] tensors with arbitrary batch / bin / time strides and a
     contiguous channel dimension (xb may be None).  Returns [nb, nf, nt, ceil4(cout)] channels-last
     (padding channels are 0)."""
-    _need_dev(xa, xb, packed)
+    _need_dev_act(xa)
+    _need_dev(xb, packed)
+    a_bf = xa.dtype == torch.bfloat16
+    if a_bf and not bf16:
+        raise RuntimeError("fnssl.conv3x3_causal: a bfloat16 input needs the bf16 kernel (bf16=True)")
     xa, xb = _conform(xa), _conform(xb)
     nb, nf, nt, ca = xa.shape
     cb = 0 if xb is None else xb.shape[3]
@@ -442,7 +491,8 @@ def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none", bf16: bool = Fa
     sa = xa.stride()
     sb_ = xb.stride() if xb is not None else (0, 0, 0, 1)
     code = {"none": 0, "relu": 1, "tanh": 2}[act]
-    fn = _lib.load().fnssl_conv3x3_causal_bf16 if bf16 else _lib.load().fnssl_conv3x3_causal
+    lib = _lib.load()
+    fn = (lib.fnssl_conv3x3_causal_bf16a if a_bf else lib.fnssl_conv3x3_causal_bf16) if bf16 else lib.fnssl_conv3x3_causal
     check(fn(_ptr(xa), sa[0], sa[1], sa[2], ca,
              _ptr(xb) if xb is not None else None, sb_[0], sb_[1], sb_[2], cb,
              _ptr(packed), cout, nb, nf, nt, code, _ptr(out), cs, _stream()),

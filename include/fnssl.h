@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 4
+#define FNSSL_ABI_VERSION 5
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -146,10 +146,23 @@ typedef struct {
    * to bf16, accumulation / gates / cell state / all tensors stay fp32 (BASELINE config 3).  Built for
    * the IPDnet layer shapes (c0, c2 multiples of 16, no src1 / out_sum).                              */
   int precision;
+  /* FNSSL_PRECISION_BF16W only: element types of the activation tensors.  Bit 0 / 1 / 2 set = src0 / src2 / out hold
+   * fp32, clear = bf16 (then the pointer addresses 2-byte elements; view strides always count ELEMENTS and must be
+   * multiples of 8 for bf16 tensors).                                                                  */
+  int f32_mask;
 } fnssl_lstm_desc;
 
 #define FNSSL_PRECISION_FP32 0
 #define FNSSL_PRECISION_BF16 1
+/* "wide" bf16 kernels (lstm_bf16w.h): same arithmetic contract as FNSSL_PRECISION_BF16 — weights and the [x | h]
+ * operands rounded to bf16, fp32 accumulation, gates and cell state — on v_mfma_f32_32x32x16_bf16 with 32 sequences
+ * per wave, an LDS-DMA weight ring and bf16 activation tensors between layers (f32_mask).  wpack from
+ * fnssl_lstm_pack_bf16w.  Built for the IPDnet hidden-256 layer shapes; no src1 / out_sum / reserve / carry. */
+#define FNSSL_PRECISION_BF16W 2
+
+size_t fnssl_lstm_packed_floats_bf16w(int c0, int c2, int hidden);
+int fnssl_lstm_pack_bf16w(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                          int c0, int c2, int hidden, float* packed);
 
 /* bf16 weight stream (bias stays fp32): size in floats, and the host-only packer. */
 size_t fnssl_lstm_packed_floats_bf16(int c0, int c2, int hidden);
@@ -343,6 +356,13 @@ int fnssl_conv3x3_causal_bf16(const float* xa, long long a_sb, long long a_sf, l
                               const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
                               const float* wpack, int cout, int nb, int nf, int nt, int act,
                               float* out, int cout_stride, void* stream);
+
+/* Same, with segment A held as bf16 (what the wide bf16 LSTM kernels write): xa_bf16 addresses 2-byte elements,
+ * a_sb / a_sf / a_st count elements (multiples of 4), base 8-byte aligned; xb stays fp32. */
+int fnssl_conv3x3_causal_bf16a(const void* xa_bf16, long long a_sb, long long a_sf, long long a_st, int ca,
+                               const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
+                               const float* wpack, int cout, int nb, int nf, int nt, int act,
+                               float* out, int cout_stride, void* stream);
 
 /* y[row, t2, c] = mean_{k < K} x[row, K*t2 + k, c]   (AvgPool2d((1, K)); c % 4 == 0). */
 int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y, void* stream);

@@ -943,3 +943,65 @@ def test_config2_full_batch_independence_and_oracle(dev):
     from fnssl import ops
     ops.release_workspaces()
     torch.cuda.empty_cache()
+
+
+# --------------------------------------------------------------------------- wide bf16 kernels (32 sequences per wave)
+@pytest.mark.parametrize("mode,H,bidir,c0,c2,nb,nt,nf,x0_bf", [
+    ("narrow", 256, False, 256, 16, 1, 9, 40, True),     # ragged: 40 sequences = one full + one partial 32-group
+    ("narrow", 256, False, 256, 16, 3, 5, 64, True),     # 192 sequences: several workgroups
+    ("full", 128, True, 256, 16, 1, 20, 7, True),        # block-2 full-band, both directions, 20 sequences
+    ("full", 128, True, 16, 0, 2, 33, 6, False),         # block-1 full-band: 16 fp32 feature channels, 66 sequences
+])
+def test_lstm_bf16_wide_matches_oracle_and_narrow_kernel(dev, mode, H, bidir, c0, c2, nb, nt, nf, x0_bf):
+    """lstm_bf16w.h (v_mfma_f32_32x32x16_bf16, LDS-DMA tile ring, bf16 activations, bias as three bf16 terms) against
+    the bf16-emulating oracle, and against the 16-sequence bf16 kernel on the same bf16-representable input."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    I = c0 + c2
+    sd = lstm_state(I, H, bidir, 5100 + H + I)
+    x = O.bf16_round(rs_randn(5101, (nb, nt, nf, I), 0.7))            # bf16-representable: both kernels see the same x
+    seq = x.reshape(nb * nt, nf, I) if mode == "full" else np.transpose(x, (0, 2, 1, 3)).reshape(nb * nf, nt, I)
+    want = O.lstm(seq, sd, "L.", bidir, bf16=True)
+    ndir = 2 if bidir else 1
+    want = want.reshape(nb, nt, nf, -1) if mode == "full" else np.transpose(want.reshape(nb, nf, nt, -1), (0, 2, 1, 3))
+    sfx = [""] + (["_reverse"] if bidir else [])
+    args = lambda s: (sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s], sd["L.bias_hh_l0" + s])  # noqa: E731
+    ww = [ops.pack_lstm_bf16w(*args(s), c0, c2, dev) for s in sfx]
+    wn = [ops.pack_lstm_bf16(*args(s), c0, c2, dev) for s in sfx]
+    xd = to_dev(x, dev)
+    x0 = xd[..., :c0].contiguous()
+    x2 = xd[..., c0:].contiguous() if c2 else None
+    out_w = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev, dtype=torch.bfloat16)
+    ops.lstm_layer(mode, x0.bfloat16() if x0_bf else x0, None, x2, ww, H, out_w, bf16=True, wide=True)
+    out_n = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+    ops.lstm_layer(mode, x0, None, x2, wn, H, out_n, bf16=True)
+    got = out_w.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    # the wide kernel's output is itself rounded to bf16 (2^-9 relative, |h| <= 1)
+    assert np.abs(got - want).max() <= BF_ATOL + 2e-3, "vs bf16 oracle: %g" % np.abs(got - want).max()
+    assert np.abs(got - out_n.cpu().numpy()).max() <= BF_ATOL + 2e-3
+    # typical agreement is at rounding level, not at the worst-case bound
+    assert np.abs(got - O.bf16_round(want)).mean() < 2e-4
+
+
+def test_lstm_bf16_wide_rejects_unbuilt_shapes(dev):
+    from fnssl import ops
+    sd = lstm_state(128, 256, False, 5200)
+    w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], 128, 0, dev)]
+    x = torch.zeros((1, 4, 16, 128), device=dev, dtype=torch.bfloat16)
+    out = torch.zeros((1, 4, 16, 256), device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="wide bf16 path is not built"):
+        ops.lstm_layer("narrow", x, None, None, w, 256, out, bf16=True, wide=True)
+
+
+def test_conv3x3_bf16_input_matches_fp32_input(dev):
+    """fnssl_conv3x3_causal_bf16a (segment A arrives as bf16) == the bf16 kernel fed the same values as fp32."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    w = rs_randn(5300, (128, 272, 3, 3), 0.05)
+    xa = O.bf16_round(rs_randn(5301, (2, 5, 19, 256)))
+    xb = rs_randn(5302, (2, 5, 19, 16))
+    packed = ops.pack_conv3x3(w, 256, 16, dev, bf16=True)
+    a = ops.conv3x3_causal(to_dev(xa, dev), to_dev(xb, dev), packed, 128, "relu", bf16=True)
+    b = ops.conv3x3_causal(to_dev(xa, dev).bfloat16(), to_dev(xb, dev), packed, 128, "relu", bf16=True)
+    assert torch.equal(a, b)

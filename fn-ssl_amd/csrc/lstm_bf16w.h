@@ -94,11 +94,16 @@ __device__ __forceinline__ v8bfw join8(v4bfw lo, v4bfw hi) { return __builtin_sh
 // NW consumer waves (32 sequences each) + NL loader waves.  NL = 0: the consumers fetch the stream themselves.  NL > 0
 // (launches that leave SIMDs idle anyway — IPDnet's narrow-band layers at batch 64 are 2 groups per CU): the DMA issue
 // (4 instructions per KiB) moves to waves on the idle SIMDs and the consumers' issue slots go to MFMAs and gate math.
-template <int H, int NW, int NB0, int NB2, int FLAGS, int NSLOT, int NL>
+// ABL (make ABLATE=1 builds only): timing ablations with wrong results — 1 no gate math, 2 no barriers, 4 no MFMAs,
+// 8 no A-operand LDS reads, 16 no output stores / h staging, 32 no x loads
+template <int H, int NW, int NB0, int NB2, int FLAGS, int NSLOT, int NL, int ABL = 0>
 __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmParams p) {
   constexpr int NT = H / 8, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr int NF = NL > 0 ? NL : NW;                    // waves that fetch
-  constexpr int KPW = (KT + NF - 1) / NF;                 // records each of them fetches per tile
+  constexpr int KP = KT / 2;                              // ring granule: half a tile ("piece")
+  constexpr int KPW = (KP + NF - 1) / NF;                 // records each fetching wave requests per piece
+  constexpr int NPS = 2 * NT;                             // pieces per step
+  static_assert(KT % 2 == 0, "tiles are fetched in two pieces");
   constexpr bool F0 = FLAGS & kW_F0, F2 = FLAGS & kW_F2, OUTF = FLAGS & kW_OUTF;
   constexpr int AD = 4;                                   // A-operand reads in flight ahead of the MFMA that uses them
   constexpr int RING = NSLOT * KT * 1024, HBUF = NKH * 1024;   // bytes: weight ring; one wave's h_t staging area
@@ -131,41 +136,47 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
   const bool rev = dir == 1;
   const unsigned lds0 = (unsigned)(size_t)smem;            // LDS byte address of the ring
 
-  // ---- weight ring: slot = one tile (KT KiB).  Protocol per tile T (one barrier, at the tile's start):
-  //   s_waitcnt vmcnt(0): my share of tile T + 1 (requested one tile-time ago) has landed;  s_barrier: so has
-  //   everybody's, and everybody is done reading tile T - 1;  then request tile T + 2 into the slot T - 1 vacated.
-  // While tile T is consumed, tile T + 1 is therefore complete in LDS: the A-operand prefetch runs across the tile
-  // boundary without another synchronisation.
+  // ---- weight ring: NSLOT tiles = 6 half-tile pieces of KP KiB, one barrier per piece.  At the barrier that opens
+  // piece j: piece j + 1 has landed everywhere (so the A-operand prefetch may run across the boundary), pieces
+  // j + 2 .. j + 4 are in flight (1.5 tile-times, > 1500 cycles, of cover for an L2 round trip under load — with
+  // whole tiles and one request in flight per loader the ring, not the MFMAs, set the pace: 2400 cycles per tile),
+  // and everybody is done with piece j - 1, whose slot the request for piece j + 5 takes.  A fetching wave certifies
+  // its share with s_waitcnt vmcnt(3 * KPW): loads complete in order, so all but its youngest 3 * KPW are done.
   const int fw = NL > 0 ? w - NW : w;                      // my index among the fetching waves (< 0: I do not fetch)
-  const int rlast = fw + (KPW - 1) * NF < KT ? fw + (KPW - 1) * NF : KT - 1;   // past the end: repeat the last record
-  auto fetch_tile = [&](int tile_in_step, int slot) {     // my share: records fw, fw + NF, ...
-    const unsigned sb = (unsigned)(tile_in_step * KT) * 1024u, lb = lds0 + (unsigned)(slot * KT) * 1024u;
+  const int rlast = fw + (KPW - 1) * NF < KP ? fw + (KPW - 1) * NF : KP - 1;   // past the end: repeat the last record
+  auto fetch_piece = [&](int piece_in_step, int slot) {   // my share: records fw, fw + NF, ... of the piece
+    const unsigned sb = (unsigned)(piece_in_step * KP) * 1024u, lb = lds0 + (unsigned)(slot * KP) * 1024u;
     static_for<KPW - 1>([&](auto mc) {
       dma16_imm<decltype(mc)::value * NF * 1024>(rw, vlane, sb + (unsigned)fw * 1024u, lb + (unsigned)fw * 1024u);
     });
     dma16_imm<0>(rw, vlane, sb + (unsigned)rlast * 1024u, lb + (unsigned)rlast * 1024u);
   };
+  int ft = 0, fslot = 0;                                   // next piece to request (position inside the step), its slot
+  auto fetch_next = [&]() {
+    fetch_piece(ft, fslot);
+    ft = ft + 1 == NPS ? 0 : ft + 1;
+    fslot = fslot + 1 == 2 * NSLOT ? 0 : fslot + 1;
+  };
+  auto fetch_barrier = [&]() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * KPW) : "memory"); };
+  if (fw >= 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) fetch_next();
+  }
   if constexpr (NL > 0) {
     if (w >= NW) {   // ---- loader wave: the same barrier sequence as the consumers, nothing but DMA in between
-      fetch_tile(0, 0);
-      fetch_tile(NT > 1 ? 1 : 0, 1);
-      int lt = NT > 2 ? 2 : 0, ls = 2;
-      const long long ntiles = (long long)NT * p.nsteps;
-      for (long long g = 0; g < ntiles; ++g) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        fetch_tile(lt, ls);
-        lt = lt + 1 == NT ? 0 : lt + 1;
-        ls = ls + 1 == NSLOT ? 0 : ls + 1;
+      const long long npieces = (long long)NPS * p.nsteps;
+      for (long long g = 0; g < npieces; ++g) {
+        if constexpr (ABL & 2)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * KPW) : "memory");
+        else
+          fetch_barrier();
+        fetch_next();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       return;
     }
-  } else {
-    fetch_tile(0, 0);
-    fetch_tile(NT > 1 ? 1 : 0, 1);
   }
-  int ft = NT > 2 ? 2 : 0, fslot = 2;                      // next tile to request (position inside the step) and its slot
-  int cslot = 0;                                           // slot of the tile being consumed
+  int cslot = 0;                                           // slot (in tiles) of the tile being consumed
 
   // ---- state ---------------------------------------------------------------------------------------------------
   const v4bfw zb4 = v4bfw{0, 0, 0, 0};
@@ -209,14 +220,17 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
   auto arec = [&](const char* base, int r) { return __builtin_bit_cast(v8bfw, *reinterpret_cast<const v4f*>(base + r * 1024)); };
   // With loader waves the consumers never wait on vector memory at a tile boundary (their x loads and h stores are
   // waited for where the compiler needs them); without, a wave also certifies its own DMA share.
-  auto tile_barrier = [&]() {
-    if constexpr (NL > 0)
+  auto piece_barrier = [&]() {
+    if constexpr (ABL & 2) return;
+    if constexpr (NL > 0) {
       asm volatile("s_barrier" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      fetch_barrier();
+      fetch_next();
+    }
   };
-  // the first tile of all: wait for it, publish, and prime the A pipeline
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  // the first piece of all: wait for it, publish, and prime the A pipeline
+  piece_barrier();
   v8bfw apipe[AD];
 #pragma unroll
   for (int i = 0; i < AD; ++i) apipe[i] = arec(lds_rd, i);
@@ -233,6 +247,10 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
   bool pend_live = false;
   auto gate = [&](auto tp, unsigned oo_t) {     // post-process tile TP (of the step whose output offset is oo_t)
     constexpr int TP = decltype(tp)::value;
+    if constexpr (ABL & 1) {
+      creg[TP] += v4f{accp[0], accp[5], accp[10], accp[15]};
+      return;
+    }
     // gates of units 8 TP + 4 hb + j (j = 0..3) of the lane's sequence: D register 4 * gate + j
     const v4f ig = sigmoid4(v4f{accp[0], accp[1], accp[2], accp[3]});
     const v4f fg = sigmoid4(v4f{accp[4], accp[5], accp[6], accp[7]});
@@ -242,6 +260,10 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
     const v4f hn = mul_rn4(og, tanh4(cn));
     creg[TP] = cn;
     const v4bfw hb4 = __builtin_convertvector(hn, v4bfw);
+    if constexpr (ABL & 16) {
+      creg[TP].x += (float)hb4[0];
+      return;
+    }
     if constexpr (NL > 0) {
       if (valid) {
         if constexpr (OUTF)
@@ -282,15 +304,10 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
 
     static_for<NT>([&](auto tc) {
       constexpr int T = decltype(tc)::value;
-      if (T > 0 || step > 0) tile_barrier();                // see the protocol above
-      if constexpr (NL == 0) {
-        fetch_tile(ft, fslot);
-        ft = ft + 1 == NT ? 0 : ft + 1;
-        fslot = fslot + 1 == NSLOT ? 0 : fslot + 1;
-      }
+      if (T > 0 || step > 0) piece_barrier();               // see the protocol above
       flush_pending();
       // the next step's input blocks trickle in, one block per tile
-      if constexpr (T < NKX) xn[T] = load_x(ic<T>{}, ttn);
+      if constexpr (T < NKX && !(ABL & 32)) xn[T] = load_x(ic<T>{}, ttn);
 
       const char* cb = lds_rd + cslot * (KT * 1024);
       cslot = cslot + 1 == NSLOT ? 0 : cslot + 1;
@@ -301,6 +318,8 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
       } else {
         if (step > 0) gate(ic<NT - 1>{}, oo_prev);
       }
+      // (two alternating accumulators were tried — a same-accumulator MFMA chain with instructions in between pays a
+      //  re-issue penalty — and lost 8 %: the chain is not what paces this loop)
       v16f acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       // record K of tile T sits in register (T * KT + K) % AD of the A pipeline, which runs on across tiles;
       // NT * KT % AD == 0, so the phase only depends on the tile's position inside the step
@@ -308,17 +327,23 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
       static_for<KT>([&](auto kc) {
         constexpr int K = decltype(kc)::value;
         constexpr int R = (T * KT + K) % AD;
+        if constexpr (K == KP) piece_barrier();             // second half of the tile
         if constexpr (T == 0 && K == 1 + NKX) {
           if (step > 0) reload_h();                         // the last tile's h has just been staged
         }
-        const v8bfw a = apipe[R];
-        apipe[R] = (K + AD < KT) ? arec(cb, K + AD) : arec(nb_, K + AD - KT);
-        if constexpr (K == 0)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc, 0, 0, 0);          // + bias (exact)
-        else if constexpr (K <= NKX)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[K - 1 < NKX ? K - 1 : 0], acc, 0, 0, 0);
-        else
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hop[K - 1 - NKX], acc, 0, 0, 0);
+        if constexpr (!(ABL & 4)) {
+          const v8bfw a = apipe[R];
+          if constexpr (!(ABL & 8)) apipe[R] = (K + AD < KT) ? arec(cb, K + AD) : arec(nb_, K + AD - KT);
+          if constexpr (K == 0)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, acc, 0, 0, 0);          // + bias (exact)
+          else if constexpr (K <= NKX)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[K - 1 < NKX ? K - 1 : 0], acc, 0, 0, 0);
+          else
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hop[K - 1 - NKX], acc, 0, 0, 0);
+        } else {
+          acc[K % 16] += (float)apipe[R][0];
+          apipe[R] = (K + AD < KT) ? arec(cb, K + AD) : arec(nb_, K + AD - KT);
+        }
       });
       accp = acc;
     });
@@ -335,11 +360,11 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int H, int NW, int NB0, int NB2, int FLAGS, int NSLOT, int NL>
+template <int H, int NW, int NB0, int NB2, int FLAGS, int NSLOT, int NL, int ABL = 0>
 int launch_bf16w_k(const LstmParams& p, int nwg, hipStream_t st) {
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
   const size_t lds = (size_t)NSLOT * KT * 1024 + (size_t)NW * (H / 16) * 1024;
-  auto k = lstm_bf16w_kernel<H, NW, NB0, NB2, FLAGS, NSLOT, NL>;
+  auto k = lstm_bf16w_kernel<H, NW, NB0, NB2, FLAGS, NSLOT, NL, ABL>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3((NW + NL) * 64), lds, st, p);

@@ -1,8 +1,9 @@
 // Wide bf16-MFMA LSTM kernels (lstm_bf16w.h): instantiations for the IPDnet (hidden 256) layer shapes, the packer of
 // the tile-ordered bf16 weight stream and the launch planner.
+#include <cstdlib>
 #include <cstring>
 
-#include "lstm_bf16w.h"
+#include "lstm_bf16p.h"
 
 namespace fnssl_lstm {
 
@@ -24,17 +25,46 @@ int launch_bf16w(const LstmParams& p, int H, int NW, int flags, int nwg, hipStre
   return kNoStatic;
 }
 
-// One launch: every 32-sequence group of every direction; 2 waves per workgroup while that still gives one workgroup
-// per CU (the ring of a workgroup takes most of a CU's LDS), else 4.
+#define TRYP(H_, NB0_, NB2_, FL_)                                                    \
+  if (H == H_ && p.c0 == 16 * NB0_ && p.c2 == 16 * NB2_ && flags == (FL_)) return launch_bf16p_k<H_, NB0_, NB2_, FL_>(p, nwg, st);
+
+// pair-split kernels (lstm_bf16p.h): workgroup = 2 groups of 32 sequences x 2 roles
+int launch_bf16p(const LstmParams& p, int H, int flags, int nwg, hipStream_t st) {
+#ifdef FNSSL_BUILD_ABLATE   // timing ablations of the config-3 narrow-band kernel (wrong results): make ABLATE=1 only
+  if (const char* e = getenv("FNSSL_BF16W_ABL")) {
+    if (H == 256 && p.c0 == 256 && p.c2 == 16 && flags == kW_F2) {
+      switch (atoi(e)) {
+        case 1: return launch_bf16p_k<256, 16, 1, kW_F2, 1>(p, nwg, st);
+        case 4: return launch_bf16p_k<256, 16, 1, kW_F2, 4>(p, nwg, st);
+        case 5: return launch_bf16p_k<256, 16, 1, kW_F2, 5>(p, nwg, st);
+        default: break;
+      }
+    }
+  }
+#endif
+  TRYP(128, 1, 0, kW_F0)
+  TRYP(256, 16, 1, kW_F2)
+  TRYP(128, 16, 1, kW_F2)
+  return kNoStatic;
+}
+
+// One launch: every 32-sequence group of every direction.  Default: the pair-split kernels; FNSSL_BF16W_SOLO=1 keeps
+// the one-wave-per-group kernels of lstm_bf16w.h (A/B).
 int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st) {
   const int ncu = fnssl::device_cus();
   const int groups = (p.nseq + 31) / 32;
   const long long total = (long long)groups * p.ndir;
-  const int nw = (total <= 2ll * ncu || H >= 256) ? 2 : 4;
   p.task0 = 0;
   p.task1 = groups;
-  p.wgs_per_dir = (groups + nw - 1) / nw;
-  const int rc = launch_bf16w(p, H, nw, flags, p.wgs_per_dir * p.ndir, st);
+  int rc;
+  if (!getenv("FNSSL_BF16W_SOLO")) {
+    p.wgs_per_dir = (groups + 1) / 2;
+    rc = launch_bf16p(p, H, flags, p.wgs_per_dir * p.ndir, st);
+  } else {
+    const int nw = (total <= 2ll * ncu || H >= 256) ? 2 : 4;
+    p.wgs_per_dir = (groups + nw - 1) / nw;
+    rc = launch_bf16w(p, H, nw, flags, p.wgs_per_dir * p.ndir, st);
+  }
   if (rc == kNoStatic) {
     fnssl::set_error("lstm_forward: the wide bf16 path is not built for hidden %d, inputs (%d, %d), element mask %d", H,
                      p.c0, p.c2, flags);

@@ -283,6 +283,10 @@ class FnsslTrain:
         net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.sd.items()})
         self.net = net.to(dev)
         self.eng = train.TrainEngine(self.net, seed=1, chunk_pairs=args.chunk_pairs or None)
+        # --c-step: the whole step as ONE C call (fnssl_train_step); single process only (no all-reduce inside)
+        self.cstep = train.CTrainStep(self.eng) if args.c_step else None
+        if self.cstep is not None and world > 1:
+            raise SystemExit("--c-step is the single-process entry point (fnssl_train_step has no collective)")
         g = torch.Generator(device=dev)
         g.manual_seed(100 + rank)
         self.npair = self.mics * (self.mics - 1) // 2
@@ -296,6 +300,9 @@ class FnsslTrain:
 
     def step(self):
         x = self.ops.preprocess(self.sig, "MM", layout=1)
+        if self.cstep is not None:
+            self.cstep.step_nosync(x, self.gt, 1000003 + 8191 * (self.eng.step_count + 1))
+            return self.eng.loss_dev
         return self.eng.step(x, self.gt, sync_loss=False)
 
     def check(self, out):
@@ -445,6 +452,7 @@ def main():
                     help="config 2, NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, "
                          "fp32 accumulate/tensors); reported with dtype 'bf16' and its measured deviation")
     ap.add_argument("--fp32", action="store_true", help="config 3 in fp32 instead of bf16")
+    ap.add_argument("--c-step", action="store_true", help="config 4: the step as one C call (fnssl_train_step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample (config 2)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample (config 2)")

@@ -175,7 +175,10 @@ typedef unsigned int v2uc __attribute__((ext_vector_type(2)));
 
 // ABF: segment A arrives as bf16 (the wide bf16 LSTM kernels write bf16 activations): its blocks are ready-made
 // operand halves, no conversion and half the bytes.
-template <int NT, int NW, int M, bool ABF = false>
+// PT: 16-position tiles per wave.  With PT = 1 every 1 KiB weight record read from LDS feeds ONE 16-cycle MFMA, i.e.
+// 12 waves ask the LDS for 3x its 256 B/clk (round 1: 15 % of the bf16 roof, LDS array 18 % "busy" but the waves parked
+// 75 %); with PT = 2 a record feeds two MFMAs (the wave owns 32 consecutive time positions).
+template <int NT, int NW, int M, bool ABF = false, int PT = 2>
 __global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams p) {
   static_assert(NT == 4 || NT == 8, "4 or 8 output-channel tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,6 +191,7 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams 
   ws.init(p.wpack, lane, w, p.quads_per_pass, 1, p.chq, p.pad, smem);
   const int nva = p.ca >> 4, nv = nva + (p.cb >> 4), npairs = (nv + 1) >> 1;
   const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+  const v4bf zb = v4bf{0, 0, 0, 0};
 
   for (int pass = 0; pass < p.passes; ++pass) {
     int tile = (pass * (int)gridDim.x + (int)blockIdx.x) * NW + w;
@@ -201,67 +205,85 @@ __global__ void __launch_bounds__(NW * 64) conv3x3_bf16_kernel(const ConvParams 
                           : make_rsrc(p.xa + (long long)b * p.a_sb);
     const rsrc_t rb = make_rsrc(p.xb ? p.xb + (long long)b * p.b_sb : p.xa);
     const rsrc_t ro = make_rsrc(p.out + (long long)b * p.nf * p.nt * p.cout_stride);
-    int tpos = tt * 16 + n;
-    const bool pvalid = tvalid && tpos < p.nt;
-    v4f acc[NT];
+    const int tpos0 = tt * (16 * PT) + n;
+    v4f acc[NT][PT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = zero4;
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < PT; ++q) acc[j][q] = zero4;
 
     for (int df = -1; df <= 1; ++df) {
       const int ff = f + df;
       const bool frow = ff >= 0 && ff < p.nf;
       const int fc = frow ? ff : f;
       for (int dt = 0; dt < 3; ++dt) {
-        int ts = tpos + dt - 2;
-        const bool live = frow && ts >= 0;
-        ts = ts < 0 ? 0 : (ts >= p.nt ? p.nt - 1 : ts);
-        const unsigned offa = (unsigned)(((long long)fc * p.a_sf + (long long)ts * p.a_st) * (ABF ? 2 : 4)) +
-                              (ABF ? 8 : 16) * g;
-        const unsigned offb = (unsigned)(((long long)fc * p.b_sf + (long long)ts * p.b_st) * 4) + 16 * g;
+        unsigned offa[PT], offb[PT];
+        bool live[PT];
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+          int ts = tpos0 + 16 * q + dt - 2;
+          live[q] = frow && ts >= 0;
+          ts = ts < 0 ? 0 : (ts >= p.nt ? p.nt - 1 : ts);
+          offa[q] = (unsigned)(((long long)fc * p.a_sf + (long long)ts * p.a_st) * (ABF ? 2 : 4)) + (ABF ? 8 : 16) * g;
+          offb[q] = (unsigned)(((long long)fc * p.b_sf + (long long)ts * p.b_st) * 4) + 16 * g;
+        }
         // 16-channel block v of [xa | xb] as the lane's 4 bf16 operand values (channels 16 v + 4 g + 0..3)
-        auto block = [&](int v) -> v4bf {
-          if (v >= nv) return v4bf{0, 0, 0, 0};
+        auto block = [&](int v, int q) -> v4bf {
+          if (v >= nv) return zb;
           if (v < nva) {
             if constexpr (ABF)
-              return __builtin_bit_cast(v4bf, __builtin_amdgcn_raw_buffer_load_b64(ra, offa, 32 * v, 0));
+              return __builtin_bit_cast(v4bf, __builtin_amdgcn_raw_buffer_load_b64(ra, offa[q], 32 * v, 0));
             else
-              return __builtin_convertvector(bld4(ra, offa, 64 * v), v4bf);
+              return __builtin_convertvector(bld4(ra, offa[q], 64 * v), v4bf);
           }
-          return __builtin_convertvector(bld4(rb, offb, 64 * (v - nva)), v4bf);
+          return __builtin_convertvector(bld4(rb, offb[q], 64 * (v - nva)), v4bf);
         };
-        v4bf n0 = block(0), n1 = block(1);
+        v4bf n0[PT], n1[PT];
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+          n0[q] = block(0, q);
+          n1[q] = block(1, q);
+        }
         for (int pi = 0; pi < npairs; ++pi) {
-          v4bf lo = n0, hi = n1;
-          if (!live) {
-            lo = v4bf{0, 0, 0, 0};
-            hi = v4bf{0, 0, 0, 0};
+          v8bf bv[PT];
+#pragma unroll
+          for (int q = 0; q < PT; ++q) {
+            const v4bf lo = live[q] ? n0[q] : zb, hi = live[q] ? n1[q] : zb;
+            bv[q] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            n0[q] = block(2 * pi + 2, q);   // operands of the next pair: in flight behind this pair's MFMAs
+            n1[q] = block(2 * pi + 3, q);
           }
-          n0 = block(2 * pi + 2);   // operands of the next pair: in flight behind this pair's MFMAs
-          n1 = block(2 * pi + 3);
-          const v8bf bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int qd = 0; qd < NT / 4; ++qd) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[4 * qd + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, ws.record(j)), bv,
-                                                                        acc[4 * qd + j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+              const v8bf av = __builtin_bit_cast(v8bf, ws.record(j));
+#pragma unroll
+              for (int q = 0; q < PT; ++q)
+                acc[4 * qd + j][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[q], acc[4 * qd + j][q], 0, 0, 0);
+            }
             (void)ws.advance();
           }
         }
       }
     }
     for (int u = 0; u < p.pad; ++u) (void)ws.advance();
-    if (tpos >= p.nt) tpos = p.nt - 1;
-    const unsigned obase = (unsigned)((((long long)f * p.nt + tpos) * p.cout_stride) * 4) + 16 * g;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      v4f r = acc[j];
-      if (p.act == 1) {
-        r = v4f{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
-      } else if (p.act == 2) {
-        r = v4f{tanhf(r.x), tanhf(r.y), tanhf(r.z), tanhf(r.w)};
+    for (int q = 0; q < PT; ++q) {
+      int tpos = tpos0 + 16 * q;
+      const bool pvalid = tvalid && tpos < p.nt;
+      if (tpos >= p.nt) tpos = p.nt - 1;
+      const unsigned obase = (unsigned)((((long long)f * p.nt + tpos) * p.cout_stride) * 4) + 16 * g;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        v4f r = acc[j][q];
+        if (p.act == 1) {
+          r = v4f{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
+        } else if (p.act == 2) {
+          r = v4f{tanhf(r.x), tanhf(r.y), tanhf(r.z), tanhf(r.w)};
+        }
+        if (pvalid && 16 * j + 4 * g < p.cout) bst4(r, ro, obase, 64 * j);
       }
-      if (pvalid && 16 * j + 4 * g < p.cout) bst4(r, ro, obase, 64 * j);
     }
   }
 }
@@ -430,7 +452,7 @@ static int conv_run(int bf, const float* xa, long long a_sb, long long a_sf, lon
   p.nt = nt;
   p.act = act;
   p.a_bf16 = bf == 2;
-  p.tiles_t = (nt + 15) / 16;
+  p.tiles_t = bf ? (nt + 31) / 32 : (nt + 15) / 16;   // bf16 kernels: 32 positions per wave
   p.ntiles = nb * nf * p.tiles_t;
   const int NT = conv_nt_tiles(cout);
   constexpr int NW = 12, M = 4;

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -35,6 +35,9 @@ SYMBOLS = [
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
     "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
+    "fnssl_train_create", "fnssl_train_destroy", "fnssl_train_param_floats", "fnssl_train_param_offset",
+    "fnssl_train_map_bytes", "fnssl_train_upload_maps", "fnssl_train_workspace_bytes", "fnssl_train_backward",
+    "fnssl_train_step",
     "fnssl_sn_layernorm", "fnssl_sn_encoder", "fnssl_sn_fconv", "fnssl_sn_full", "fnssl_sn_mamba_workspace_bytes",
     "fnssl_sn_mamba", "fnssl_sn_head", "fnssl_sn_forward_workspace_bytes", "fnssl_sn_state_floats", "fnssl_sn_forward",
 ]
@@ -197,6 +200,20 @@ def load():
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz
     lib.fnssl_forward.argtypes = [C.POINTER(Net), vp, i, i, i, vp, vp, sz, i, vp]
+    lib.fnssl_train_create.argtypes = [i, C.POINTER(vp)]
+    lib.fnssl_train_destroy.argtypes = [vp]
+    lib.fnssl_train_destroy.restype = None
+    lib.fnssl_train_param_floats.argtypes = [vp]
+    lib.fnssl_train_param_floats.restype = ll
+    lib.fnssl_train_param_offset.argtypes = [vp, i, i, i]
+    lib.fnssl_train_param_offset.restype = ll
+    lib.fnssl_train_map_bytes.argtypes = [vp]
+    lib.fnssl_train_map_bytes.restype = sz
+    lib.fnssl_train_upload_maps.argtypes = [vp, vp, vp]
+    lib.fnssl_train_workspace_bytes.argtypes = [vp, i, i, i]
+    lib.fnssl_train_workspace_bytes.restype = sz
+    lib.fnssl_train_backward.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, C.c_uint, ll, ll, vp, vp, sz, vp]
+    lib.fnssl_train_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, C.c_uint, f, f, f, f, i, vp, vp, sz, vp]
     PV = C.POINTER(BtfView)
     lib.fnssl_sn_layernorm.argtypes = [vp, ll, i, vp, vp, f, vp, vp]
     lib.fnssl_sn_encoder.argtypes = [vp, ll, ll, ll, ll, i, i, i, i, vp, vp, vp, vp, vp, ll, ll, ll, vp]

@@ -443,3 +443,88 @@ class TrainEngine:
     def gradients(self):
         """name -> gradient tensor (views of the flat vector; as left by the last step, before the 1/world scale)."""
         return {k: self.gview(k) for k in self.names}
+
+
+class CTrainStep:
+    """The training backward / step as ONE C call each (``fnssl_train_backward`` / ``fnssl_train_step``): forward in
+    train mode, loss, BPTT, weight gradients (rocBLAS GEMMs called from the library), Adam — no Python in between.
+    Shares the flat parameter / gradient / moment vectors of a ``TrainEngine`` (whose layout it verifies against the
+    library's own table), so the two paths can be compared and mixed; the Python-orchestrated engine remains the one
+    that overlaps the per-layer gradient all-reduce with the backward."""
+
+    def __init__(self, engine: "TrainEngine"):
+        self.eng = engine
+        lib = _lib.load()
+        h = C.c_void_p()
+        check(lib.fnssl_train_create(1 if engine.online else 0, C.byref(h)), "train_create")
+        self.h = h
+        if lib.fnssl_train_param_floats(h) != engine.theta.numel():
+            raise RuntimeError("fnssl.train.CTrainStep: flat vector length %d != library's %d"
+                               % (engine.theta.numel(), lib.fnssl_train_param_floats(h)))
+        for li, L in enumerate(engine.layers):
+            for di, s in enumerate(L.sfx):
+                for wi, n in enumerate(("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")):
+                    if lib.fnssl_train_param_offset(h, li, di, wi) != engine.offset["%s.%s%s" % (L.name, n, s)][0]:
+                        raise RuntimeError("fnssl.train.CTrainStep: parameter layout mismatch at %s.%s%s" % (L.name, n, s))
+        if (lib.fnssl_train_param_offset(h, 6, 0, 0) != engine.offset["emb2ipd.weight"][0] or
+                lib.fnssl_train_param_offset(h, 6, 0, 1) != engine.offset["emb2ipd.bias"][0]):
+            raise RuntimeError("fnssl.train.CTrainStep: parameter layout mismatch at emb2ipd")
+        self.maps = torch.empty(lib.fnssl_train_map_bytes(h), dtype=torch.uint8, device=engine.dev)
+        with torch.cuda.device(engine.dev):
+            check(lib.fnssl_train_upload_maps(h, self.maps.data_ptr(), ops._stream()), "train_upload_maps")
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.load().fnssl_train_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _workspace(self, nbp, nf, nt):
+        n = _lib.load().fnssl_train_workspace_bytes(self.h, nbp, nf, nt)
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = None
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.eng.dev)
+        return self._ws
+
+    @ops.on_device
+    def backward(self, x, gt_ipd, seed_base, pair0=0, n_total=None):
+        """Accumulate loss and gradients of one chunk into the engine's ``loss_dev`` / ``grad`` (zero them first)."""
+        e = self.eng
+        ops._need_dev(x, gt_ipd)
+        x, gt_ipd = x.contiguous(), gt_ipd.contiguous()
+        nbp, _, nf, nt = x.shape
+        nb, nt2, nf2, npair = gt_ipd.shape
+        if n_total is None:
+            n_total = nbp * nt2 * nf2
+        ws = self._workspace(nbp, nf, nt)
+        check(_lib.load().fnssl_train_backward(self.h, e.theta.data_ptr(), e.grad.data_ptr(), x.data_ptr(), gt_ipd.data_ptr(),
+                                               nb, npair, nf, nt, seed_base & 0xFFFFFFFF, pair0, n_total,
+                                               e.loss_dev.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+              "train_backward")
+
+    def step(self, x, gt_ipd, seed_base):
+        """One single-process optimisation step (zero, backward, Adam) in one C call; returns the loss."""
+        self.step_nosync(x, gt_ipd, seed_base)
+        return float(self.eng.loss_dev.item())
+
+    @ops.on_device
+    def step_nosync(self, x, gt_ipd, seed_base):
+        """``step`` without reading the loss back (it stays in ``engine.loss_dev``)."""
+        e = self.eng
+        ops._need_dev(x, gt_ipd)
+        x, gt_ipd = x.contiguous(), gt_ipd.contiguous()
+        nbp, _, nf, nt = x.shape
+        nb, nt2, nf2, npair = gt_ipd.shape
+        ws = self._workspace(nbp, nf, nt)
+        e.step_count += 1
+        check(_lib.load().fnssl_train_step(self.h, e.theta.data_ptr(), e.grad.data_ptr(), e.exp_avg.data_ptr(),
+                                           e.exp_avg_sq.data_ptr(), x.data_ptr(), gt_ipd.data_ptr(), nb, npair, nf, nt,
+                                           seed_base & 0xFFFFFFFF, e.lr, e.betas[0], e.betas[1], e.eps, e.step_count,
+                                           e.loss_dev.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()), "train_step")
+        for m in e.model.modules():
+            for attr in ("_packed_key", "_net_key"):
+                if hasattr(m, attr):
+                    setattr(m, attr, None)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 5
+#define FNSSL_ABI_VERSION 6
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -273,6 +273,41 @@ int fnssl_mse_loss(const float* pred, const float* gt, int nb, int np, int nt2, 
  * multiplied by grad_scale first (1 / world_size after the sum all-reduce).  step counts from 1. */
 int fnssl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* ---- whole-network training backward / step (SURVEY.md 8b "later fnssl_backward"; FN-SSL/Lightning/main.py:149-157,
+ * 191-198, 269-271) ------------------------------------------------------------------------------------------
+ * The parameters, gradient and Adam moments of FN_SSL live in flat DEVICE vectors of fnssl_train_param_floats()
+ * floats: element 0 is a constant 0, then the tensors in the reference's named_parameters() order
+ * (block_k.fullLstm.{weight_ih_l0, weight_hh_l0, bias_ih_l0, bias_hh_l0, *_reverse}, block_k.narrLstm..., emb2ipd.weight,
+ * emb2ipd.bias; fnssl_train_param_offset gives each offset).  The handle is a HOST object holding the layer table and
+ * the gather maps flat vector -> packed weight streams; the maps are uploaded once into a caller-owned device buffer. */
+typedef struct fnssl_train fnssl_train;
+int fnssl_train_create(int is_online, fnssl_train** out);
+void fnssl_train_destroy(fnssl_train* t);
+long long fnssl_train_param_floats(const fnssl_train* t);
+long long fnssl_train_param_offset(const fnssl_train* t, int layer, int dir, int what);
+size_t fnssl_train_map_bytes(const fnssl_train* t);
+int fnssl_train_upload_maps(fnssl_train* t, void* dev_buf, void* stream);   /* synchronises `stream` once */
+size_t fnssl_train_workspace_bytes(const fnssl_train* t, int nbp, int nf, int nt);
+
+/*
+ * One chunk of nb utterances x np pairs: train-mode forward (dropout keyed on seed_base and the GLOBAL pair index
+ * pair0 + local pair), MSE against gt, backward; ACCUMULATES into grad and *loss (both DEVICE; the caller zeroes them
+ * once per step).
+ *   x   [nb*np, 4, nf, nt]  features (layout 1 of fnssl_pair_features)      gt  [nb, nt/12, 2*nf, np]
+ *   n_total = element count of the whole batch the loss mean runs over (= nb*np*(nt/12)*2*nf when this is the only chunk)
+ * The weight-gradient GEMMs call rocBLAS (resolved with dlopen at first use).  A multi-GPU caller sum-all-reduces grad
+ * between this call and fnssl_adam_step (grad_scale = 1 / world).
+ */
+int fnssl_train_backward(fnssl_train* t, const float* theta, float* grad, const float* x, const float* gt,
+                         int nb, int np, int nf, int nt, unsigned seed_base, long long pair0, long long n_total,
+                         float* loss, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Single-process optimisation step: zero grad / loss, fnssl_train_backward on the whole batch, fnssl_adam_step. */
+int fnssl_train_step(fnssl_train* t, float* theta, float* grad, float* exp_avg, float* exp_avg_sq,
+                     const float* x, const float* gt, int nb, int np, int nf, int nt, unsigned seed_base,
+                     float lr, float beta1, float beta2, float eps, int step, float* loss,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Head                                                                      */

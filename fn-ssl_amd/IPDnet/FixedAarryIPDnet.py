@@ -41,6 +41,14 @@ def _ceil16(c):
     return (c + 15) // 16 * 16
 
 
+def _aligned16(x):
+    """Base address and batch / bin / time strides on 16-byte boundaries (what the LDS-DMA of conv_bf16x needs)."""
+    if x is None:
+        return True
+    es = x.element_size()
+    return x.data_ptr() % 16 == 0 and all((x.stride(d) * es) % 16 == 0 for d in range(3))
+
+
 def _is_bf16(module):
     return next(module.parameters()).dtype == torch.bfloat16
 
@@ -192,6 +200,7 @@ class CausCnnBlock(nn.Module):
         self.pad = padding
         self.relu = nn.ReLU(inplace=True)
         self.tanh = nn.Tanh()
+        self._packed_x = None
         self._packed = None
         self._packed_key = None
 
@@ -208,6 +217,12 @@ class CausCnnBlock(nn.Module):
             self._packed = (ops.pack_conv3x3(w1, ca, cb, device, bf),
                             ops.pack_conv3x3(self.conv2.weight, h, 0, device, bf),
                             ops.pack_conv3x3(self.conv3.weight, h, 0, device, bf))
+            # the LDS-staged kernel (conv_bf16x.hip) for the two large convolutions, where it takes the shapes
+            self._packed_x = None
+            if bf and ops.conv3x3_bf16x_supported(h, ca, cb) and ops.conv3x3_bf16x_supported(h, h, 0) \
+                    and not os.environ.get("FNSSL_NO_CONVX"):
+                self._packed_x = (ops.pack_conv3x3_bf16x(w1, ca, cb, device),
+                                  ops.pack_conv3x3_bf16x(self.conv2.weight, h, 0, device))
             self._packed_key = key
         return self._packed
 
@@ -223,6 +238,13 @@ class CausCnnBlock(nn.Module):
         if ca + cb != self.inp_dim and not (bf and ca + cb == _ceil16(self.inp_dim - ca) + ca):
             raise RuntimeError("CausCnnBlock: %d + %d input channels, expected %d" % (ca, cb, self.inp_dim))
         w1, w2, w3 = self._streams(xa.device, ca, cb)
+        if self._packed_x is not None and xa.dtype == torch.bfloat16 and _aligned16(xa) and _aligned16(xb):
+            x1, x2 = self._packed_x
+            y = ops.conv3x3_causal_bf16x(xa, xb, x1, self.cnn_hidden_dim, "relu")
+            y = ops.avgpool_time(y, 3, bf16_out=True)
+            y = ops.conv3x3_causal_bf16x(y, None, x2, self.cnn_hidden_dim, "relu")
+            y = ops.avgpool_time(y, 4)
+            return ops.conv3x3_causal(y, None, w3, self.out_dim, "tanh", bf)
         y = ops.conv3x3_causal(xa, xb, w1, self.cnn_hidden_dim, "relu", bf)
         y = ops.avgpool_time(y, 3)
         y = ops.conv3x3_causal(y, None, w2, self.cnn_hidden_dim, "relu", bf)

@@ -117,15 +117,24 @@ sn_encoder_kernel(const float* __restrict__ x, long long sb, long long sc, long 
   float acc[H];
 #pragma unroll
   for (int o = 0; o < H; ++o) acc[o] = bias[o];
-  for (int c = 0; c < cin; ++c) {
+  // the taps of channel c + 1 are requested before the 480 FMAs of channel c (the compiler does not move loads
+  // across the back edge; without this every trip starts with a full memory round trip)
+  auto taps = [&](int c, float (&v)[KE]) {
     const float* xc = x + b * sb + c * sc + f * sf;
     const float* sc_in = state_in ? state_in + ((b * cin + c) * nf + f) * (KE - 1) : nullptr;
-    float v[KE];
 #pragma unroll
     for (int k = 0; k < KE; ++k) {
       const int tt = t + k - (KE - 1);
       v[k] = tt >= 0 ? xc[tt * st] : (sc_in ? sc_in[(KE - 1) + tt] : 0.f);
     }
+  };
+  float vn[KE];
+  taps(0, vn);
+  for (int c = 0; c < cin; ++c) {
+    float v[KE];
+#pragma unroll
+    for (int k = 0; k < KE; ++k) v[k] = vn[k];
+    if (c + 1 < cin) taps(c + 1, vn);
     const float* wc = wT + (long long)c * KE * H;
 #pragma unroll
     for (int k = 0; k < KE; ++k)
@@ -354,22 +363,30 @@ sn_mamba_xproj_kernel(const float* __restrict__ xz, int nt, long long npts, cons
   float acc[XP];
 #pragma unroll
   for (int j = 0; j < XP; ++j) acc[j] = 0.f;
+  auto taps = [&](int e4, float4 (&v)[KC]) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      const int tt = t - (KC - 1) + k;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tt >= 0) {
+        v[k] = *reinterpret_cast<const float4*>(xz + (s * nt + tt) * (2 * E) + e4 * 4);
+      } else if (conv_state) {
+        v[k] = *reinterpret_cast<const float4*>(conv_state + (s * (KC - 1) + (KC - 1) + tt) * E + e4 * 4);
+      }
+    }
+  };
+  float4 vn[KC];
+  taps(0, vn);                                  // next block's taps in flight behind this block's 160 FMAs
   for (int e4 = 0; e4 < E / 4; ++e4) {
     float xi[KC][4];
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
-      const int tt = t - (KC - 1) + k;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tt >= 0) {
-        v = *reinterpret_cast<const float4*>(xz + (s * nt + tt) * (2 * E) + e4 * 4);
-      } else if (conv_state) {
-        v = *reinterpret_cast<const float4*>(conv_state + (s * (KC - 1) + (KC - 1) + tt) * E + e4 * 4);
-      }
-      xi[k][0] = v.x;
-      xi[k][1] = v.y;
-      xi[k][2] = v.z;
-      xi[k][3] = v.w;
+      xi[k][0] = vn[k].x;
+      xi[k][1] = vn[k].y;
+      xi[k][2] = vn[k].z;
+      xi[k][3] = vn[k].w;
     }
+    if (e4 + 1 < E / 4) taps(e4 + 1, vn);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = e4 * 4 + i;
@@ -482,7 +499,7 @@ sn_mamba_out_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, i
 #pragma unroll
   for (int o = 0; o < 48; ++o) acc[o] = 0.f;
   const float* yb = ybuf + (s * nt + (long long)t2 * tp) * E;
-  for (int e4 = 0; e4 < E / 4; ++e4) {
+  auto ysum = [&](int e4) {
     float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = 0; i < tp; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(yb + (long long)i * E + e4 * 4);
@@ -491,6 +508,12 @@ sn_mamba_out_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, i
       yv.z += v.z;
       yv.w += v.w;
     }
+    return yv;
+  };
+  float4 ynext = ysum(0);                       // the next block is requested before this block's 192 FMAs
+  for (int e4 = 0; e4 < E / 4; ++e4) {
+    const float4 yv = ynext;
+    if (e4 + 1 < E / 4) ynext = ysum(e4 + 1);
     const float yy[4] = {yv.x * inv, yv.y * inv, yv.z * inv, yv.w * inv};
     const float* we = woT + (e4 * 4) * H + half * 48;
 #pragma unroll

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -30,6 +30,8 @@ SYMBOLS = [
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features", "fnssl_conv3x3_packed_floats_bf16", "fnssl_conv3x3_pack_bf16",
     "fnssl_conv3x3_causal_bf16", "fnssl_conv3x3_causal_bf16a",
+    "fnssl_conv3x3_packed_bytes_bf16x", "fnssl_conv3x3_pack_bf16x", "fnssl_conv3x3_causal_bf16x",
+    "fnssl_avgpool_time_bf16",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
     "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
@@ -197,6 +199,11 @@ def load():
     lib.fnssl_conv3x3_causal_bf16.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
     lib.fnssl_conv3x3_causal_bf16a.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
     lib.fnssl_avgpool_time.argtypes = [vp, i, i, i, i, vp, vp]
+    lib.fnssl_conv3x3_packed_bytes_bf16x.argtypes = [i, i, i]
+    lib.fnssl_conv3x3_packed_bytes_bf16x.restype = sz
+    lib.fnssl_conv3x3_pack_bf16x.argtypes = [vp, i, i, i, vp]
+    lib.fnssl_conv3x3_causal_bf16x.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
+    lib.fnssl_avgpool_time_bf16.argtypes = [vp, i, i, i, i, vp, vp]
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz
     lib.fnssl_forward.argtypes = [C.POINTER(Net), vp, i, i, i, vp, vp, sz, i, vp]

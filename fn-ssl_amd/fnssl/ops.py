@@ -500,15 +500,64 @@ def conv3x3_causal(xa, xb, packed, cout: int, act: str = "none", bf16: bool = Fa
     return out
 
 
+def conv3x3_bf16x_supported(cout: int, ca: int, cb: int) -> bool:
+    """Whether the LDS-staged bf16 conv kernel (conv_bf16x.hip) takes these channel counts."""
+    return _lib.load().fnssl_conv3x3_packed_bytes_bf16x(cout, ca, cb) > 0
+
+
+def pack_conv3x3_bf16x(weight, ca: int, cb: int, device) -> torch.Tensor:
+    """Pack a Conv2d weight [cout, ca + cb, 3, 3] into the weight stream of ``conv3x3_causal_bf16x``."""
+    w = np.ascontiguousarray(weight.detach().float().cpu().numpy() if isinstance(weight, torch.Tensor) else weight,
+                             dtype=np.float32)
+    cout = w.shape[0]
+    if w.shape != (cout, ca + cb, 3, 3):
+        raise RuntimeError("fnssl.pack_conv3x3_bf16x: weight shape %s does not match [cout, %d + %d, 3, 3]"
+                           % (w.shape, ca, cb))
+    lib = _lib.load()
+    n = lib.fnssl_conv3x3_packed_bytes_bf16x(cout, ca, cb)
+    if n == 0:
+        raise RuntimeError("fnssl.pack_conv3x3_bf16x: unsupported sizes cout=%d ca=%d cb=%d" % (cout, ca, cb))
+    out = np.empty(n // 4, dtype=np.float32)       # raw stream bytes, carried as a float32 tensor like the others
+    check(lib.fnssl_conv3x3_pack_bf16x(w.ctypes.data_as(C.c_void_p), cout, ca, cb, out.ctypes.data_as(C.c_void_p)),
+          "conv3x3_pack_bf16x")
+    return torch.from_numpy(out).to(device)
+
+
 @on_device
-def avgpool_time(x, k: int):
-    """[nb, nf, nt, C] channels-last -> [nb, nf, nt // k, C] (AvgPool2d((1, k)) of the NCHW view)."""
+def conv3x3_causal_bf16x(xa, xb, packed, cout: int, act: str = "none"):
+    """``conv3x3_causal`` for a bfloat16 ``xa`` (and an optional fp32 ``xb``) through the LDS-staged kernel.
+    Returns fp32 [nb, nf, nt, cout]."""
+    _need_dev_act(xa)
+    _need_dev(xb, packed)
+    if xa.dtype != torch.bfloat16 or (xb is not None and xb.dtype != torch.float32):
+        raise RuntimeError("fnssl.conv3x3_causal_bf16x: xa must be bfloat16 and xb float32")
+    nb, nf, nt, ca = xa.shape
+    cb = 0 if xb is None else xb.shape[3]
+    if xb is not None and tuple(xb.shape[:3]) != (nb, nf, nt):
+        raise RuntimeError("fnssl.conv3x3_causal_bf16x: xb must match xa's [nb, nf, nt]")
+    if xa.stride(3) != 1 or (xb is not None and xb.stride(3) != 1):
+        raise RuntimeError("fnssl.conv3x3_causal_bf16x: channel dimension must be contiguous")
+    out = torch.empty((nb, nf, nt, cout), dtype=torch.float32, device=xa.device)
+    sa = xa.stride()
+    sb_ = xb.stride() if xb is not None else (0, 0, 0, 1)
+    code = {"none": 0, "relu": 1, "tanh": 2}[act]
+    check(_lib.load().fnssl_conv3x3_causal_bf16x(
+        _ptr(xa), sa[0], sa[1], sa[2], ca, _ptr(xb) if xb is not None else None, sb_[0], sb_[1], sb_[2], cb,
+        _ptr(packed), cout, nb, nf, nt, code, _ptr(out), cout, _stream()), "conv3x3_causal_bf16x")
+    return out
+
+
+@on_device
+def avgpool_time(x, k: int, bf16_out: bool = False):
+    """[nb, nf, nt, C] channels-last -> [nb, nf, nt // k, C] (AvgPool2d((1, k)) of the NCHW view); ``bf16_out``
+    rounds the result to bfloat16 (the operand rounding of the bf16 conv that follows, done once here)."""
     _need_dev(x)
     x = x.contiguous()
     nb, nf, nt, c = x.shape
-    y = torch.empty((nb, nf, nt // k, c), dtype=torch.float32, device=x.device)
+    y = torch.empty((nb, nf, nt // k, c), dtype=torch.bfloat16 if bf16_out else torch.float32, device=x.device)
     if y.numel():
-        check(_lib.load().fnssl_avgpool_time(_ptr(x), nb * nf, nt, c, k, _ptr(y), _stream()), "avgpool_time")
+        fn = _lib.load().fnssl_avgpool_time_bf16 if bf16_out else _lib.load().fnssl_avgpool_time
+        check(fn(_ptr(x), nb * nf, nt, c, k, _ptr(y), _stream()), "avgpool_time")
     return y
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 6
+#define FNSSL_ABI_VERSION 7
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -401,6 +401,21 @@ int fnssl_conv3x3_causal_bf16a(const void* xa_bf16, long long a_sb, long long a_
 
 /* y[row, t2, c] = mean_{k < K} x[row, K*t2 + k, c]   (AvgPool2d((1, K)); c % 4 == 0). */
 int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y, void* stream);
+
+/* Second bf16 formulation (conv_bf16x.hip): activations staged through LDS in coalesced half-lines, 32x32x16 bf16
+ * MFMA tiles.  Same contract as fnssl_conv3x3_causal_bf16a (segment A bf16, the skip segment B fp32, fp32 output),
+ * its own weight stream; supported: 64 < cout <= 128 with cout % 4 == 0, ca % 32 == 0, cb % 16 == 0, bases and
+ * strides 16-byte aligned (packed_bytes returns 0 otherwise and the caller keeps the _bf16a entry). */
+size_t fnssl_conv3x3_packed_bytes_bf16x(int cout, int ca, int cb);
+int fnssl_conv3x3_pack_bf16x(const float* w, int cout, int ca, int cb, void* packed);
+int fnssl_conv3x3_causal_bf16x(const void* xa_bf16, long long a_sb, long long a_sf, long long a_st, int ca,
+                               const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
+                               const void* wpack, int cout, int nb, int nf, int nt, int act,
+                               float* out, int cout_stride, void* stream);
+
+/* fnssl_avgpool_time with the result rounded to bf16 (the next conv's segment A; the rounding is the one the
+ * bf16 conv kernels apply to fp32 operands, so the chain's results do not change). */
+int fnssl_avgpool_time_bf16(const float* x, int rows, int nt, int c, int k, void* y_bf16, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Whole network (replaces FN_SSL.forward, FN-SSL/Model.py:72-90)             */

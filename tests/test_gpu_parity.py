@@ -1005,3 +1005,56 @@ def test_conv3x3_bf16_input_matches_fp32_input(dev):
     a = ops.conv3x3_causal(to_dev(xa, dev), to_dev(xb, dev), packed, 128, "relu", bf16=True)
     b = ops.conv3x3_causal(to_dev(xa, dev).bfloat16(), to_dev(xb, dev), packed, 128, "relu", bf16=True)
     assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------- LDS-staged bf16 conv (conv_bf16x.hip)
+@pytest.mark.parametrize("cout,ca,cb,nb,nf,nt,act", [(128, 256, 16, 1, 4, 21, "relu"),      # IPDnet conv1, one tile
+                                                      (128, 128, 0, 2, 3, 100, "relu"),      # conv2: 2 time tiles, ragged
+                                                      (128, 256, 16, 2, 5, 130, "none"),     # 3 time tiles, halo across tiles
+                                                      (96, 32, 32, 1, 2, 64, "tanh"),        # partial cout tile, 2 skip groups
+                                                      (128, 64, 0, 3, 70, 70, "relu")])      # > 256 workgroup tiles? no: passes
+def test_conv3x3_bf16x_matches_bf16_oracle(dev, cout, ca, cb, nb, nf, nt, act):
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    w = rs_randn(5400 + cout + ca, (cout, ca + cb, 3, 3), 0.1)
+    xa = O.bf16_round(rs_randn(5401, (nb, nf, nt, ca)))
+    xb = rs_randn(5402, (nb, nf, nt, cb)) if cb else None
+    assert ops.conv3x3_bf16x_supported(cout, ca, cb)
+    packed = ops.pack_conv3x3_bf16x(w, ca, cb, dev)
+    got = ops.conv3x3_causal_bf16x(to_dev(xa, dev).bfloat16(), to_dev(xb, dev) if cb else None, packed, cout, act)
+    got = got.cpu().numpy()
+    want = _oracle_conv(xa, O.bf16_round(xb) if cb else None, O.bf16_round(w), act)
+    scale = max(1.0, np.abs(want).max())
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-5 * scale, np.abs(got - want).max()
+
+
+def test_conv3x3_bf16x_many_passes_and_strided_views(dev):
+    """More workgroup tiles than workgroups (several passes per workgroup, ring and tile buffers wrapping across
+    tiles) and inputs that are strided views (the [b, t, f, c] tensors IPDnet hands over, permuted)."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    nb, nf, nt, ca, cb, cout = 5, 257, 67, 32, 16, 128            # 5 * 257 * 2 = 2570 wave tiles -> 643 workgroup tiles
+    w = rs_randn(5410, (cout, ca + cb, 3, 3), 0.1)
+    xa = O.bf16_round(rs_randn(5411, (nb, nt, nf, ca)))           # stored [b, t, f, c]
+    xb = rs_randn(5412, (nb, nt, nf, cb))
+    packed = ops.pack_conv3x3_bf16x(w, ca, cb, dev)
+    got = ops.conv3x3_causal_bf16x(to_dev(xa, dev).bfloat16().permute(0, 2, 1, 3), to_dev(xb, dev).permute(0, 2, 1, 3),
+                                   packed, cout, "relu").cpu().numpy()
+    want = _oracle_conv(xa.transpose(0, 2, 1, 3), O.bf16_round(xb).transpose(0, 2, 1, 3), O.bf16_round(w), "relu")
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    # and bit-identical to the first bf16 kernel on the same operands? no: different accumulation order; close
+    p1 = ops.pack_conv3x3(w, ca, cb, dev, bf16=True)
+    ref = ops.conv3x3_causal(to_dev(xa, dev).bfloat16().permute(0, 2, 1, 3), to_dev(xb, dev).permute(0, 2, 1, 3), p1, cout,
+                             "relu", bf16=True).cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    with pytest.raises(RuntimeError, match="unsupported sizes"):
+        ops.pack_conv3x3_bf16x(np.zeros((28, 128, 3, 3), np.float32), 128, 0, dev)
+    assert not ops.conv3x3_bf16x_supported(128, 48, 0) and not ops.conv3x3_bf16x_supported(128, 64, 8)
+
+
+def test_avgpool_time_bf16_is_the_rounded_fp32_pool(dev):
+    from fnssl import ops
+    x = to_dev(rs_randn(5420, (2, 3, 25, 128)), dev)
+    for k in (3, 4):
+        assert torch.equal(ops.avgpool_time(x, k, bf16_out=True), ops.avgpool_time(x, k).bfloat16())

@@ -240,10 +240,9 @@ class CausCnnBlock(nn.Module):
         w1, w2, w3 = self._streams(xa.device, ca, cb)
         if self._packed_x is not None and xa.dtype == torch.bfloat16 and _aligned16(xa) and _aligned16(xb):
             x1, x2 = self._packed_x
-            y = ops.conv3x3_causal_bf16x(xa, xb, x1, self.cnn_hidden_dim, "relu")
-            y = ops.avgpool_time(y, 3, bf16_out=True)
-            y = ops.conv3x3_causal_bf16x(y, None, x2, self.cnn_hidden_dim, "relu")
-            y = ops.avgpool_time(y, 4)
+            # conv -> ReLU -> AvgPool((1, 3)) and conv -> ReLU -> AvgPool((1, 4)), pooling in the conv epilogues
+            y = ops.conv3x3_causal_bf16x(xa, xb, x1, self.cnn_hidden_dim, "relu", pool=3, bf16_out=True)
+            y = ops.conv3x3_causal_bf16x(y, None, x2, self.cnn_hidden_dim, "relu", pool=4)
             return ops.conv3x3_causal(y, None, w3, self.out_dim, "tanh", bf)
         y = ops.conv3x3_causal(xa, xb, w1, self.cnn_hidden_dim, "relu", bf)
         y = ops.avgpool_time(y, 3)

@@ -47,7 +47,9 @@ struct ConvXParams {
   float* out;
   int cout, cout_stride;
   int nb, nf, nt, act;
-  int tiles_t, ntw;      // wave tiles = nb * nf * tiles_t, tiles_t = ceil(nt / 64)
+  int tiles_t, ntw;      // wave tiles = nb * nf * tiles_t; a tile = tstride output frames
+  int pool, out_bf16;    // fused AvgPool2d((1, pool)) of the activated output (1 = none, 3, 4); pooled output as bf16
+  int tstride, ntp;      // output frames per tile (63 with pool 3: 21 windows; else 64); frames of the (pooled) output
   int nwt, share, per_pass, passes;   // workgroup tiles, per-XCD share, workgroups per XCD, passes
   int ga, gtot;          // channel groups of segment A (ca / 32) and in total (+ cb / 16)
   int abl;               // make ABLATE=1 builds: timing ablations with wrong results (1 no MFMA, 2 no activation DMA, 4 no weight DMA, 8 no barrier, 16 no LDS reads, 32 no stores)
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__(512) conv3x3_bf16x_kernel(const ConvXParams p)
     xl_rb = make_rsrc_n(p.xb ? reinterpret_cast<const char*>(p.xb) + ((long long)c.b * p.b_sb + (long long)fc * p.b_sf) * 4
                              : reinterpret_cast<const char*>(p.xa),
                         ok ? p.b_bytes : 0u);
-    const int t = 64 * c.tt - 2 + (lane >> 2);
+    const int t = p.tstride * c.tt - 2 + (lane >> 2);
     xl_va = (unsigned)(t * (int)p.a_st * 2) + 16u * xc;
     xl_vb = (unsigned)(t * (int)p.b_st * 4) + 16u * xc;
   };
@@ -204,30 +206,80 @@ __global__ void __launch_bounds__(512) conv3x3_bf16x_kernel(const ConvXParams p)
   // (r & 3) + 8 (r >> 2) + 4 hb of the tile, so one dword store instruction writes two whole 128-byte lines (32
   // consecutive channels of two positions) — 16-byte stores scattered over 64 rows made every line a partial write.
   // Frames >= nt fall outside the row descriptor's extent and are dropped; channels >= cout get an offset outside it.
+  // The time pooling that follows the convolution in CausCnnBlock is applied here (same operation order and
+  // roundings as pool_t_kernel: activation, left-to-right sum, IEEE division, optional bf16 rounding):
+  //   pool 4: a window is the 4 registers (r & 3) of one (q, r >> 2) — 8 windows per lane, nothing crosses lanes;
+  //   pool 3: a tile is 63 frames = 21 windows; the two half-waves exchange their registers (lane ^ 32), then the
+  //           hb = 0 half produces the even windows and the hb = 1 half the odd ones.
   auto store_tile = [&]() {
     const TileCoord cc0 = coord(c_pass);
-    const unsigned rowb = (unsigned)p.nt * (unsigned)p.cout_stride * 4u;
-    const rsrc_t ro = make_rsrc_n(p.out + ((long long)cc0.b * p.nf + cc0.f) * p.nt * p.cout_stride, cc0.valid ? rowb : 0u);
-    const unsigned cs4 = (unsigned)p.cout_stride * 4u;
+    const unsigned es = p.out_bf16 ? 2u : 4u;
+    const unsigned rowb = (unsigned)p.ntp * (unsigned)p.cout_stride * es;
+    const rsrc_t ro = make_rsrc_n(reinterpret_cast<const char*>(p.out) +
+                                      ((long long)cc0.b * p.nf + cc0.f) * p.ntp * p.cout_stride * es,
+                                  cc0.valid ? rowb : 0u);
+    const unsigned cse = (unsigned)p.cout_stride * es;
+    auto act = [&](float v) -> float {
+      if (p.act == 1) return fmaxf(v, 0.f);
+      if (p.act == 2) return tanhf(v);
+      return v;
+    };
+    auto put = [&](float v, unsigned vo, unsigned so) {
+      if (p.out_bf16)
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)v), ro, vo, so, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo, so, 0);
+    };
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
       const int co = 32 * (2 * ch + cc) + n;
-      const unsigned vo = co < p.cout ? (unsigned)(64 * cc0.tt + 4 * hb) * cs4 + 4u * co : 0xffffff00u;
+      const bool cok = co < p.cout;
+      if (p.pool == 1) {
+        const unsigned vo = cok ? (unsigned)(64 * cc0.tt + 4 * hb) * cse + es * co : 0xffffff00u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            put(act(acc[cc][q][r]), vo, (unsigned)(32 * q + (r & 3) + 8 * (r >> 2)) * cse);
+      } else if (p.pool == 4) {
+        const unsigned vo = cok ? (unsigned)(16 * cc0.tt + hb) * cse + es * co : 0xffffff00u;   // window 8 q + 2 m + hb
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            float sum = act(acc[cc][q][4 * m]);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) sum += act(acc[cc][q][4 * m + k]);
+            put(__fdiv_rn(sum, 4.f), vo, (unsigned)(8 * q + 2 * m) * cse);
+          }
+      } else {
+        float own[2][16], oth[2][16];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            own[q][r] = act(acc[cc][q][r]);
+            oth[q][r] = __shfl_xor(own[q][r], 32, 64);
+          }
+        // frame p of the tile seen from a lane of half H: own registers if the frame's half ((p >> 2) & 1) is H
+        auto frame = [&](int pp, int H) -> float {
+          const int q = pp >> 5, i = pp & 31, r = (i & 3) + 4 * (i >> 3);
+          return ((i >> 2) & 1) == H ? own[q][r] : oth[q][r];
+        };
+        const unsigned vo = cok ? (unsigned)(21 * cc0.tt + hb) * cse + es * co : 0xffffff00u;    // window 2 s + hb
+#pragma unroll
+        for (int sl = 0; sl < 11; ++sl) {
+          const float a = (frame(6 * sl, 0) + frame(6 * sl + 1, 0)) + frame(6 * sl + 2, 0);
+          float b = 0.f;
+          if (sl < 10) b = (frame(6 * sl + 3, 1) + frame(6 * sl + 4, 1)) + frame(6 * sl + 5, 1);
+          // window 21 of the hb = 1 half (sl = 10) would belong to the next tile: parked outside the row
+          put(__fdiv_rn(hb ? b : a, 3.f), (sl == 10 && hb) ? 0xffffff00u : vo, (unsigned)(2 * sl) * cse);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[cc][q][r];
-          if (p.act == 1) {
-            v = fmaxf(v, 0.f);
-          } else if (p.act == 2) {
-            v = tanhf(v);
-          }
-          if (!(ABL && (p.abl & 32)))
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ro, vo,
-                                                  (unsigned)(32 * q + (r & 3) + 8 * (r >> 2)) * cs4, 0);
-          acc[cc][q][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) acc[cc][q][r] = 0.f;
     }
   };
 
@@ -398,9 +450,11 @@ int fnssl_conv3x3_pack_bf16x(const float* w, int cout, int ca, int cb, void* pac
 
 int fnssl_conv3x3_causal_bf16x(const void* xa_bf16, long long a_sb, long long a_sf, long long a_st, int ca,
                                const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
-                               const void* wpack, int cout, int nb, int nf, int nt, int act, float* out,
-                               int cout_stride, void* stream) {
+                               const void* wpack, int cout, int nb, int nf, int nt, int act, int pool, int out_bf16,
+                               void* out, int cout_stride, void* stream) {
   FNSSL_REQUIRE(xa_bf16 && wpack && out, "conv3x3_bf16x: null pointer");
+  FNSSL_REQUIRE((pool == 1 || pool == 3 || pool == 4) && (out_bf16 == 0 || out_bf16 == 1),
+                "conv3x3_bf16x: pool must be 1, 3 or 4 and out_bf16 0 or 1");
   FNSSL_REQUIRE(nb > 0 && nf > 0 && nt > 0, "conv3x3_bf16x: empty problem");
   FNSSL_REQUIRE(fnssl_conv3x3_packed_bytes_bf16x(cout, ca, cb) > 0, "conv3x3_bf16x: unsupported channel counts");
   FNSSL_REQUIRE(cb == 0 || xb, "conv3x3_bf16x: segment B missing");
@@ -417,7 +471,7 @@ int fnssl_conv3x3_causal_bf16x(const void* xa_bf16, long long a_sb, long long a_
   };
   ConvXParams p;
   FNSSL_REQUIRE(slab(a_sb, a_sf, a_st, ca, 2, p.a_bytes) && (cb == 0 || slab(b_sb, b_sf, b_st, cb, 4, p.b_bytes)) &&
-                    (long double)nf * nt * cout_stride * 4 < 4.0e9L,
+                    (long double)nf * (nt / pool) * cout_stride * 4 < 4.0e9L,
                 "conv3x3_bf16x: strides must keep 16-byte alignment and one utterance below 2 GB");
   if (cb == 0) p.b_bytes = 0;
   p.xa = xa_bf16;
@@ -429,14 +483,19 @@ int fnssl_conv3x3_causal_bf16x(const void* xa_bf16, long long a_sb, long long a_
   p.b_sf = b_sf;
   p.b_st = b_st;
   p.wpack = wpack;
-  p.out = out;
+  p.out = static_cast<float*>(out);
   p.cout = cout;
   p.cout_stride = cout_stride;
   p.nb = nb;
   p.nf = nf;
   p.nt = nt;
   p.act = act;
-  p.tiles_t = (nt + 63) / 64;
+  p.pool = pool;
+  p.out_bf16 = out_bf16;
+  p.ntp = nt / pool;
+  if (p.ntp == 0) return FNSSL_OK;                      // fewer frames than one pooling window: empty output
+  p.tstride = pool == 3 ? 63 : 64;
+  p.tiles_t = (p.ntp * pool + p.tstride - 1) / p.tstride;   // frames past the last whole window are not computed
   const long long ntw = (long long)nb * nf * p.tiles_t;
   FNSSL_REQUIRE(ntw < (1ll << 29), "conv3x3_bf16x: too many tiles");
   p.ntw = (int)ntw;

@@ -202,7 +202,7 @@ def load():
     lib.fnssl_conv3x3_packed_bytes_bf16x.argtypes = [i, i, i]
     lib.fnssl_conv3x3_packed_bytes_bf16x.restype = sz
     lib.fnssl_conv3x3_pack_bf16x.argtypes = [vp, i, i, i, vp]
-    lib.fnssl_conv3x3_causal_bf16x.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, vp, i, vp]
+    lib.fnssl_conv3x3_causal_bf16x.argtypes = [vp, ll, ll, ll, i, vp, ll, ll, ll, i, vp, i, i, i, i, i, i, i, vp, i, vp]
     lib.fnssl_avgpool_time_bf16.argtypes = [vp, i, i, i, i, vp, vp]
     lib.fnssl_forward_workspace_bytes.argtypes = [i, i, i, i, i]
     lib.fnssl_forward_workspace_bytes.restype = sz

@@ -524,9 +524,10 @@ def pack_conv3x3_bf16x(weight, ca: int, cb: int, device) -> torch.Tensor:
 
 
 @on_device
-def conv3x3_causal_bf16x(xa, xb, packed, cout: int, act: str = "none"):
-    """``conv3x3_causal`` for a bfloat16 ``xa`` (and an optional fp32 ``xb``) through the LDS-staged kernel.
-    Returns fp32 [nb, nf, nt, cout]."""
+def conv3x3_causal_bf16x(xa, xb, packed, cout: int, act: str = "none", pool: int = 1, bf16_out: bool = False):
+    """``conv3x3_causal`` for a bfloat16 ``xa`` (and an optional fp32 ``xb``) through the LDS-staged kernel, with the
+    time pooling that follows it in CausCnnBlock fused into the epilogue (``pool`` 1 / 3 / 4).
+    Returns [nb, nf, nt // pool, cout], float32 or (``bf16_out``) bfloat16."""
     _need_dev_act(xa)
     _need_dev(xb, packed)
     if xa.dtype != torch.bfloat16 or (xb is not None and xb.dtype != torch.float32):
@@ -537,13 +538,15 @@ def conv3x3_causal_bf16x(xa, xb, packed, cout: int, act: str = "none"):
         raise RuntimeError("fnssl.conv3x3_causal_bf16x: xb must match xa's [nb, nf, nt]")
     if xa.stride(3) != 1 or (xb is not None and xb.stride(3) != 1):
         raise RuntimeError("fnssl.conv3x3_causal_bf16x: channel dimension must be contiguous")
-    out = torch.empty((nb, nf, nt, cout), dtype=torch.float32, device=xa.device)
+    out = torch.empty((nb, nf, nt // pool, cout), dtype=torch.bfloat16 if bf16_out else torch.float32, device=xa.device)
+    if out.numel() == 0:
+        return out
     sa = xa.stride()
     sb_ = xb.stride() if xb is not None else (0, 0, 0, 1)
     code = {"none": 0, "relu": 1, "tanh": 2}[act]
     check(_lib.load().fnssl_conv3x3_causal_bf16x(
         _ptr(xa), sa[0], sa[1], sa[2], ca, _ptr(xb) if xb is not None else None, sb_[0], sb_[1], sb_[2], cb,
-        _ptr(packed), cout, nb, nf, nt, code, _ptr(out), cout, _stream()), "conv3x3_causal_bf16x")
+        _ptr(packed), cout, nb, nf, nt, code, pool, int(bf16_out), _ptr(out), cout, _stream()), "conv3x3_causal_bf16x")
     return out
 
 

@@ -405,13 +405,16 @@ int fnssl_avgpool_time(const float* x, int rows, int nt, int c, int k, float* y,
 /* Second bf16 formulation (conv_bf16x.hip): activations staged through LDS in coalesced half-lines, 32x32x16 bf16
  * MFMA tiles.  Same contract as fnssl_conv3x3_causal_bf16a (segment A bf16, the skip segment B fp32, fp32 output),
  * its own weight stream; supported: 64 < cout <= 128 with cout % 4 == 0, ca % 32 == 0, cb % 16 == 0, bases and
- * strides 16-byte aligned (packed_bytes returns 0 otherwise and the caller keeps the _bf16a entry). */
+ * strides 16-byte aligned (packed_bytes returns 0 otherwise and the caller keeps the _bf16a entry).
+ * pool = 3 or 4 applies the AvgPool2d((1, pool)) that follows the activation in CausCnnBlock.forward
+ * (IPDnet/FixedAarryIPDnet.py:63-70) in the epilogue: out is [nb, nf, nt / pool, cout_stride]; out_bf16 = 1 writes
+ * it as bf16 (the next conv's segment A).  pool = 1, out_bf16 = 0: the plain fp32 [nb, nf, nt, cout_stride]. */
 size_t fnssl_conv3x3_packed_bytes_bf16x(int cout, int ca, int cb);
 int fnssl_conv3x3_pack_bf16x(const float* w, int cout, int ca, int cb, void* packed);
 int fnssl_conv3x3_causal_bf16x(const void* xa_bf16, long long a_sb, long long a_sf, long long a_st, int ca,
                                const float* xb, long long b_sb, long long b_sf, long long b_st, int cb,
                                const void* wpack, int cout, int nb, int nf, int nt, int act,
-                               float* out, int cout_stride, void* stream);
+                               int pool, int out_bf16, void* out, int cout_stride, void* stream);
 
 /* fnssl_avgpool_time with the result rounded to bf16 (the next conv's segment A; the rounding is the one the
  * bf16 conv kernels apply to fp32 operands, so the chain's results do not change). */

@@ -1058,3 +1058,22 @@ def test_avgpool_time_bf16_is_the_rounded_fp32_pool(dev):
     x = to_dev(rs_randn(5420, (2, 3, 25, 128)), dev)
     for k in (3, 4):
         assert torch.equal(ops.avgpool_time(x, k, bf16_out=True), ops.avgpool_time(x, k).bfloat16())
+
+
+@pytest.mark.parametrize("pool,nt", [(3, 300), (3, 64), (3, 5), (4, 100), (4, 67), (3, 2)])
+def test_conv3x3_bf16x_fused_pool_equals_conv_then_pool(dev, pool, nt):
+    """The pooling fused into the conv epilogue reproduces conv -> avgpool_time bit for bit (fp32 and bf16 output),
+    including ragged lengths (frames past the last whole window dropped) and tiles of 63 frames (pool 3)."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    nb, nf, ca, cb, cout = 2, 5, 64, 16, 128
+    w = rs_randn(5500 + pool + nt, (cout, ca + cb, 3, 3), 0.1)
+    xa = to_dev(O.bf16_round(rs_randn(5501, (nb, nf, nt, ca))), dev).bfloat16()
+    xb = to_dev(rs_randn(5502, (nb, nf, nt, cb)), dev)
+    packed = ops.pack_conv3x3_bf16x(w, ca, cb, dev)
+    plain = ops.conv3x3_causal_bf16x(xa, xb, packed, cout, "relu")
+    for bf in (False, True):
+        fused = ops.conv3x3_causal_bf16x(xa, xb, packed, cout, "relu", pool=pool, bf16_out=bf)
+        want = ops.avgpool_time(plain, pool, bf16_out=bf)
+        assert fused.shape == want.shape == (nb, nf, nt // pool, cout) and fused.dtype == want.dtype
+        assert torch.equal(fused, want), (fused.float() - want.float()).abs().max()

@@ -17,6 +17,8 @@
 // Every kernel takes strided [B, T, F, 96] views (channels contiguous), so the reference's permutes
 // (:222-233, :235-253, :333-335, :355-364) are never materialised and the residual adds, the frequency /
 // time poolings and the activations are fused into the producing kernel.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -350,6 +352,317 @@ sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Dense layers on the matrix pipe.  The scalar-operand formulation above is latency-bound where a launch has few
+// points (layers 1..7 run on 51 k points = 800 waves: one wave walks 96 x 96 weights through scalar loads that return
+// out of order, i.e. in batches behind s_waitcnt lgkmcnt(0) — 130 us for 8 us of FMAs), so the projections of the
+// Mamba block and the encoder also exist as v_mfma_f32_16x16x4_f32 kernels (exact fp32, same flop rate as packed FMA):
+//   a wave owns 16 points; lane (n, kq) holds the K/4 channels kq*K/4 .. of point n (the B operand of every k-step);
+//   the weight matrix sits in LDS for the whole launch as A operands — tile j (16 outputs) x group g (4 k-steps):
+//   lane (i, kq) reads W[kq*K/4 + 4g .. +3][16 j + i] with one ds_read_b128 — filled once per workgroup;
+//   D[output 4*og + r][point n]: a lane stores 4 consecutive outputs of its point (16 bytes).
+// ---------------------------------------------------------------------------------------------------------
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+template <int K, int N>
+__device__ __forceinline__ void fill_w_lds(float* lds, const float* __restrict__ wT, int ldw, int kvalid, int nvalid) {
+  constexpr int KQ = K / 4, G = KQ / 4;
+  static_assert(K % 16 == 0 && N % 16 == 0, "whole k-step groups and output tiles");
+  // LDS order, one 16-byte write per thread and trip (conflict-free); its 4 values are 4 consecutive rows of wT at the
+  // same output, and the 16 lanes of an output tile read 64 contiguous bytes of each row (the matrix is L2-resident)
+  for (int idx = threadIdx.x; idx < (N / 16) * G * 64; idx += blockDim.x) {
+    const int lane = idx & 63, g = (idx >> 6) % G, j = (idx >> 6) / G;
+    const int k0 = (lane >> 4) * KQ + 4 * g, o = 16 * j + (lane & 15);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (k0 + i < kvalid && o < nvalid) ? wT[(long long)(k0 + i) * ldw + o] : 0.f;
+    *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// acc[jj] += W-tile (j0 + jj) . x   for NJ output tiles at once (independent accumulators keep the pipe busy)
+template <int K, int NJ>
+__device__ __forceinline__ void mfma_tiles(const float (&a)[K / 4], const float* ldsw_lane, int j0, v4f_t (&acc)[NJ]) {
+  constexpr int G = K / 16;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    v4f_t w[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) w[jj] = *reinterpret_cast<const v4f_t*>(ldsw_lane + ((j0 + jj) * G + g) * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][i], a[4 * g + i], acc[jj], 0, 0, 0);
+    // keep the scheduler from hoisting every group's LDS reads to the top (it spills the operand registers)
+    if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Mamba, phase 1 on the matrix pipe: xz[p, 0:384] = in_proj(LayerNorm(x_p)),  p = (b*nf + f)*nt + t
+__global__ void __launch_bounds__(1024)
+sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const float* __restrict__ ln_w,
+                        const float* __restrict__ ln_b, const float* __restrict__ winT, float* __restrict__ xz) {
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 24 tiles x 6 groups x 1 KiB
+  fill_w_lds<H, 2 * E>(ldsw, winT, 2 * E, H, 2 * E);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+  const float* ldsw_lane = ldsw + lane * 4;
+  const long long ntiles = (npts + 15) / 16;
+  float lw[H / 4], lb[H / 4];
+#pragma unroll
+  for (int i = 0; i < H / 4; ++i) {
+    lw[i] = ln_w[kq * (H / 4) + i];
+    lb[i] = ln_b[kq * (H / 4) + i];
+  }
+  for (long long tile = (long long)blockIdx.x * 16 + w; tile < ntiles; tile += (long long)gridDim.x * 16) {
+    const long long p = tile * 16 + n;
+    const long long pc = p < npts ? p : npts - 1;
+    const int t = (int)(pc % nt);
+    const int f = (int)((pc / nt) % nf);
+    const long long b = pc / ((long long)nt * nf);
+    const float4* row = reinterpret_cast<const float4*>(xv.p + b * xv.sb + t * xv.st + f * xv.sf + kq * (H / 4));
+    float a[H / 4];
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) {
+      const float4 v = row[i];
+      a[4 * i] = v.x;
+      a[4 * i + 1] = v.y;
+      a[4 * i + 2] = v.z;
+      a[4 * i + 3] = v.w;
+    }
+    // LayerNorm over the point's 96 channels = the lane's 24 + the three lanes 16, 32, 48 further on
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < H / 4; ++i) sum += a[i];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / H);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < H / 4; ++i) {
+      const float d = a[i] - mean;
+      var = fmaf(d, d, var);
+    }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.f / sqrtf(var * (1.f / H) + kEps);
+#pragma unroll
+    for (int i = 0; i < H / 4; ++i) a[i] = (a[i] - mean) * rstd * lw[i] + lb[i];
+    float* dst = xz + p * (2 * E) + 4 * kq;
+#pragma unroll 1
+    for (int j0 = 0; j0 < (2 * E) / 16; j0 += 4) {
+      v4f_t acc[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
+      mfma_tiles<H, 4>(a, ldsw_lane, j0, acc);
+      if (p < npts) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          *reinterpret_cast<float4*>(dst + 16 * (j0 + jj)) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
+      }
+    }
+  }
+}
+
+// Mamba, phase 2a: u[p, e] = SiLU(conv4(xi))(p, e) over the taps t-3..t of xz (thread = point x channel quad).  u is
+// what x_proj and the scan both consume; it lives in the scan's output buffer (the scan reads u_t before it writes y_t).
+__global__ void __launch_bounds__(256)
+sn_mamba_conv_kernel(const float* __restrict__ xz, int nt, long long npts, const float* __restrict__ conv_w,
+                     const float* __restrict__ conv_b, const float* __restrict__ conv_state, float* __restrict__ u) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npts * (E / 4)) return;
+  const int e0 = (int)(idx % (E / 4)) * 4;
+  const long long p = idx / (E / 4);
+  const int t = (int)(p % nt);
+  const long long sq = p / nt;
+  float4 v[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {
+    const int tt = t - (KC - 1) + k;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tt >= 0) {
+      v[k] = *reinterpret_cast<const float4*>(xz + (sq * nt + tt) * (2 * E) + e0);
+    } else if (conv_state) {
+      v[k] = *reinterpret_cast<const float4*>(conv_state + (sq * (KC - 1) + (KC - 1) + tt) * E + e0);
+    }
+  }
+  const float xi[KC][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+  const float4 cb = *reinterpret_cast<const float4*>(conv_b + e0);
+  const float cbv[4] = {cb.x, cb.y, cb.z, cb.w};
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 cw = *reinterpret_cast<const float4*>(conv_w + (e0 + i) * KC);
+    float a = cbv[i];
+    a = fmaf(cw.x, xi[0][i], a);
+    a = fmaf(cw.y, xi[1][i], a);
+    a = fmaf(cw.z, xi[2][i], a);
+    a = fmaf(cw.w, xi[3][i], a);
+    r[i] = silu_f(a);
+  }
+  *reinterpret_cast<float4*>(u + p * E + e0) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// Mamba, phase 2b on the matrix pipe: dbl[p, 0:40] = x_proj(u_p)
+__global__ void __launch_bounds__(512)
+sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const float* __restrict__ wxT,
+                           float* __restrict__ dbl) {
+  constexpr int XN = 48;                                           // 40 outputs in 3 tiles
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 3 tiles x 12 groups x 1 KiB
+  fill_w_lds<E, XN>(ldsw, wxT, XP, E, XP);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+  const float* ldsw_lane = ldsw + lane * 4;
+  const long long ntiles = (npts + 15) / 16;
+  for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
+    const long long p = tile * 16 + n;
+    const long long pc = p < npts ? p : npts - 1;
+    const float4* ub = reinterpret_cast<const float4*>(u + pc * E + kq * (E / 4));
+    float a[E / 4];
+#pragma unroll
+    for (int e4 = 0; e4 < E / 16; ++e4) {
+      const float4 v = ub[e4];
+      a[4 * e4] = v.x;
+      a[4 * e4 + 1] = v.y;
+      a[4 * e4 + 2] = v.z;
+      a[4 * e4 + 3] = v.w;
+    }
+    v4f_t acc[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
+    mfma_tiles<E, 3>(a, ldsw_lane, 0, acc);
+    if (p < npts) {
+      float* dst = dbl + p * XP + 4 * kq;
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+        if (16 * jj + 4 * kq < XP)
+          *reinterpret_cast<float4*>(dst + 16 * jj) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
+    }
+  }
+}
+
+// Mamba, phase 4 on the matrix pipe: out = pool_T(x) + out_proj(pool_T(y)),  p = s*nt2 + t2
+__global__ void __launch_bounds__(512)
+sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, int nt2, int nf, int tp,
+                         long long nout, const float* __restrict__ woT, int residual, float* out, long long o_sb,
+                         long long o_st, long long o_sf) {
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x 12 groups x 1 KiB
+  fill_w_lds<E, H>(ldsw, woT, H, E, H);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+  const float* ldsw_lane = ldsw + lane * 4;
+  const long long ntiles = (nout + 15) / 16;
+  const float inv = 1.f / (float)tp;
+  for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
+    const long long p = tile * 16 + n;
+    const long long pc = p < nout ? p : nout - 1;
+    const int t2 = (int)(pc % nt2);
+    const long long sq = pc / nt2;
+    const int f = (int)(sq % nf);
+    const long long b = sq / nf;
+    const float* yb = ybuf + (sq * nt + (long long)t2 * tp) * E + kq * (E / 4);
+    float a[E / 4];
+#pragma unroll
+    for (int e4 = 0; e4 < E / 16; ++e4) {
+      float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < tp; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(yb + (long long)i * E + e4 * 4);
+        yv.x += v.x;
+        yv.y += v.y;
+        yv.z += v.z;
+        yv.w += v.w;
+      }
+      a[4 * e4] = yv.x * inv;
+      a[4 * e4 + 1] = yv.y * inv;
+      a[4 * e4 + 2] = yv.z * inv;
+      a[4 * e4 + 3] = yv.w * inv;
+      if ((e4 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const float* xb = xv.p + b * xv.sb + (long long)t2 * tp * xv.st + f * xv.sf + 4 * kq;
+    float* dst = out + b * o_sb + t2 * o_st + f * o_sf + 4 * kq;
+#pragma unroll
+    for (int j0 = 0; j0 < H / 16; j0 += 3) {
+      v4f_t acc[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
+      mfma_tiles<E, 3>(a, ldsw_lane, j0, acc);
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        float4 o4 = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
+        if (residual) {
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int i = 0; i < tp; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (long long)i * xv.st + 16 * (j0 + jj));
+            r.x += v.x;
+            r.y += v.y;
+            r.z += v.z;
+            r.w += v.w;
+          }
+          o4 = make_float4(fmaf(r.x, inv, o4.x), fmaf(r.y, inv, o4.y), fmaf(r.z, inv, o4.z), fmaf(r.w, inv, o4.w));
+        }
+        if (p < nout) *reinterpret_cast<float4*>(dst + 16 * (j0 + jj)) = o4;
+      }
+    }
+  }
+}
+
+// Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP; p = (b*nf + f)*nt + t
+template <int KP>
+__global__ void __launch_bounds__(512)
+sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, long long sf, long long st, int cin,
+                       int nf, int nt, long long npts, const float* __restrict__ wT, const float* __restrict__ bias,
+                       const float* __restrict__ state_in, float* __restrict__ out, long long o_sb, long long o_st,
+                       long long o_sf) {
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x KP/16 groups x 1 KiB
+  fill_w_lds<KP, H>(ldsw, wT, H, cin * KE, H);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+  const float* ldsw_lane = ldsw + lane * 4;
+  const long long ntiles = (npts + 15) / 16;
+  const int kvalid = cin * KE;
+  for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
+    const long long p = tile * 16 + n;
+    const long long pc = p < npts ? p : npts - 1;
+    const int t = (int)(pc % nt);
+    const int f = (int)((pc / nt) % nf);
+    const long long b = pc / ((long long)nt * nf);
+    const float* xr = x + b * sb + f * sf;
+    int kql = kq;                                     // keeps the KP/4 per-lane tap offsets out of loop-invariant code motion
+    asm volatile("" : "+v"(kql));
+    float a[KP / 4];
+#pragma unroll
+    for (int i = 0; i < KP / 4; ++i) {
+      const int kidx = kql * (KP / 4) + i;
+      const int c = kidx / KE, k = kidx - c * KE;
+      const int tt = t + k - (KE - 1);
+      // branch-free (see the x_proj kernel): padded taps and frames before the chunk without carried state are masked
+      const int cc = kidx < kvalid ? c : 0;
+      const float* src = xr + cc * sc + (tt >= 0 ? tt : 0) * st;
+      if (state_in) src = tt >= 0 ? src : state_in + ((b * cin + cc) * nf + f) * (KE - 1) + (KE - 1) + tt;
+      const float m = (kidx < kvalid && (tt >= 0 || state_in)) ? 1.f : 0.f;
+      a[i] = *src * m;
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    float* dst = out + b * o_sb + t * o_st + f * o_sf + 4 * kq;
+#pragma unroll
+    for (int j0 = 0; j0 < H / 16; j0 += 3) {
+      v4f_t acc[3];
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * (j0 + jj) + 4 * kq);
+        acc[jj] = v4f_t{bv.x, bv.y, bv.z, bv.w};
+      }
+      mfma_tiles<KP, 3>(a, ldsw_lane, j0, acc);
+      if (p < npts) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+          *reinterpret_cast<float4*>(dst + 16 * (j0 + jj)) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Mamba, phase 2: dbl[s, t, 0:40] = x_proj(SiLU(causal_depthwise_conv4(xi)))  — (dt 6 | B 16 | C 16 | pad)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -413,7 +726,7 @@ sn_mamba_scan_kernel(const float* __restrict__ xz, const float* __restrict__ dbl
                      const float* __restrict__ conv_w, const float* __restrict__ conv_b,
                      const float* __restrict__ wdt, const float* __restrict__ bdt, const float* __restrict__ a,
                      const float* __restrict__ dpar, float* conv_state, float* ssm_state, int carry,
-                     float* __restrict__ ybuf) {
+                     float* ybuf, int have_u) {
   const long long s = blockIdx.x;
   const int e = threadIdx.x;
   float A[NST], h[NST], wd[RK], cw[KC];
@@ -436,23 +749,37 @@ sn_mamba_scan_kernel(const float* __restrict__ xz, const float* __restrict__ dbl
   const float* xrow = xz + s * nt * (2 * E) + e;
   const float* drow = dbl + s * nt * XP;
   float* yrow = ybuf + s * nt * E + e;
-  float xi_n = nt > 0 ? xrow[0] : 0.f, z_n = nt > 0 ? xrow[E] : 0.f;
+  // Everything a step reads from memory is requested one step ahead: the recurrence itself is ~150 VALU operations,
+  // a step that first waits for its 38 wave-uniform dbl_t scalars (scalar loads, L2 latency) took 2 us.
+  // have_u: ybuf holds u = SiLU(conv4(xi)) (sn_mamba_conv_kernel); the step reads u_t (one step ahead) before it
+  // overwrites the slot with y_t, and the conv taps are only needed for the carried state at the end
+  float xi_n = nt > 0 ? (have_u ? yrow[0] : xrow[0]) : 0.f, z_n = nt > 0 ? xrow[E] : 0.f;
+  float row_n[RK + 2 * NST];
+#pragma unroll
+  for (int i = 0; i < RK + 2 * NST; ++i) row_n[i] = nt > 0 ? drow[i] : 0.f;
   for (int t = 0; t < nt; ++t) {
     const float xi = xi_n, z = z_n;
+    float row[RK + 2 * NST];
+#pragma unroll
+    for (int i = 0; i < RK + 2 * NST; ++i) row[i] = row_n[i];
     if (t + 1 < nt) {                                    // next step's operands are in flight during this one
-      xi_n = xrow[(long long)(t + 1) * (2 * E)];
+      xi_n = have_u ? yrow[(long long)(t + 1) * E] : xrow[(long long)(t + 1) * (2 * E)];
       z_n = xrow[(long long)(t + 1) * (2 * E) + E];
+#pragma unroll
+      for (int i = 0; i < RK + 2 * NST; ++i) row_n[i] = drow[(long long)(t + 1) * XP + i];   // wave-uniform: scalar loads
     }
-    const float* row = drow + (long long)t * XP;         // wave-uniform: scalar loads
-    float u = cb;
-    u = fmaf(cw[0], x0, u);
-    u = fmaf(cw[1], x1, u);
-    u = fmaf(cw[2], x2, u);
-    u = fmaf(cw[3], xi, u);
-    u = silu_f(u);
-    x0 = x1;
-    x1 = x2;
-    x2 = xi;
+    float u = xi;
+    if (!have_u) {
+      u = cb;
+      u = fmaf(cw[0], x0, u);
+      u = fmaf(cw[1], x1, u);
+      u = fmaf(cw[2], x2, u);
+      u = fmaf(cw[3], xi, u);
+      u = silu_f(u);
+      x0 = x1;
+      x1 = x2;
+      x2 = xi;
+    }
     float dtv = bd;
 #pragma unroll
     for (int r = 0; r < RK; ++r) dtv = fmaf(wd[r], row[r], dtv);
@@ -471,6 +798,17 @@ sn_mamba_scan_kernel(const float* __restrict__ xz, const float* __restrict__ dbl
   if (ssm_state) {
 #pragma unroll
     for (int n = 0; n < NST; ++n) ssm_state[(s * E + e) * NST + n] = h[n];
+  }
+  if (conv_state && have_u) {                            // the last three xi of the chunk (older ones: the carried state)
+    float xs[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int tt = nt - 3 + j;
+      xs[j] = tt >= 0 ? xrow[(long long)tt * (2 * E)] : (tt == -1 ? x2 : (tt == -2 ? x1 : x0));
+    }
+    x0 = xs[0];
+    x1 = xs[1];
+    x2 = xs[2];
   }
   if (conv_state) {
     conv_state[(s * 3 + 0) * E + e] = x0;
@@ -619,6 +957,14 @@ inline MambaWs carve_mamba(float* ws, long long npts) {
 
 }  // namespace
 
+// workgroups of the matrix-pipe kernels: 8 waves x one 16-point tile each per pass, per_cu workgroups per CU (what
+// the kernel's LDS weight image allows)
+static unsigned mfma_grid(long long npts, int per_cu, int waves = 8) {
+  const long long wgs = ((npts + 15) / 16 + waves - 1) / waves;
+  const long long cap = (long long)fnssl::device_cus() * per_cu;
+  return (unsigned)(wgs < cap ? wgs : cap);
+}
+
 extern "C" {
 
 int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, const float* b, float eps, float* y,
@@ -645,8 +991,28 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
   hipStream_t s = fnssl::as_stream(stream);
   {
     fnssl::TimedLaunch tl("sn_encoder", s, 2.0 * npts * cin * KE * H);
-    hipLaunchKernelGGL(sn_encoder_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, x, x_sb, x_sc, x_sf, x_st, cin, nf, nt,
-                       npts, wT, bias, state_in, out, o_sb, o_st, o_sf);
+    const int kk = cin * KE;
+    if (!getenv("FNSSL_SN_SCALAR") && kk <= 160) {
+#define FNSSL_SN_ENC(KP)                                                                                            \
+  do {                                                                                                              \
+    const size_t lds = (size_t)KP * H * sizeof(float);                                                              \
+    static const hipError_t attr_enc = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+    FNSSL_HIP(attr_enc);                                                                                            \
+    hipLaunchKernelGGL(sn_encoder_mfma_kernel<KP>, dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, x_sc, x_sf, \
+                       x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);                         \
+  } while (0)
+      if (kk <= 32)
+        FNSSL_SN_ENC(32);
+      else if (kk <= 80)
+        FNSSL_SN_ENC(80);
+      else
+        FNSSL_SN_ENC(160);
+#undef FNSSL_SN_ENC
+    } else {
+      hipLaunchKernelGGL(sn_encoder_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, x, x_sb, x_sc, x_sf, x_st, cin, nf, nt,
+                         npts, wT, bias, state_in, out, o_sb, o_st, o_sf);
+    }
     FNSSL_CHECK_LAUNCH("sn_encoder_kernel");
   }
   if (state_out) {
@@ -730,22 +1096,43 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   FNSSL_REQUIRE(blocks_of(npts) < (1u << 31) && nseq < (1ll << 31), "sn_mamba: too many points");
   const MambaWs m = carve_mamba(static_cast<float*>(workspace), npts);
   hipStream_t s = fnssl::as_stream(stream);
+  const bool mfma = !getenv("FNSSL_SN_SCALAR");   // A/B: the scalar-operand kernels
   {
     fnssl::TimedLaunch tl("sn_mamba_in", s, 2.0 * npts * H * 2 * E);
-    hipLaunchKernelGGL(sn_mamba_in_kernel, dim3(blocks_of(npts), 4), dim3(256), 0, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
-                       w->winT, m.xz);
+    if (mfma) {
+      const unsigned nwg = mfma_grid(npts, 1, 16);
+      const size_t lds = (size_t)H * 2 * E * sizeof(float);
+      static const hipError_t attr_in = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_in_mfma_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      FNSSL_HIP(attr_in);
+      hipLaunchKernelGGL(sn_mamba_in_mfma_kernel, dim3(nwg), dim3(1024), lds, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
+                         w->winT, m.xz);
+    } else {
+      hipLaunchKernelGGL(sn_mamba_in_kernel, dim3(blocks_of(npts), 4), dim3(256), 0, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
+                         w->winT, m.xz);
+    }
     FNSSL_CHECK_LAUNCH("sn_mamba_in_kernel");
   }
   {
     fnssl::TimedLaunch tl("sn_mamba_xproj", s, 2.0 * npts * E * (XP - 2 + KC));
-    hipLaunchKernelGGL(sn_mamba_xproj_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
-                       w->wxT, carry ? conv_state : nullptr, m.dbl);
+    if (mfma) {
+      const long long nq = npts * (E / 4);
+      FNSSL_REQUIRE(blocks_of(nq) < (1u << 31), "sn_mamba: too many points");
+      hipLaunchKernelGGL(sn_mamba_conv_kernel, dim3(blocks_of(nq)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
+                         carry ? conv_state : nullptr, m.y);
+      FNSSL_CHECK_LAUNCH("sn_mamba_conv_kernel");
+      const size_t lds = (size_t)E * 48 * sizeof(float);
+      hipLaunchKernelGGL(sn_mamba_xproj_mfma_kernel, dim3(mfma_grid(npts, 4)), dim3(512), lds, s, m.y, npts, w->wxT, m.dbl);
+    } else {
+      hipLaunchKernelGGL(sn_mamba_xproj_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
+                         w->wxT, carry ? conv_state : nullptr, m.dbl);
+    }
     FNSSL_CHECK_LAUNCH("sn_mamba_xproj_kernel");
   }
   {
     fnssl::TimedLaunch tl("sn_mamba_scan", s, (double)npts * E * (7.0 * NST + 2 * RK + 2 * KC));
     hipLaunchKernelGGL(sn_mamba_scan_kernel, dim3((unsigned)nseq), dim3(E), 0, s, m.xz, m.dbl, nt, w->conv_w, w->conv_b,
-                       w->wdt, w->bdt, w->a, w->d, conv_state, ssm_state, carry, m.y);
+                       w->wdt, w->bdt, w->a, w->d, conv_state, ssm_state, carry, m.y, mfma ? 1 : 0);
     FNSSL_CHECK_LAUNCH("sn_mamba_scan_kernel");
   }
   {
@@ -753,8 +1140,17 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
     const long long nout = nseq * nt2;
     if (nout > 0) {
       fnssl::TimedLaunch tl("sn_mamba_out", s, 2.0 * nout * E * H);
-      hipLaunchKernelGGL(sn_mamba_out_kernel, dim3(blocks_of(nout), 2), dim3(256), 0, s, m.y, *x, nt, nt2, nf, time_pool,
-                         nout, w->woT, residual, out, o_sb, o_st, o_sf);
+      if (mfma) {
+        const size_t lds = (size_t)E * H * sizeof(float);
+        static const hipError_t attr_out = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FNSSL_HIP(attr_out);
+        hipLaunchKernelGGL(sn_mamba_out_mfma_kernel, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt, nt2, nf,
+                           time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
+      } else {
+        hipLaunchKernelGGL(sn_mamba_out_kernel, dim3(blocks_of(nout), 2), dim3(256), 0, s, m.y, *x, nt, nt2, nf, time_pool,
+                           nout, w->woT, residual, out, o_sb, o_st, o_sf);
+      }
       FNSSL_CHECK_LAUNCH("sn_mamba_out_kernel");
     }
   }

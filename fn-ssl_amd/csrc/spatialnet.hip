@@ -463,6 +463,165 @@ sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const
   }
 }
 
+// f-conv branch on the matrix pipe: x (+)= PReLU(Conv1d_grouped_k5(LayerNorm(x))) along F, optional AvgPool over F.
+// A workgroup = 256 points = 256 / nf whole frames = 16 tiles of 16 consecutive bins.  Lane (n, q) of a tile owns bin n
+// and, for q < 3, the channels 12 g + 4 q .. + 3 of every group g (32 registers): these are exactly the outputs
+// D[4 q + r][n] of the group's product, so residual and pooling never leave the lane.  LayerNorm'd rows go to an LDS
+// image [frame][bin + 2 (zero rows either side)][100] once; per group the lane gathers its 16 of the 64 (60 used)
+// patch values (tap, channel) = the B operand, the group's [16 x 64] weights are A operands resident in LDS.
+template <int POOL>
+__global__ void __launch_bounds__(1024)
+sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nframes, long long nblk, fnssl_sn_fconv_w w,
+                     int residual, float* out, long long o_sb, long long o_st, long long o_sf) {
+  constexpr int YS = 100;                                          // row stride of the LDS image (floats)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldw = lds;                                                // 8 groups x 4 k-groups x 1 KiB
+  float* par = lds + NG * 1024;                                    // ln_w | ln_b | bias | prelu (L1 latency per use otherwise)
+  float* ytile = par + 4 * H;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+#pragma unroll 1
+  for (int g = 0; g < NG; ++g) fill_w_lds<64, 16>(ldw + g * 1024, w.wT + g * (KF * CG * CG), CG, KF * CG, CG);
+  if (tid < 4 * H) {
+    const float* src = tid < H ? w.ln_w : (tid < 2 * H ? w.ln_b : (tid < 3 * H ? w.bias : w.prelu));
+    par[tid] = src[tid % H];
+  }
+  __syncthreads();
+  const int pt = 16 * wv + n;
+  const int fr = pt >> lg_nf, f = pt & (nf - 1);
+  const int rows = nf + 4;
+  // patch element k = 16 q + i of a group = (tap k / 12, channel k % 12): 12 is a multiple of 4, so the lane's 16
+  // elements are four aligned float4 of the image (offset tap * YS + channel from the bin's row - 2); k >= 60 is padding
+  int poff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = 16 * q + 4 * j;
+    const int tap = (k * 171) >> 11;                               // k / 12 for k < 64
+    poff[j] = k < KF * CG ? tap * YS + (k - CG * tap) : -1;
+  }
+  float* yrow = ytile + (fr * rows + f + 2) * YS + 4 * q;
+  const float* ybase = ytile + (fr * rows + f) * YS;
+  const float* ldw_lane = ldw + lane * 4;
+  if (q < 3 && f < 2) {                                            // the 'same' padding: two zero rows either side, once
+    float* z0 = ytile + (fr * rows + f) * YS + 4 * q;
+    float* z1 = ytile + (fr * rows + nf + 2 + f) * YS + 4 * q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      *reinterpret_cast<float4*>(z0 + CG * g) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(z1 + CG * g) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  auto load_rows = [&](long long blk, float (&xr)[NG][4]) {
+    const long long frame = blk * (256 >> lg_nf) + fr;
+    const bool ok = blk < nblk && frame < nframes && q < 3;
+    const long long fc = ok ? frame : 0;
+    const float* row = xv.p + (fc / nt) * xv.sb + (fc % nt) * xv.st + f * xv.sf + 4 * q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(row + CG * g);
+      xr[g][0] = v.x;
+      xr[g][1] = v.y;
+      xr[g][2] = v.z;
+      xr[g][3] = v.w;
+    }
+  };
+  // persistent workgroup: the weight image is filled once; the next block's rows are requested before this block's
+  // products, so a block costs its LDS passes and MFMAs, not an HBM round trip
+  float xn[NG][4];
+  load_rows(blockIdx.x, xn);
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    float xr[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xr[g][r] = xn[g][r];
+    const long long frame = blk * (256 >> lg_nf) + fr;
+    const bool valid = frame < nframes;
+    const long long b = frame / nt;
+    const int t = (int)(frame % nt);
+    // LayerNorm over the bin's 96 channels: 32 in each of the lanes q = 0..2 (q = 3 holds zeros)
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) sum += (xr[g][0] + xr[g][1]) + (xr[g][2] + xr[g][3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / H);
+    float var = 0.f;
+    if (q < 3) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = xr[g][r] - mean;
+          var = fmaf(d, d, var);
+        }
+    }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.f / sqrtf(var * (1.f / H) + kEps);
+    if (q < 3) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const float4 lw = *reinterpret_cast<const float4*>(par + CG * g + 4 * q);
+        const float4 lb = *reinterpret_cast<const float4*>(par + H + CG * g + 4 * q);
+        *reinterpret_cast<float4*>(yrow + CG * g) =
+            make_float4((xr[g][0] - mean) * rstd * lw.x + lb.x, (xr[g][1] - mean) * rstd * lw.y + lb.y,
+                        (xr[g][2] - mean) * rstd * lw.z + lb.z, (xr[g][3] - mean) * rstd * lw.w + lb.w);
+      }
+    }
+    __syncthreads();
+    load_rows(blk + gridDim.x, xn);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      float a[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (poff[j] >= 0) v = *reinterpret_cast<const float4*>(ybase + CG * g + poff[j]);
+        a[4 * j] = v.x;
+        a[4 * j + 1] = v.y;
+        a[4 * j + 2] = v.z;
+        a[4 * j + 3] = v.w;
+      }
+      v4f_t acc[1] = {v4f_t{0.f, 0.f, 0.f, 0.f}};
+      mfma_tiles<64, 1>(a, ldw_lane + g * 1024, 0, acc);
+      if (q < 3) {
+        const float4 bv = *reinterpret_cast<const float4*>(par + 2 * H + CG * g + 4 * q);
+        const float4 pv = *reinterpret_cast<const float4*>(par + 3 * H + CG * g + 4 * q);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[0][r] + bb[r];
+          v = v >= 0.f ? v : pp[r] * v;
+          float& xs = xr[g][r];
+          xs = residual ? xs + v : v;
+        }
+      }
+    }
+    if (POOL > 1) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = xr[g][r];
+          v += __shfl_xor(v, 1, 64);
+          if (POOL == 8) {
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+          }
+          xr[g][r] = v * (1.f / POOL);
+        }
+    }
+    if (valid && q < 3 && (f & (POOL - 1)) == 0) {
+      float* dst = out + b * o_sb + t * o_st + (f / POOL) * o_sf + 4 * q;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        *reinterpret_cast<float4*>(dst + CG * g) = make_float4(xr[g][0], xr[g][1], xr[g][2], xr[g][3]);
+    }
+    __syncthreads();                                               // everybody is done reading the image
+  }
+}
+
 // Mamba, phase 2a: u[p, e] = SiLU(conv4(xi))(p, e) over the taps t-3..t of xz (thread = point x channel quad).  u is
 // what x_proj and the scan both consume; it lives in the scan's output buffer (the scan reads u_t before it writes y_t).
 __global__ void __launch_bounds__(256)
@@ -1039,9 +1198,19 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl(nf > 128 ? "sn_fconv_f256" : (nf > 16 ? "sn_fconv_f128" : "sn_fconv_f16"), s,
                         2.0 * nframes * nf * H * CG * KF);
+  const bool mfma = !getenv("FNSSL_SN_SCALAR") && nf >= 16;
+  const size_t lds = (size_t)(NG * 1024 + 4 * H + (256 + 4 * (256 >> lg)) * 100) * sizeof(float);
 #define FNSSL_SN_FCONV(P)                                                                                         \
-  hipLaunchKernelGGL(sn_fconv_kernel<P>, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, \
-                     out, o_sb, o_st, o_sf)
+  if (mfma) {                                                                                                     \
+    static const hipError_t attr_fc = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_fconv_mfma_kernel<P>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    FNSSL_HIP(attr_fc);                                                                                           \
+    const long long cus = fnssl::device_cus();                                                                    \
+    hipLaunchKernelGGL(sn_fconv_mfma_kernel<P>, dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(1024), lds, s, *x, nt, nf, \
+                       lg, nframes, nblk, *w, residual, out, o_sb, o_st, o_sf);                                   \
+  } else                                                                                                          \
+    hipLaunchKernelGGL(sn_fconv_kernel<P>, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, \
+                       out, o_sb, o_st, o_sf)
   if (pool == 1) {
     FNSSL_SN_FCONV(1);
   } else if (pool == 2) {

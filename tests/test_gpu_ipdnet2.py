@@ -180,3 +180,20 @@ def test_network_streaming_and_batch_independence(dev):
         net.forward_stream(xd[..., :7])
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 10, 256, 10))                                  # CPU tensor: no CPU path
+
+
+def test_matrix_pipe_kernels_equal_scalar_kernels_at_multi_pass_size(dev, monkeypatch):
+    """The fp32-MFMA formulation of the encoder, the frequency convs and the Mamba projections (persistent workgroups,
+    several passes per workgroup at this size: 32 utterances x 250 frames) against the scalar-operand kernels that the
+    other tests pin to the oracle and the reference fixtures (FNSSL_SN_SCALAR=1); same fp32 products, different
+    summation order."""
+    sd, net = build_net(dev, 2400, dim_input=30, num_layers=2)
+    x = to_dev(rs_randn(2401, (32, 30, 256, 250), 0.7), dev)
+    got = net(x)
+    monkeypatch.setenv("FNSSL_SN_SCALAR", "1")
+    want = net(x)
+    monkeypatch.delenv("FNSSL_SN_SCALAR")
+    assert tuple(got.shape) == (32, 50, 512, 4, 2)
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5, err
+    assert torch.equal(net(x), got)                                       # deterministic

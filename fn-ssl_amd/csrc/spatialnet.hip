@@ -800,7 +800,7 @@ sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, 
       if (state_in) src = tt >= 0 ? src : state_in + ((b * cin + cc) * nf + f) * (KE - 1) + (KE - 1) + tt;
       const float m = (kidx < kvalid && (tt >= 0 || state_in)) ? 1.f : 0.f;
       a[i] = *src * m;
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     float* dst = out + b * o_sb + t * o_st + f * o_sf + 4 * kq;
 #pragma unroll

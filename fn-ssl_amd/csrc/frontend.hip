@@ -215,6 +215,7 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(256)
 pack_array_kernel(const float2* __restrict__ spec, const float* __restrict__ mu, int nch, int nt, float eps,
                   float* __restrict__ x) {
+  extern __shared__ float row_lds[];   // LAYOUT 0: the (b, t) row [256 bins][2 nch] = one contiguous piece of x
   const long long row = blockIdx.x;   // (b, t)
   const int f = threadIdx.x;
   const int t = (int)(row % nt);
@@ -224,15 +225,22 @@ pack_array_kernel(const float2* __restrict__ spec, const float* __restrict__ mu,
     const float2 v = spec[((b * nch + c) * nt + t) * kBins + f + 1];
     const float re = __fdiv_rn(v.x, den), im = __fdiv_rn(v.y, den);
     if (LAYOUT == 0) {
-      float* o = x + (row * kNF + f) * (2 * nch);
-      o[c] = re;
-      o[nch + c] = im;
+      // staged: bin-major 4-byte stores straight to x were 2 nch partial writes of a 64-byte stride per lane
+      row_lds[f * (2 * nch) + c] = re;
+      row_lds[f * (2 * nch) + nch + c] = im;
     } else {
       float* o = x + b * 2 * nch * (long long)kNF * nt + (long long)f * nt + t;
       const long long cs = (long long)kNF * nt;
       o[c * cs] = re;
       o[(nch + c) * cs] = im;
     }
+  }
+  if (LAYOUT == 0) {
+    __syncthreads();
+    float* o = x + row * kNF * (2 * nch);
+    const int n = kNF * 2 * nch;                       // multiple of 4; the row starts on a 16-byte boundary
+    for (int i = 4 * f; i < n; i += 4 * 256)
+      *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(row_lds + i);
   }
 }
 
@@ -329,8 +337,15 @@ int fnssl_array_features(const float* spec, const float* magsum, const float* co
     fnssl::TimedLaunch tl("pack", st);
     const long long rows = (long long)nb * nt;
     FNSSL_REQUIRE(rows < (1ll << 31), "array_features: too many rows");
+    {
+      const size_t lds = (size_t)kNF * 2 * nch * sizeof(float);
+      FNSSL_REQUIRE(lds <= 160 * 1024, "array_features: %d channels do not fit the staging row", nch);
+      if (lds > 48 * 1024)
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pack_array_kernel<0>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (layout == 0)
-      hipLaunchKernelGGL(pack_array_kernel<0>, dim3((unsigned)rows), dim3(256), 0, st,
+      hipLaunchKernelGGL(pack_array_kernel<0>, dim3((unsigned)rows), dim3(256), (size_t)kNF * 2 * nch * sizeof(float), st,
                          reinterpret_cast<const float2*>(spec), mu, nch, nt, eps, x);
     else
       hipLaunchKernelGGL(pack_array_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st,

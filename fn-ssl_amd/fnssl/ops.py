@@ -166,16 +166,24 @@ def array_features(spec, magsum, eps: float = 1e-6, sample_length: int = 280, la
 
 
 def preprocess_array(sig, eps: float = 1e-6, sample_length: int = 280, layout: int = 1):
-    """Waveforms [nb, ns, nch] -> IPDnet input features (runIPDnetOn.py:237-254)."""
+    """Waveforms [nb, ns, nch] -> IPDnet input features (runIPDnetOn.py:237-254).
+
+    layout 1 returns the reference's tensor [nb, 2*nch, 256, nt] as a VIEW of the frame-major storage
+    [nb, nt, 256, 2*nch] the network consumes (same shape and values for every reader; ``IPDnet.forward`` then skips
+    its own transposition pass, and the front end writes whole rows instead of one float per 1200-byte stride).
+    ``array_features(..., layout=1)`` still produces the contiguous NCHW tensor."""
     spec, magsum = stft(sig)
-    x, _ = array_features(spec, magsum, eps, sample_length, layout)
-    return x
+    x, _ = array_features(spec, magsum, eps, sample_length, 0)
+    return x if layout == 0 else x.permute(0, 3, 2, 1)
 
 
 @on_device
 def nchw_to_seq(x):
     """[n, c, nf, nt] -> [n, nt, nf, c] (Model.py:73) as a contiguous tensor."""
     _need_dev(x)
+    xs = x.permute(0, 3, 2, 1)
+    if xs.is_contiguous():          # already stored frame-major (e.g. what preprocess_array hands over): nothing to move
+        return xs
     x = x.contiguous()
     n, c, nf, nt = x.shape
     y = torch.empty((n, nt, nf, c), dtype=torch.float32, device=x.device)

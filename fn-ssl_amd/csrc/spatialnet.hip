@@ -363,6 +363,22 @@ sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const floa
 // ---------------------------------------------------------------------------------------------------------
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
+// sk / so: element strides of the input (k) and output (o) index in the source matrix
+template <int K, int N>
+__device__ __forceinline__ void fill_w_lds_strided(float* lds, const float* __restrict__ w, int sk, int so, int kvalid,
+                                                   int nvalid) {
+  constexpr int KQ = K / 4, G = KQ / 4;
+  static_assert(K % 16 == 0 && N % 16 == 0, "whole k-step groups and output tiles");
+  for (int idx = threadIdx.x; idx < (N / 16) * G * 64; idx += blockDim.x) {
+    const int lane = idx & 63, g = (idx >> 6) % G, j = (idx >> 6) / G;
+    const int k0 = (lane >> 4) * KQ + 4 * g, o = 16 * j + (lane & 15);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (k0 + i < kvalid && o < nvalid) ? w[(long long)(k0 + i) * sk + (long long)o * so] : 0.f;
+    *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 template <int K, int N>
 __device__ __forceinline__ void fill_w_lds(float* lds, const float* __restrict__ wT, int ldw, int kvalid, int nvalid) {
   constexpr int KQ = K / 4, G = KQ / 4;
@@ -1098,6 +1114,72 @@ sn_head_kernel(fnssl_btf_view xv, int nt2, int nfc, long long npts, const float*
   }
 }
 
+// Head on the matrix pipe.  Fine bin r of a compressed bin is output tile r of FreqInverse's 96 -> 256 product; its
+// D fragment (lane (point, q): outputs 4 q .. + 3) after bias + tanh is exactly the B operand of the decoder's
+// 16 -> 16 product (K = 16: lane q holds k = 4 q .. + 3), so the decoder is one more group of 4 MFMAs per fine bin.
+// Output order of IPDnet2.py:355-364: element gg*8 + m*2 + a <- dec[a*8 + gg*4 + m]: lane q holds (a, gg) = (q >> 1,
+// q & 1), m = 0..3; it trades registers with lane q ^ 2 (the other a) and stores one float4.
+__device__ __forceinline__ float tanh_fast(float x) {       // 1 - 2 / (e^2x + 1): the LSTM kernels' formulation
+  return __fmaf_rn(-2.0f, __builtin_amdgcn_rcpf(__fadd_rn(__expf(2.0f * x), 1.0f)), 1.0f);
+}
+
+__global__ void __launch_bounds__(512)
+sn_head_mfma_kernel(fnssl_btf_view xv, int nt2, int nfc, long long npts, const float* __restrict__ wfiP,
+                    const float* __restrict__ bfiP, const float* __restrict__ wdT, const float* __restrict__ bd,
+                    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // FreqInverse: 16 tiles x 6 groups x 1 KiB; decoder: 1 KiB
+  float* ldsd = ldsw + 16 * 6 * 256;
+  fill_w_lds_strided<H, 16 * DO>(ldsw, wfiP, 1, H, H, 16 * DO);
+  fill_w_lds<DO, DO>(ldsd, wdT, DO, DO, DO);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+  const float* ldsw_lane = ldsw + lane * 4;
+  const float* ldsd_lane = ldsd + lane * 4;
+  const long long ntiles = (npts + 15) / 16;
+  const float4 bdv = *reinterpret_cast<const float4*>(bd + 4 * q);
+  for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
+    const long long p = tile * 16 + n;
+    const long long pc = p < npts ? p : npts - 1;
+    const int fc = (int)(pc % nfc);
+    const int t2 = (int)((pc / nfc) % nt2);
+    const long long b = pc / ((long long)nfc * nt2);
+    const float4* row = reinterpret_cast<const float4*>(xv.p + b * xv.sb + t2 * xv.st + fc * xv.sf + q * (H / 4));
+    float a[H / 4];
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) {
+      const float4 v = row[i];
+      a[4 * i] = v.x;
+      a[4 * i + 1] = v.y;
+      a[4 * i + 2] = v.z;
+      a[4 * i + 3] = v.w;
+    }
+    const int nf = nfc * 16;
+    float* orow = out + ((b * nt2 + t2) * (2LL * nf) + 2LL * fc * 16) * 8 + (q & 1) * 8 + (q >> 1) * 4;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 16; j0 += 4) {
+      v4f_t acc[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float4 bv = *reinterpret_cast<const float4*>(bfiP + (j0 + jj) * DO + 4 * q);
+        acc[jj] = v4f_t{bv.x, bv.y, bv.z, bv.w};
+      }
+      mfma_tiles<H, 4>(a, ldsw_lane, j0, acc);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float v[4] = {tanh_fast(acc[jj][0]), tanh_fast(acc[jj][1]), tanh_fast(acc[jj][2]), tanh_fast(acc[jj][3])};
+        v4f_t dec[1] = {v4f_t{bdv.x, bdv.y, bdv.z, bdv.w}};
+        mfma_tiles<DO, 1>(v, ldsd_lane, 0, dec);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(dec[0][i], 32, 64);
+        const float4 st = (q >> 1) == 0 ? make_float4(dec[0][0], o[0], dec[0][1], o[1])
+                                        : make_float4(o[2], dec[0][2], o[3], dec[0][3]);
+        if (p < npts) *reinterpret_cast<float4*>(orow + (j0 + jj) * 16) = st;
+      }
+    }
+  }
+}
+
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int ilog2(int v) {
   int l = 0;
@@ -1345,7 +1427,16 @@ int fnssl_sn_head(const fnssl_btf_view* x, int nb, int nt2, int nfc, const float
   const long long npts = (long long)nb * nt2 * nfc;
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl("sn_head", s, 2.0 * npts * 16 * (DO * H + DO * DO));
-  hipLaunchKernelGGL(sn_head_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, *x, nt2, nfc, npts, wfiP, bfiP, wdT, bd, out);
+  if (!getenv("FNSSL_SN_SCALAR")) {
+    const size_t lds = (size_t)(16 * 6 * 256 + 256) * sizeof(float);
+    static const hipError_t attr_head = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_head_mfma_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    FNSSL_HIP(attr_head);
+    hipLaunchKernelGGL(sn_head_mfma_kernel, dim3(mfma_grid(npts, 1)), dim3(512), lds, s, *x, nt2, nfc, npts, wfiP, bfiP, wdT,
+                       bd, out);
+  } else {
+    hipLaunchKernelGGL(sn_head_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, *x, nt2, nfc, npts, wfiP, bfiP, wdT, bd, out);
+  }
   FNSSL_CHECK_LAUNCH("sn_head_kernel");
   return FNSSL_OK;
 }

@@ -18,6 +18,7 @@
 // (:222-233, :235-253, :333-335, :355-364) are never materialised and the residual adds, the frequency /
 // time poolings and the activations are fused into the producing kernel.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -783,7 +784,8 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
   }
 }
 
-// Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP; p = (b*nf + f)*nt + t
+// Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP (80 or 160: KP / 4 a multiple of the 5 taps);
+// p = (b*nf + f)*nt + t
 template <int KP>
 __global__ void __launch_bounds__(512)
 sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, long long sf, long long st, int cin,
@@ -796,30 +798,43 @@ sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
   const long long ntiles = (npts + 15) / 16;
-  const int kvalid = cin * KE;
   for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
     const long long p = tile * 16 + n;
     const long long pc = p < npts ? p : npts - 1;
     const int t = (int)(pc % nt);
     const int f = (int)((pc / nt) % nf);
     const long long b = pc / ((long long)nt * nf);
+    // K index k = kq * KQ + i is (channel, tap) = (KQ/5 * kq + i / 5, i % 5): KQ is a multiple of the 5 taps, so the
+    // split is compile-time per i and an element offset is  lane part (channel block, frame) + a wave-uniform term —
+    // 32-bit; the generic form (a division and a 64-bit multiply-add per element) cost more cycles than the MFMAs.
     const float* xr = x + b * sb + f * sf;
-    int kql = kq;                                     // keeps the KP/4 per-lane tap offsets out of loop-invariant code motion
-    asm volatile("" : "+v"(kql));
+    const int isc = (int)sc, ist = (int)st;
+    int lane_off = (KP / 20) * kq * isc + t * ist;
+    int lane_c = (KP / 20) * kq;
+    const float* sr = state_in ? state_in + ((b * cin) * nf + f) * (KE - 1) : x;
+    int lane_so = lane_c * nf * (KE - 1) + (KE - 1) + t;
+    asm volatile("" : "+v"(lane_off), "+v"(lane_c), "+v"(lane_so));   // not hoisted as 40 separate offsets
     float a[KP / 4];
+    // one straight-line run of loads per case (a per-element test of state_in turned every element into
+    // branch - load - wait)
+    auto build = [&](auto has_state) {
 #pragma unroll
-    for (int i = 0; i < KP / 4; ++i) {
-      const int kidx = kql * (KP / 4) + i;
-      const int c = kidx / KE, k = kidx - c * KE;
-      const int tt = t + k - (KE - 1);
-      // branch-free (see the x_proj kernel): padded taps and frames before the chunk without carried state are masked
-      const int cc = kidx < kvalid ? c : 0;
-      const float* src = xr + cc * sc + (tt >= 0 ? tt : 0) * st;
-      if (state_in) src = tt >= 0 ? src : state_in + ((b * cin + cc) * nf + f) * (KE - 1) + (KE - 1) + tt;
-      const float m = (kidx < kvalid && (tt >= 0 || state_in)) ? 1.f : 0.f;
-      a[i] = *src * m;
-      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    }
+      for (int i = 0; i < KP / 4; ++i) {
+        const int ci = i / KE, k = i % KE;                           // compile-time after unrolling
+        const bool cok = lane_c + ci < cin;
+        const bool tok = t + k - (KE - 1) >= 0;
+        const float* src = xr + (cok && tok ? lane_off + ci * isc + (k - (KE - 1)) * ist : 0);
+        if constexpr (decltype(has_state)::value)
+          src = tok ? src : sr + (cok ? lane_so + ci * nf * (KE - 1) + (k - (KE - 1)) : 0);
+        const float v = *src;
+        a[i] = (cok && (tok || decltype(has_state)::value)) ? v : 0.f;
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (state_in)
+      build(std::true_type{});
+    else
+      build(std::false_type{});
     float* dst = out + b * o_sb + t * o_st + f * o_sf + 4 * kq;
 #pragma unroll
     for (int j0 = 0; j0 < H / 16; j0 += 3) {
@@ -1245,7 +1260,10 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
   {
     fnssl::TimedLaunch tl("sn_encoder", s, 2.0 * npts * cin * KE * H);
     const int kk = cin * KE;
-    if (!getenv("FNSSL_SN_SCALAR") && kk <= 160) {
+    // the matrix-pipe kernel addresses a (b, f) row's channels and frames with 32-bit element offsets
+    const bool off32 = (long double)cin * (x_sc < 0 ? -x_sc : x_sc) + (long double)nt * (x_st < 0 ? -x_st : x_st) < 2.0e9L &&
+                       (long double)cin * nf * (KE - 1) + nt < 2.0e9L;
+    if (!getenv("FNSSL_SN_SCALAR") && kk <= 160 && off32) {
 #define FNSSL_SN_ENC(KP)                                                                                            \
   do {                                                                                                              \
     const size_t lds = (size_t)KP * H * sizeof(float);                                                              \
@@ -1255,9 +1273,7 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
     hipLaunchKernelGGL(sn_encoder_mfma_kernel<KP>, dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, x_sc, x_sf, \
                        x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);                         \
   } while (0)
-      if (kk <= 32)
-        FNSSL_SN_ENC(32);
-      else if (kk <= 80)
+      if (kk <= 80)
         FNSSL_SN_ENC(80);
       else
         FNSSL_SN_ENC(160);

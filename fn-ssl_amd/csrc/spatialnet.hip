@@ -366,36 +366,36 @@ sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const floa
 // ---------------------------------------------------------------------------------------------------------
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
-// sk / so: element strides of the input (k) and output (o) index in the source matrix
-template <int K, int N>
+// sk / so: element strides of the input (k) and output (o) index in the source matrix.  BD = threads of the workgroup
+// (compile-time: the trips are fully unrolled, so all of a thread's loads — 4 per 16-byte item, up to 12 items — are in
+// flight together.  Rolled, a trip was one L2 round trip and the 147 KB image of in_proj took 21 us per workgroup: half
+// of a small launch.)  LDS order, one conflict-free 16-byte write per item; an item's 4 values are 4 consecutive k of one
+// output, and the 16 lanes of an output tile read 64 contiguous bytes of each source row (the matrix is L2-resident).
+template <int K, int N, int BD>
 __device__ __forceinline__ void fill_w_lds_strided(float* lds, const float* __restrict__ w, int sk, int so, int kvalid,
                                                    int nvalid) {
-  constexpr int KQ = K / 4, G = KQ / 4;
+  constexpr int KQ = K / 4, G = KQ / 4, TOTAL = (N / 16) * G * 64, TRIPS = (TOTAL + BD - 1) / BD;
   static_assert(K % 16 == 0 && N % 16 == 0, "whole k-step groups and output tiles");
-  for (int idx = threadIdx.x; idx < (N / 16) * G * 64; idx += blockDim.x) {
+  float v[TRIPS][4];
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) {
+    const int idx = (int)threadIdx.x + u * BD;
     const int lane = idx & 63, g = (idx >> 6) % G, j = (idx >> 6) / G;
     const int k0 = (lane >> 4) * KQ + 4 * g, o = 16 * j + (lane & 15);
-    float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (k0 + i < kvalid && o < nvalid) ? w[(long long)(k0 + i) * sk + (long long)o * so] : 0.f;
-    *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int i = 0; i < 4; ++i)
+      v[u][i] = (idx < TOTAL && k0 + i < kvalid && o < nvalid) ? w[(long long)(k0 + i) * sk + (long long)o * so] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < TRIPS; ++u) {
+    const int idx = (int)threadIdx.x + u * BD;
+    if (idx < TOTAL) *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
   }
 }
 
-template <int K, int N>
+template <int K, int N, int BD>
 __device__ __forceinline__ void fill_w_lds(float* lds, const float* __restrict__ wT, int ldw, int kvalid, int nvalid) {
-  constexpr int KQ = K / 4, G = KQ / 4;
-  static_assert(K % 16 == 0 && N % 16 == 0, "whole k-step groups and output tiles");
-  // LDS order, one 16-byte write per thread and trip (conflict-free); its 4 values are 4 consecutive rows of wT at the
-  // same output, and the 16 lanes of an output tile read 64 contiguous bytes of each row (the matrix is L2-resident)
-  for (int idx = threadIdx.x; idx < (N / 16) * G * 64; idx += blockDim.x) {
-    const int lane = idx & 63, g = (idx >> 6) % G, j = (idx >> 6) / G;
-    const int k0 = (lane >> 4) * KQ + 4 * g, o = 16 * j + (lane & 15);
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (k0 + i < kvalid && o < nvalid) ? wT[(long long)(k0 + i) * ldw + o] : 0.f;
-    *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
-  }
+  fill_w_lds_strided<K, N, BD>(lds, wT, ldw, 1, kvalid, nvalid);
 }
 
 // acc[jj] += W-tile (j0 + jj) . x   for NJ output tiles at once (independent accumulators keep the pipe busy)
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(1024)
 sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const float* __restrict__ ln_w,
                         const float* __restrict__ ln_b, const float* __restrict__ winT, float* __restrict__ xz) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 24 tiles x 6 groups x 1 KiB
-  fill_w_lds<H, 2 * E>(ldsw, winT, 2 * E, H, 2 * E);
+  fill_w_lds<H, 2 * E, 1024>(ldsw, winT, 2 * E, H, 2 * E);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -498,8 +498,18 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
   float* par = lds + NG * 1024;                                    // ln_w | ln_b | bias | prelu (L1 latency per use otherwise)
   float* ytile = par + 4 * H;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
-#pragma unroll 1
-  for (int g = 0; g < NG; ++g) fill_w_lds<64, 16>(ldw + g * 1024, w.wT + g * (KF * CG * CG), CG, KF * CG, CG);
+#pragma unroll
+  for (int g = 0; g < NG; g += 4) {                                  // 4 groups x 256 items = one item per thread
+    const int gg = g + (tid >> 8);
+    const int idx = tid & 255;
+    const int lane = idx & 63, kg = idx >> 6;
+    const int k0 = (lane >> 4) * 16 + 4 * kg, o = lane & 15;
+    const float* wg = w.wT + gg * (KF * CG * CG);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (k0 + i < KF * CG && o < CG) ? wg[(k0 + i) * CG + o] : 0.f;
+    *reinterpret_cast<float4*>(ldw + gg * 1024 + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
   if (tid < 4 * H) {
     const float* src = tid < H ? w.ln_w : (tid < 2 * H ? w.ln_b : (tid < 3 * H ? w.bias : w.prelu));
     par[tid] = src[tid % H];
@@ -687,7 +697,7 @@ sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const fl
                            float* __restrict__ dbl) {
   constexpr int XN = 48;                                           // 40 outputs in 3 tiles
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 3 tiles x 12 groups x 1 KiB
-  fill_w_lds<E, XN>(ldsw, wxT, XP, E, XP);
+  fill_w_lds<E, XN, 512>(ldsw, wxT, XP, E, XP);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -725,7 +735,7 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
                          long long nout, const float* __restrict__ woT, int residual, float* out, long long o_sb,
                          long long o_st, long long o_sf) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x 12 groups x 1 KiB
-  fill_w_lds<E, H>(ldsw, woT, H, E, H);
+  fill_w_lds<E, H, 512>(ldsw, woT, H, E, H);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -793,7 +803,7 @@ sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, 
                        const float* __restrict__ state_in, float* __restrict__ out, long long o_sb, long long o_st,
                        long long o_sf) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x KP/16 groups x 1 KiB
-  fill_w_lds<KP, H>(ldsw, wT, H, cin * KE, H);
+  fill_w_lds<KP, H, 512>(ldsw, wT, H, cin * KE, H);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -1131,301 +1141,6 @@ sn_head_kernel(fnssl_btf_view xv, int nt2, int nfc, long long npts, const float*
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The whole Mamba block in one launch.  A workgroup (16 waves) owns a few whole sequences (bins), i.e. every dependency
-// of the block — the conv taps and the scan along time — is workgroup-local, and the five stages follow each other
-// behind __syncthreads() instead of behind kernel boundaries (at 51 k points a stage is 20-60 us of mostly launch and
-// weight-fill latency plus ~10 us of gap to the next one):
-//   A  xz = in_proj(LayerNorm(x))          16-point MFMA tiles, W_in resident in LDS
-//   B  u  = SiLU(conv4(xi))                thread = (point, channel quad)
-//   C  dbl = x_proj(u)                     MFMA tiles, W_x refilled into the same LDS
-//   D  the selective scan                  thread = (sequence, channel): 3 waves per sequence
-//   E  out = pool_T(x) + out_proj(pool_T(y))   MFMA tiles, W_out refilled
-// xz / dbl / u,y stay in the workspace (L2-resident, each workgroup its own range).  y overwrites u in place inside
-// the scan; stage E therefore reads y past the CU's vector L1 (sc1), which may still hold the u values of stage C.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 ld4_l2(const float* p) {
-  float4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-__global__ void __launch_bounds__(1024)
-sn_mamba_fused_kernel(fnssl_btf_view xv, int nt, int nf, long long nseq, int seq_per_wg, fnssl_sn_mamba_w w,
-                      int residual, int tp, float* conv_state, float* ssm_state, int carry, float* __restrict__ xz,
-                      float* __restrict__ dbl, float* ybuf, float* out, long long o_sb, long long o_st, long long o_sf,
-                      int stop_after) {
-  extern __shared__ __attribute__((aligned(16))) float ldsw[];
-  const long long s0 = (long long)blockIdx.x * seq_per_wg;
-  if (s0 >= nseq) return;
-  const int nsq = (int)(nseq - s0 < seq_per_wg ? nseq - s0 : seq_per_wg);
-  const long long p0 = s0 * nt;
-  const int P = nsq * nt;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
-  const float* ldsw_lane = ldsw + lane * 4;
-  const int ntiles = (P + 15) / 16;
-
-  // ---- A: in_proj(LayerNorm(x)) ------------------------------------------------------------------------------------
-  fill_w_lds<H, 2 * E>(ldsw, w.winT, 2 * E, H, 2 * E);
-  __syncthreads();
-  if (stop_after == 1) return;
-  {
-    float lw[H / 4], lb[H / 4];
-#pragma unroll
-    for (int i = 0; i < H / 4; ++i) {
-      lw[i] = w.ln_w[kq * (H / 4) + i];
-      lb[i] = w.ln_b[kq * (H / 4) + i];
-    }
-    for (int tile = wv; tile < ntiles; tile += 16) {
-      const int pl = tile * 16 + n;
-      const int plc = pl < P ? pl : P - 1;
-      const int t = plc % nt;
-      const long long sq = s0 + plc / nt;
-      const int f = (int)(sq % nf);
-      const long long b = sq / nf;
-      const float4* row = reinterpret_cast<const float4*>(xv.p + b * xv.sb + t * xv.st + f * xv.sf + kq * (H / 4));
-      float a[H / 4];
-#pragma unroll
-      for (int i = 0; i < H / 16; ++i) {
-        const float4 v = row[i];
-        a[4 * i] = v.x;
-        a[4 * i + 1] = v.y;
-        a[4 * i + 2] = v.z;
-        a[4 * i + 3] = v.w;
-      }
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < H / 4; ++i) sum += a[i];
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * (1.f / H);
-      float var = 0.f;
-#pragma unroll
-      for (int i = 0; i < H / 4; ++i) {
-        const float d = a[i] - mean;
-        var = fmaf(d, d, var);
-      }
-      var += __shfl_xor(var, 16, 64);
-      var += __shfl_xor(var, 32, 64);
-      const float rstd = 1.f / sqrtf(var * (1.f / H) + kEps);
-#pragma unroll
-      for (int i = 0; i < H / 4; ++i) a[i] = (a[i] - mean) * rstd * lw[i] + lb[i];
-      float* dst = xz + (p0 + pl) * (2 * E) + 4 * kq;
-#pragma unroll 1
-      for (int j0 = 0; j0 < (2 * E) / 16; j0 += 4) {
-        v4f_t acc[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-        mfma_tiles<H, 4>(a, ldsw_lane, j0, acc);
-        if (pl < P) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
-            *reinterpret_cast<float4*>(dst + 16 * (j0 + jj)) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (stop_after == 2) return;
-
-  // ---- B: u = SiLU(conv4(xi)) into the y buffer; the x_proj weights go into the LDS the in_proj weights left ----------
-  fill_w_lds<E, 48>(ldsw, w.wxT, XP, E, XP);
-  for (int idx = tid; idx < P * (E / 4); idx += 1024) {
-    const int e0 = (idx % (E / 4)) * 4;
-    const int pl = idx / (E / 4);
-    const int t = pl % nt;
-    const long long sq = s0 + pl / nt;
-    float4 v[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      const int tt = t - (KC - 1) + k;
-      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tt >= 0) {
-        v[k] = *reinterpret_cast<const float4*>(xz + (p0 + pl - t + tt) * (2 * E) + e0);
-      } else if (carry) {
-        v[k] = *reinterpret_cast<const float4*>(conv_state + (sq * (KC - 1) + (KC - 1) + tt) * E + e0);
-      }
-    }
-    const float xi[KC][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
-                             {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
-    const float4 cb = *reinterpret_cast<const float4*>(w.conv_b + e0);
-    const float cbv[4] = {cb.x, cb.y, cb.z, cb.w};
-    float r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 cw = *reinterpret_cast<const float4*>(w.conv_w + (e0 + i) * KC);
-      float a = cbv[i];
-      a = fmaf(cw.x, xi[0][i], a);
-      a = fmaf(cw.y, xi[1][i], a);
-      a = fmaf(cw.z, xi[2][i], a);
-      a = fmaf(cw.w, xi[3][i], a);
-      r[i] = silu_f(a);
-    }
-    *reinterpret_cast<float4*>(ybuf + (p0 + pl) * E + e0) = make_float4(r[0], r[1], r[2], r[3]);
-  }
-  __syncthreads();
-  if (stop_after == 3) return;
-
-  // ---- C: dbl = x_proj(u) ------------------------------------------------------------------------------------------------
-  for (int tile = wv; tile < ntiles; tile += 16) {
-    const int pl = tile * 16 + n;
-    const int plc = pl < P ? pl : P - 1;
-    const float4* ub = reinterpret_cast<const float4*>(ybuf + (p0 + plc) * E + kq * (E / 4));
-    float a[E / 4];
-#pragma unroll
-    for (int e4 = 0; e4 < E / 16; ++e4) {
-      const float4 v = ub[e4];
-      a[4 * e4] = v.x;
-      a[4 * e4 + 1] = v.y;
-      a[4 * e4 + 2] = v.z;
-      a[4 * e4 + 3] = v.w;
-    }
-    v4f_t acc[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-    mfma_tiles<E, 3>(a, ldsw_lane, 0, acc);
-    if (pl < P) {
-      float* dst = dbl + (p0 + pl) * XP + 4 * kq;
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
-        if (16 * jj + 4 * kq < XP)
-          *reinterpret_cast<float4*>(dst + 16 * jj) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
-    }
-  }
-  __syncthreads();
-  if (stop_after == 4) return;
-
-  // ---- D: the scan (3 waves per sequence); the out_proj weights are filled first ----------------------------------------
-  fill_w_lds<E, H>(ldsw, w.woT, H, E, H);
-  if (tid < nsq * E) {
-    const long long s = s0 + tid / E;
-    const int e = tid % E;
-    float A[NST], h[NST], wd[RK];
-#pragma unroll
-    for (int q = 0; q < NST; ++q) {
-      A[q] = w.a[e * NST + q] * 1.44269504088896340736f;
-      h[q] = (carry && ssm_state) ? ssm_state[(s * E + e) * NST + q] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < RK; ++r) wd[r] = w.wdt[e * RK + r];
-    const float bd = w.bdt[e], dp = w.d[e];
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (carry && conv_state) {
-      x0 = conv_state[(s * 3 + 0) * E + e];
-      x1 = conv_state[(s * 3 + 1) * E + e];
-      x2 = conv_state[(s * 3 + 2) * E + e];
-    }
-    const float* xrow = xz + s * nt * (2 * E) + e;
-    const float* drow = dbl + s * nt * XP;
-    float* yrow = ybuf + s * nt * E + e;
-    float u_n = yrow[0], z_n = xrow[E];
-    float row_n[RK + 2 * NST];
-#pragma unroll
-    for (int i = 0; i < RK + 2 * NST; ++i) row_n[i] = drow[i];
-    for (int t = 0; t < nt; ++t) {
-      const float u = u_n, z = z_n;
-      float row[RK + 2 * NST];
-#pragma unroll
-      for (int i = 0; i < RK + 2 * NST; ++i) row[i] = row_n[i];
-      if (t + 1 < nt) {
-        u_n = yrow[(long long)(t + 1) * E];
-        z_n = xrow[(long long)(t + 1) * (2 * E) + E];
-#pragma unroll
-        for (int i = 0; i < RK + 2 * NST; ++i) row_n[i] = drow[(long long)(t + 1) * XP + i];
-      }
-      float dtv = bd;
-#pragma unroll
-      for (int r = 0; r < RK; ++r) dtv = fmaf(wd[r], row[r], dtv);
-      float dt = dtv;
-      if (dtv <= 20.f) {
-        const float ex = __expf(dtv), u1 = 1.f + ex;
-        dt = u1 == 1.f ? ex : __logf(u1) * __fdividef(ex, u1 - 1.f);
-      }
-      const float dtu = dt * u;
-      float y = 0.f;
-#pragma unroll
-      for (int q = 0; q < NST; ++q) {
-        const float dA = __builtin_amdgcn_exp2f(dt * A[q]);
-        h[q] = fmaf(dA, h[q], dtu * row[RK + q]);
-        y = fmaf(h[q], row[RK + NST + q], y);
-      }
-      yrow[(long long)t * E] = fmaf(dp, u, y) * silu_f(z);
-    }
-    if (ssm_state) {
-#pragma unroll
-      for (int q = 0; q < NST; ++q) ssm_state[(s * E + e) * NST + q] = h[q];
-    }
-    if (conv_state) {                                      // the last three xi of the chunk (older ones: the carried state)
-      float xs[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int tt = nt - 3 + j;
-        xs[j] = tt >= 0 ? xrow[(long long)tt * (2 * E)] : (tt == -1 ? x2 : (tt == -2 ? x1 : x0));
-      }
-      conv_state[(s * 3 + 0) * E + e] = xs[0];
-      conv_state[(s * 3 + 1) * E + e] = xs[1];
-      conv_state[(s * 3 + 2) * E + e] = xs[2];
-    }
-  }
-  __syncthreads();
-  if (stop_after == 5) return;
-
-  // ---- E: out = pool_T(x) + out_proj(pool_T(y)) --------------------------------------------------------------------------
-  const int nt2 = nt / tp;
-  const int P2 = nsq * nt2;
-  const float inv = 1.f / (float)tp;
-  for (int tile = wv; tile * 16 < P2; tile += 16) {
-    const int pl = tile * 16 + n;
-    const int plc = pl < P2 ? pl : P2 - 1;
-    const int t2 = plc % nt2;
-    const long long sq = s0 + plc / nt2;
-    const int f = (int)(sq % nf);
-    const long long b = sq / nf;
-    const float* yb = ybuf + (sq * nt + (long long)t2 * tp) * E + kq * (E / 4);
-    float a[E / 4];
-#pragma unroll
-    for (int e4 = 0; e4 < E / 16; ++e4) {
-      float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = 0; i < tp; ++i) {
-        const float4 v = ld4_l2(yb + (long long)i * E + e4 * 4);
-        yv.x += v.x;
-        yv.y += v.y;
-        yv.z += v.z;
-        yv.w += v.w;
-      }
-      a[4 * e4] = yv.x * inv;
-      a[4 * e4 + 1] = yv.y * inv;
-      a[4 * e4 + 2] = yv.z * inv;
-      a[4 * e4 + 3] = yv.w * inv;
-    }
-    const float* xb = xv.p + b * xv.sb + (long long)t2 * tp * xv.st + f * xv.sf + 4 * kq;
-    float* dst = out + b * o_sb + t2 * o_st + f * o_sf + 4 * kq;
-#pragma unroll 1
-    for (int j0 = 0; j0 < H / 16; j0 += 3) {
-      v4f_t acc[3];
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-      mfma_tiles<E, 3>(a, ldsw_lane, j0, acc);
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) {
-        float4 o4 = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
-        if (residual) {
-          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int i = 0; i < tp; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(xb + (long long)i * xv.st + 16 * (j0 + jj));
-            r.x += v.x;
-            r.y += v.y;
-            r.z += v.z;
-            r.w += v.w;
-          }
-          o4 = make_float4(fmaf(r.x, inv, o4.x), fmaf(r.y, inv, o4.y), fmaf(r.z, inv, o4.z), fmaf(r.w, inv, o4.w));
-        }
-        if (pl < P2) *reinterpret_cast<float4*>(dst + 16 * (j0 + jj)) = o4;
-      }
-    }
-  }
-}
-
 // Head on the matrix pipe.  Fine bin r of a compressed bin is output tile r of FreqInverse's 96 -> 256 product; its
 // D fragment (lane (point, q): outputs 4 q .. + 3) after bias + tanh is exactly the B operand of the decoder's
 // 16 -> 16 product (K = 16: lane q holds k = 4 q .. + 3), so the decoder is one more group of 4 MFMAs per fine bin.
@@ -1441,8 +1156,8 @@ sn_head_mfma_kernel(fnssl_btf_view xv, int nt2, int nfc, long long npts, const f
                     float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // FreqInverse: 16 tiles x 6 groups x 1 KiB; decoder: 1 KiB
   float* ldsd = ldsw + 16 * 6 * 256;
-  fill_w_lds_strided<H, 16 * DO>(ldsw, wfiP, 1, H, H, 16 * DO);
-  fill_w_lds<DO, DO>(ldsd, wdT, DO, DO, DO);
+  fill_w_lds_strided<H, 16 * DO, 512>(ldsw, wfiP, 1, H, H, 16 * DO);
+  fill_w_lds<DO, DO, 512>(ldsd, wdT, DO, DO, DO);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -1671,25 +1386,6 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   const MambaWs m = carve_mamba(static_cast<float*>(workspace), npts);
   hipStream_t s = fnssl::as_stream(stream);
   const bool mfma = !getenv("FNSSL_SN_SCALAR");   // A/B: the scalar-operand kernels
-  if (mfma && getenv("FNSSL_SN_FUSED")) {          // experiment: the whole block in one launch
-    const int ncu = fnssl::device_cus();
-    int spw = (int)((nseq + ncu - 1) / ncu);
-    spw = spw < 1 ? 1 : (spw > 5 ? 5 : spw);       // 3 waves per sequence in the scan stage, 16 waves per workgroup
-    const long long nwg = (nseq + spw - 1) / spw;
-    FNSSL_REQUIRE(nwg < (1ll << 31) && (long long)spw * nt < (1ll << 24), "sn_mamba: too many sequences / frames");
-    const size_t lds = (size_t)H * 2 * E * sizeof(float);
-    static const hipError_t attr_fu = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_fused_kernel),
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    FNSSL_HIP(attr_fu);
-    const double flops = 2.0 * npts * H * 2 * E + 2.0 * npts * E * (XP - 2 + KC) +
-                         (double)npts * E * (7.0 * NST + 2 * RK + 2 * KC) + 2.0 * nseq * (nt / time_pool) * E * H;
-    fnssl::TimedLaunch tl("sn_mamba_block", s, flops);
-    const int stop = getenv("FNSSL_SN_FUSED_STOP") ? atoi(getenv("FNSSL_SN_FUSED_STOP")) : 0;
-    hipLaunchKernelGGL(sn_mamba_fused_kernel, dim3((unsigned)nwg), dim3(1024), lds, s, *x, nt, nf, nseq, spw, *w, residual,
-                       time_pool, conv_state, ssm_state, carry, m.xz, m.dbl, m.y, out, o_sb, o_st, o_sf, stop);
-    FNSSL_CHECK_LAUNCH("sn_mamba_fused_kernel");
-    return FNSSL_OK;
-  }
   {
     fnssl::TimedLaunch tl("sn_mamba_in", s, 2.0 * npts * H * 2 * E);
     if (mfma) {

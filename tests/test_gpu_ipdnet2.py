@@ -197,3 +197,29 @@ def test_matrix_pipe_kernels_equal_scalar_kernels_at_multi_pass_size(dev, monkey
     err = (got - want).abs().max().item()
     assert err <= 2e-5, err
     assert torch.equal(net(x), got)                                       # deterministic
+
+
+@pytest.mark.parametrize("nb,nf,nt,layers", [(1, 256, 5, 2), (3, 128, 15, 2), (2, 256, 35, 3)])
+def test_matrix_pipe_kernels_equal_scalar_kernels_at_ragged_sizes(dev, monkeypatch, nb, nf, nt, layers):
+    """Point counts that are not multiples of the 16-point MFMA tiles, a 128-bin network, a single utterance; whole
+    forward and a streamed forward (carried conv / scan / encoder state) against the scalar-operand kernels."""
+    sd, net = build_net(dev, 2500 + nf + nt, dim_input=10, num_layers=layers, num_freqs=nf)
+    x = to_dev(rs_randn(2501 + nt, (nb, 10, nf, nt), 0.7), dev)
+
+    def run():
+        whole = net(x)
+        st, outs, t0 = None, [], 0
+        for n in ([5] * (nt // 5)):
+            o, st = net.forward_stream(x[..., t0:t0 + n], st)
+            outs.append(o)
+            t0 += n
+        return whole, torch.cat(outs, 1)
+
+    got, got_s = run()
+    monkeypatch.setenv("FNSSL_SN_SCALAR", "1")
+    want, want_s = run()
+    monkeypatch.delenv("FNSSL_SN_SCALAR")
+    assert got.shape == want.shape == (nb, nt // 5, 2 * nf, 4, 2)
+    assert (got - want).abs().max().item() <= 2e-5
+    assert (got_s - want_s).abs().max().item() <= 2e-5
+    assert (got_s - got).abs().max().item() <= 2e-5

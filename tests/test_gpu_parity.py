@@ -1077,3 +1077,31 @@ def test_conv3x3_bf16x_fused_pool_equals_conv_then_pool(dev, pool, nt):
         want = ops.avgpool_time(plain, pool, bf16_out=bf)
         assert fused.shape == want.shape == (nb, nf, nt // pool, cout) and fused.dtype == want.dtype
         assert torch.equal(fused, want), (fused.float() - want.float()).abs().max()
+
+
+def test_conv3x3_bf16x_random_shapes_against_first_bf16_kernel(dev):
+    """30 seeded random problems (channel groups, skip segment or not, partial cout tiles, ragged frames / bins, all
+    three poolings, strided inputs) through the LDS-staged kernel against the first bf16 kernel + avgpool_time, which
+    the tests above pin to the bf16 oracle: same operand rounding, different summation order."""
+    from fnssl import ops
+    rng = np.random.RandomState(20260928)
+    for it in range(30):
+        ca = 32 * int(rng.randint(1, 5))
+        cb = 16 * int(rng.randint(0, 3))
+        cout = int(rng.choice([68, 96, 100, 128]))
+        nb, nf, nt = int(rng.randint(1, 4)), int(rng.randint(1, 9)), int(rng.randint(1, 150))
+        pool = int(rng.choice([1, 3, 4]))
+        act = str(rng.choice(["none", "relu", "tanh"]))
+        w = rs_randn(5600 + it, (cout, ca + cb, 3, 3), 0.1)
+        xa = to_dev(rs_randn(5700 + it, (nb, nt, nf, ca)), dev).bfloat16().permute(0, 2, 1, 3)   # stored [b, t, f, c]
+        xb = to_dev(rs_randn(5800 + it, (nb, nf, nt, cb)), dev) if cb else None
+        px = ops.pack_conv3x3_bf16x(w, ca, cb, dev)
+        p1 = ops.pack_conv3x3(w, ca, cb, dev, bf16=True)
+        got = ops.conv3x3_causal_bf16x(xa, xb, px, cout, act, pool=pool)
+        ref = ops.conv3x3_causal(xa, xb, p1, cout, act, bf16=True)[..., :cout]
+        if pool > 1:
+            ref = ops.avgpool_time(ref.contiguous(), pool) if nt // pool else ref[:, :, :0]
+        assert got.shape == ref.shape, (it, got.shape, ref.shape)
+        if got.numel():
+            err = (got - ref).abs().max().item()
+            assert err <= 3e-5 * max(1.0, ref.abs().max().item()), (it, ca, cb, cout, nb, nf, nt, pool, act, err)

@@ -17,7 +17,8 @@ per-GPU batch (weak scaling; utterances are independent: no data-path collective
 all-reduce).  K steps are timed between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line whose
 `value` is utterance-frames per second over all ranks.  The line also carries
   roofline     : the dominant kernel against its roof, timed with HIP events on the launch stream inside the timed
-                 region (`frontend`: the STFT + feature kernels against the HBM roof, config 2);
+                 region — only that kernel is bracketed there (fnssl_timing_select); `kernels` and `frontend` (the STFT
+                 + feature kernels against the HBM roof, config 2) come from an instrumented pass before it;
   cpu_baseline : the CPU restatement of the reference (oracle/) timed on this host on a bounded sample
                  (N = 1, rank 0 only), and `parity`: the same sample through the HIP path vs that CPU output.
 A failed parity check nulls `value` and exits 1.
@@ -78,7 +79,7 @@ def kernel_roof(kern, name, label, peak, unit_scale=1e12, traffic=None, traffic_
     if not k or k["ms"] <= 0 or not k["flops"]:
         return None
     achieved = k["flops"] / (k["ms"] * 1e-3) / unit_scale
-    return {"bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+    return {"name": name, "bound": "mfma", "kernel": label, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
             "launches": k["count"], "avg_ms": round(k["ms"] / max(1, k["count"]), 3),
             "flop_per_launch": k["flops"] / max(1, k["count"])}
@@ -414,8 +415,8 @@ class Ipdnet2Forward:
         return {"whole_path_tflops": round(value * self.flop_per_frame / 1e12 / self.world, 2)}
 
     def roofline(self, kern):
-        # every kernel of this network is a small dense contraction: the roof is the fp32 matrix peak even though
-        # the kernels run on the packed-fp32 vector pipe (IPDnet2 section)
+        # every kernel of this network is a small dense contraction (fp32 MFMA for the projections / convs, packed fp32
+        # FMA for the scan): the roof is the fp32 matrix peak, which is also the packed-FMA rate
         dom = max((k for k in kern if k.startswith("sn_")), key=lambda k: kern[k]["ms"], default=None)
         return kernel_roof(kern, dom, "%s (dominant kernel of the step)" % dom, PEAK_FP32_MFMA_TFLOPS) if dom else None
 
@@ -487,7 +488,21 @@ def main():
     for _ in range(args.warmup):
         out = wl.step()
     sync_all()
-    ops.timing_enable(True)                      # per-kernel HIP events on the launch stream, in the timed region
+    # Per-kernel breakdown: an instrumented pass of its own (every launch bracketed by HIP events), outside the timed
+    # region — two event records per launch cost a 106-launch step (IPDnet2) 10 % of its time.  The timed region
+    # below brackets only the roofline kernel, which is what `roofline.achieved` is computed from.
+    probe_steps = max(1, min(3, args.steps))
+    ops.timing_select(None)
+    ops.timing_enable(True)
+    for _ in range(probe_steps):
+        out = wl.step()
+    sync_all()
+    ops.timing_enable(False)
+    kern_all = ops.timing_collect()
+    roof_probe = wl.roofline(kern_all)
+    roof_name = roof_probe.get("name") if roof_probe else None
+    ops.timing_select(roof_name)
+    ops.timing_enable(roof_name is not None)     # HIP events on the launch stream around the roofline kernel only
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -497,6 +512,7 @@ def main():
     sync_all()
     dt_local = time.perf_counter() - t0
     ops.timing_enable(False)
+    ops.timing_select(None)
     kern = ops.timing_collect()
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
     log("rank %d: timed %d steps in %.3f s (median step %.3f ms by HIP events)" % (rank, args.steps, dt_local,
@@ -513,11 +529,13 @@ def main():
     wl.check(out)
 
     value = wl.frames_per_step * args.steps * world / dt
-    roof = wl.roofline(kern)
-    breakdown = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["count"] / args.steps,
+    roof = wl.roofline(kern) if roof_name else None      # from the events recorded inside the timed region
+    if roof is not None:
+        roof.pop("name", None)
+    breakdown = {k: {"ms_per_step": round(v["ms"] / probe_steps, 3), "launches_per_step": v["count"] / probe_steps,
                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] else None}
-                 for k, v in sorted(kern.items())}
-    extra = wl.extra(value, kern, args.steps)
+                 for k, v in sorted(kern_all.items())}
+    extra = wl.extra(value, kern_all, probe_steps)
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -532,6 +550,7 @@ def main():
             "config": wl.config(), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "ms_per_step_median_hip_events": round(step_ms[len(step_ms) // 2], 3), "ms_per_step_per_rank": per_rank,
             "rccl_world_size": dist.get_world_size() if dist is not None else 1, "kernels": breakdown,
+            "kernels_source": "separate instrumented pass of %d steps (every launch bracketed); the timed region brackets only the roofline kernel" % probe_steps,
         }
         line.update(extra)
         print(json.dumps(line))

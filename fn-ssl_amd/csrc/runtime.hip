@@ -43,11 +43,13 @@ struct Rec {
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 bool g_timing = false;
+char g_select[64] = "";   // non-empty: only launches with this name are bracketed
 }  // namespace
 
 TimedLaunch::TimedLaunch(const char* name, hipStream_t s, double flops)
     : name_(name), s_(s), flops_(flops) {
   if (!g_timing) return;
+  if (g_select[0] && std::strcmp(g_select, name) != 0) return;
   if (hipEventCreate(&e0_) != hipSuccess) {
     e0_ = nullptr;
     return;
@@ -78,6 +80,12 @@ const char* fnssl_last_error(void) { return fnssl::g_err; }
 int fnssl_timing_enable(int enable) {
   std::lock_guard<std::mutex> lk(fnssl::g_mu);
   fnssl::g_timing = enable != 0;
+  return FNSSL_OK;
+}
+
+int fnssl_timing_select(const char* name) {
+  std::lock_guard<std::mutex> lk(fnssl::g_mu);
+  std::snprintf(fnssl::g_select, sizeof(fnssl::g_select), "%s", name ? name : "");
   return FNSSL_OK;
 }
 

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -35,7 +35,7 @@ SYMBOLS = [
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
     "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
-    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect",
+    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select",
     "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
     "fnssl_train_create", "fnssl_train_destroy", "fnssl_train_param_floats", "fnssl_train_param_offset",
     "fnssl_train_map_bytes", "fnssl_train_upload_maps", "fnssl_train_workspace_bytes", "fnssl_train_backward",
@@ -236,6 +236,7 @@ def load():
     lib.fnssl_sn_state_floats.restype = sz
     lib.fnssl_sn_forward.argtypes = [C.POINTER(SnNet), vp, ll, ll, ll, ll, i, i, i, vp, i, vp, vp, sz, vp]
     lib.fnssl_timing_enable.argtypes = [i]
+    lib.fnssl_timing_select.argtypes = [C.c_char_p]
     lib.fnssl_timing_collect.argtypes = [i, vp, vp, vp, vp]
     if lib.fnssl_abi_version() != ABI_VERSION:
         raise RuntimeError("fnssl: ABI version mismatch (library %d, binding %d)"

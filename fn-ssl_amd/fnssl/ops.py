@@ -664,6 +664,11 @@ def timing_enable(on: bool):
     check(_lib.load().fnssl_timing_enable(1 if on else 0), "timing_enable")
 
 
+def timing_select(name=None):
+    """Bracket only launches of kernel ``name`` (None: all)."""
+    check(_lib.load().fnssl_timing_select(name.encode() if name else None), "timing_select")
+
+
 def timing_collect(cap: int = 64):
     names = ((C.c_char * 64) * cap)()
     ms = (C.c_double * cap)()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 7
+#define FNSSL_ABI_VERSION 8
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -588,6 +588,10 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
 
 /* enable = 1: every kernel launch is bracketed by hipEvents on its stream. */
 int fnssl_timing_enable(int enable);
+/* Restrict the bracketing to launches of one kernel name (as reported by fnssl_timing_collect); NULL or "": all.
+ * bench.py brackets only the roofline kernel inside the timed region: two event records per launch on 106 launches
+ * cost IPDnet2 10 % of its step. */
+int fnssl_timing_select(const char* name);
 /* Drain recorded events (synchronises them) and reset.  Returns the number of
  * distinct kernel names; names/ms/count/flops are HOST arrays of capacity cap. */
 int fnssl_timing_collect(int cap, char (*names)[64], double* total_ms, long long* count,

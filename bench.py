@@ -438,6 +438,11 @@ WORKLOADS = {2: FnsslForward, 3: IpdnetForward, 4: FnsslTrain, 5: Ipdnet2Forward
 
 
 def main():
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints a
+    # version banner at init) are pointed at stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -553,7 +558,7 @@ def main():
             "kernels_source": "separate instrumented pass of %d steps (every launch bracketed); the timed region brackets only the roofline kernel" % probe_steps,
         }
         line.update(extra)
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
     if failed:

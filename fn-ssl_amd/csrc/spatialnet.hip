@@ -600,7 +600,7 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
     }
     __syncthreads();
     load_rows(blk + gridDim.x, xn);
-#pragma unroll 1
+#pragma unroll
     for (int g = 0; g < NG; ++g) {
       float a[16];
 #pragma unroll

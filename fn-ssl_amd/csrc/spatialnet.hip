@@ -651,6 +651,191 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
   }
 }
 
+// Full-band branch on the matrix pipe: x (+)= SiLU(unsqueeze(Linear_over_F(SiLU(squeeze(LayerNorm(x)))))).
+// Same workgroup shape and channel ownership as the f-conv kernel (256 points = whole frames; lane (n, q) owns bin n and
+// the channels 12 g + 4 q .. + 3, q < 3), three products:
+//   squeeze   s[8]  = Ws . ln        K = 96 (the lane's 32 registers ARE its B operand; lane q = 3 holds zeros, K = 128),
+//                                    N = 16 (8 used); D gives lane (bin, q < 2) the outputs 4 q .. + 3
+//   over F    y[f'][(frame, c)] = sum_f Wf[f][f'] s[f][(frame, c)]   K = M = NF, 16 columns = 2 frames x 8 squeezed
+//                                    channels per tile: always 8 (M-tile, column-tile) pairs, one per wave 0..7;
+//                                    s goes through LDS transposed per frame ([frame][c][f], f contiguous = the B operand)
+//   unsqueeze out[96] = Wu . y       K = 8 (16), 8 output tiles whose rows are permuted to the ownership order, so the
+//                                    D fragment lands on the lane that holds the residual row
+template <int NF, int POOLDUMMY>
+__global__ void __launch_bounds__(1024)
+sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk, fnssl_sn_full_w w, int residual,
+                    float* out, long long o_sb, long long o_st, long long o_sf) {
+  constexpr int LG = NF == 128 ? 7 : (NF == 64 ? 6 : (NF == 32 ? 5 : 4));
+  constexpr int FPB = 256 / NF;                                     // frames per block
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ldwf = lds;                                                // (NF/16)^2 KiB
+  float* ldws = ldwf + (NF / 16) * (NF / 16) * 256;                 // 8 KiB
+  float* ldwu = ldws + 8 * 256;                                     // 8 KiB
+  float* par = ldwu + 8 * 256;                                      // ln_w 96 | ln_b 96 | bu 96 | bs 16 | bf NF
+  float* st_img = par + 3 * H + 16 + NF;                            // [frame][8][NF]
+  float* y_img = st_img + 256 * 8;                                  // [point][8]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+  fill_w_lds<NF, NF, 1024>(ldwf, w.wfT, NF, NF, NF);
+  if (tid < 512) {                                                  // squeeze image: 8 k-groups x 64 lanes
+    const int ln = tid & 63, gk = tid >> 6, o = ln & 15, kq = ln >> 4;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (kq < 3 && o < HS) ? w.wsT[(CG * gk + 4 * kq + i) * HS + o] : 0.f;
+    *reinterpret_cast<float4*>(ldws + tid * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {                                                          // unsqueeze image: 8 output tiles x 64 lanes
+    const int t2 = tid - 512, ln = t2 & 63, g = t2 >> 6, orow = ln & 15, kq = ln >> 4, og = orow >> 2, r = orow & 3;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (og < 3 && 4 * kq + i < HS) ? w.wuT[(4 * kq + i) * H + CG * g + 4 * og + r] : 0.f;
+    *reinterpret_cast<float4*>(ldwu + t2 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  for (int i = tid; i < 3 * H + 16 + NF; i += 1024) {
+    float v;
+    if (i < H) v = w.ln_w[i];
+    else if (i < 2 * H) v = w.ln_b[i - H];
+    else if (i < 3 * H) v = w.bu[i - 2 * H];
+    else if (i < 3 * H + 16) v = i - 3 * H < HS ? w.bs[i - 3 * H] : 0.f;
+    else v = w.bf[i - 3 * H - 16];
+    par[i] = v;
+  }
+  __syncthreads();
+  const int pt = 16 * wv + n;
+  const int fr = pt >> LG, f = pt & (NF - 1);
+  const float* ldws_lane = ldws + lane * 4;
+  const float* ldwu_lane = ldwu + lane * 4;
+  const float* ldwf_lane = ldwf + lane * 4;
+  auto load_rows = [&](long long blk, float (&xr)[NG][4]) {
+    const long long frame = blk * FPB + fr;
+    const bool ok = blk < nblk && frame < nframes && q < 3;
+    const long long fc = ok ? frame : 0;
+    const float* row = xv.p + (fc / nt) * xv.sb + (fc % nt) * xv.st + f * xv.sf + 4 * q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(row + CG * g);
+      xr[g][0] = v.x;
+      xr[g][1] = v.y;
+      xr[g][2] = v.z;
+      xr[g][3] = v.w;
+    }
+  };
+  float xn[NG][4];
+  load_rows(blockIdx.x, xn);
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    float xr[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xr[g][r] = xn[g][r];
+    const long long frame = blk * FPB + fr;
+    const bool valid = frame < nframes;
+    const long long b = frame / nt;
+    const int t = (int)(frame % nt);
+    // LayerNorm (32 channels in each of the lanes q = 0..2)
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) sum += (xr[g][0] + xr[g][1]) + (xr[g][2] + xr[g][3]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / H);
+    float var = 0.f;
+    if (q < 3) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = xr[g][r] - mean;
+          var = fmaf(d, d, var);
+        }
+    }
+    var += __shfl_xor(var, 16, 64);
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.f / sqrtf(var * (1.f / H) + kEps);
+    float a[32];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float4 lw = *reinterpret_cast<const float4*>(par + CG * g + 4 * (q < 3 ? q : 0));
+      const float4 lb = *reinterpret_cast<const float4*>(par + H + CG * g + 4 * (q < 3 ? q : 0));
+      const float m = q < 3 ? 1.f : 0.f;
+      a[4 * g] = ((xr[g][0] - mean) * rstd * lw.x + lb.x) * m;
+      a[4 * g + 1] = ((xr[g][1] - mean) * rstd * lw.y + lb.y) * m;
+      a[4 * g + 2] = ((xr[g][2] - mean) * rstd * lw.z + lb.z) * m;
+      a[4 * g + 3] = ((xr[g][3] - mean) * rstd * lw.w + lb.w) * m;
+    }
+    // ---- squeeze -> SiLU -> transposed image [frame][c][f]
+    {
+      v4f_t acc[1] = {v4f_t{0.f, 0.f, 0.f, 0.f}};
+      mfma_tiles<128, 1>(a, ldws_lane, 0, acc);
+      if (q < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          st_img[(fr * HS + 4 * q + r) * NF + f] = silu_f(acc[0][r] + par[3 * H + 4 * q + r]);
+      }
+    }
+    __syncthreads();
+    load_rows(blk + gridDim.x, xn);
+    // ---- Linear over F: pair (M-tile mt, column tile ct) on wave 0..7; column n = (frame 2 ct + (n >> 3), c = n & 7)
+    if (wv < 8) {
+      constexpr int CT = 128 / NF;                                  // column tiles
+      const int mt = wv / CT, ct = wv % CT;
+      const int cfr = 2 * ct + (n >> 3), cc = n & 7;
+      float bv[NF / 4];
+      const float4* src = reinterpret_cast<const float4*>(st_img + (cfr * HS + cc) * NF + q * (NF / 4));
+#pragma unroll
+      for (int i = 0; i < NF / 16; ++i) {
+        const float4 v = src[i];
+        bv[4 * i] = v.x;
+        bv[4 * i + 1] = v.y;
+        bv[4 * i + 2] = v.z;
+        bv[4 * i + 3] = v.w;
+      }
+      v4f_t acc[1] = {v4f_t{0.f, 0.f, 0.f, 0.f}};
+      mfma_tiles<NF, 1>(bv, ldwf_lane, mt, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int fo = 16 * mt + 4 * q + r;
+        y_img[(cfr * NF + fo) * HS + cc] = acc[0][r] + par[3 * H + 16 + fo];
+      }
+    }
+    __syncthreads();
+    // ---- unsqueeze -> SiLU -> residual
+    {
+      float yv[4];
+      const float4 v = *reinterpret_cast<const float4*>(y_img + pt * HS + 4 * (q < 2 ? q : 0));
+      const float m = q < 2 ? 1.f : 0.f;
+      yv[0] = v.x * m;
+      yv[1] = v.y * m;
+      yv[2] = v.z * m;
+      yv[3] = v.w * m;
+#pragma unroll
+      for (int g0 = 0; g0 < NG; g0 += 4) {
+        v4f_t acc[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
+        mfma_tiles<16, 4>(yv, ldwu_lane, g0, acc);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float4 bu4 = *reinterpret_cast<const float4*>(par + 2 * H + CG * (g0 + jj) + 4 * (q < 3 ? q : 0));
+          const float bb[4] = {bu4.x, bu4.y, bu4.z, bu4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float u = silu_f(acc[jj][r] + bb[r]);
+            xr[g0 + jj][r] = residual ? xr[g0 + jj][r] + u : u;
+          }
+        }
+      }
+    }
+    if (valid && q < 3) {
+      float* dst = out + b * o_sb + t * o_st + f * o_sf + 4 * q;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        *reinterpret_cast<float4*>(dst + CG * g) = make_float4(xr[g][0], xr[g][1], xr[g][2], xr[g][3]);
+    }
+    // the next block's images are written after its own barriers; st_img is rewritten only after the __syncthreads()
+    // that follows this block's last read of it (above), y_img after the next block's first barrier
+  }
+}
+
 // Mamba, phase 2a: u[p, e] = SiLU(conv4(xi))(p, e) over the taps t-3..t of xz (thread = point x channel quad).  u is
 // what x_proj and the scan both consume; it lives in the scan's output buffer (the scan reads u_t before it writes y_t).
 __global__ void __launch_bounds__(256)
@@ -1356,8 +1541,30 @@ int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_s
   FNSSL_REQUIRE(nblk < (1ll << 31), "sn_full: too many frames");
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl("sn_full", s, 2.0 * nframes * nf * (2.0 * H * HS + (double)HS * nf));
-  hipLaunchKernelGGL(sn_full_kernel, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, out,
-                     o_sb, o_st, o_sf);
+  const bool mfma = !getenv("FNSSL_SN_SCALAR") && (nf == 16 || nf == 64 || nf == 128);
+  if (mfma) {
+    const long long cus = fnssl::device_cus();
+    const unsigned grid = (unsigned)(nblk < cus ? nblk : cus);
+    const size_t lds = (size_t)((nf / 16) * (nf / 16) * 256 + 16 * 256 + 3 * H + 16 + nf + 2 * 256 * 8) * sizeof(float);
+#define FNSSL_SN_FULL(NFV)                                                                                         \
+  do {                                                                                                             \
+    static const hipError_t attr_fl = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_full_mfma_kernel<NFV, 0>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    FNSSL_HIP(attr_fl);                                                                                            \
+    hipLaunchKernelGGL((sn_full_mfma_kernel<NFV, 0>), dim3(grid), dim3(1024), lds, s, *x, nt, nframes, nblk, *w, residual, \
+                       out, o_sb, o_st, o_sf);                                                                     \
+  } while (0)
+    if (nf == 16)
+      FNSSL_SN_FULL(16);
+    else if (nf == 64)
+      FNSSL_SN_FULL(64);
+    else
+      FNSSL_SN_FULL(128);
+#undef FNSSL_SN_FULL
+  } else {
+    hipLaunchKernelGGL(sn_full_kernel, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, out,
+                       o_sb, o_st, o_sf);
+  }
   FNSSL_CHECK_LAUNCH("sn_full_kernel");
   return FNSSL_OK;
 }

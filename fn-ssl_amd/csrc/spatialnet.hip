@@ -1462,9 +1462,8 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
 #define FNSSL_SN_ENC(KP)                                                                                            \
   do {                                                                                                              \
     const size_t lds = (size_t)KP * H * sizeof(float);                                                              \
-    static const hipError_t attr_enc = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-    FNSSL_HIP(attr_enc);                                                                                            \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(sn_encoder_mfma_kernel<KP>, dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, x_sc, x_sf, \
                        x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);                         \
   } while (0)
@@ -1507,9 +1506,8 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   const size_t lds = (size_t)(NG * 1024 + 4 * H + (256 + 4 * (256 >> lg)) * 100) * sizeof(float);
 #define FNSSL_SN_FCONV(P)                                                                                         \
   if (mfma) {                                                                                                     \
-    static const hipError_t attr_fc = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_fconv_mfma_kernel<P>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    FNSSL_HIP(attr_fc);                                                                                           \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_fconv_mfma_kernel<P>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     const long long cus = fnssl::device_cus();                                                                    \
     hipLaunchKernelGGL(sn_fconv_mfma_kernel<P>, dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(1024), lds, s, *x, nt, nf, \
                        lg, nframes, nblk, *w, residual, out, o_sb, o_st, o_sf);                                   \
@@ -1548,9 +1546,8 @@ int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_s
     const size_t lds = (size_t)((nf / 16) * (nf / 16) * 256 + 16 * 256 + 3 * H + 16 + nf + 2 * 256 * 8) * sizeof(float);
 #define FNSSL_SN_FULL(NFV)                                                                                         \
   do {                                                                                                             \
-    static const hipError_t attr_fl = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_full_mfma_kernel<NFV, 0>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-    FNSSL_HIP(attr_fl);                                                                                            \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_full_mfma_kernel<NFV, 0>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
     hipLaunchKernelGGL((sn_full_mfma_kernel<NFV, 0>), dim3(grid), dim3(1024), lds, s, *x, nt, nframes, nblk, *w, residual, \
                        out, o_sb, o_st, o_sf);                                                                     \
   } while (0)
@@ -1598,9 +1595,8 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
     if (mfma) {
       const unsigned nwg = mfma_grid(npts, 1, 16);
       const size_t lds = (size_t)H * 2 * E * sizeof(float);
-      static const hipError_t attr_in = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_in_mfma_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      FNSSL_HIP(attr_in);
+      FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_in_mfma_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(sn_mamba_in_mfma_kernel, dim3(nwg), dim3(1024), lds, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
                          w->winT, m.xz);
     } else {
@@ -1638,9 +1634,8 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
       fnssl::TimedLaunch tl("sn_mamba_out", s, 2.0 * nout * E * H);
       if (mfma) {
         const size_t lds = (size_t)E * H * sizeof(float);
-        static const hipError_t attr_out = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        FNSSL_HIP(attr_out);
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(sn_mamba_out_mfma_kernel, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt, nt2, nf,
                            time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
       } else {
@@ -1664,9 +1659,8 @@ int fnssl_sn_head(const fnssl_btf_view* x, int nb, int nt2, int nfc, const float
   fnssl::TimedLaunch tl("sn_head", s, 2.0 * npts * 16 * (DO * H + DO * DO));
   if (!getenv("FNSSL_SN_SCALAR")) {
     const size_t lds = (size_t)(16 * 6 * 256 + 256) * sizeof(float);
-    static const hipError_t attr_head = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_head_mfma_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    FNSSL_HIP(attr_head);
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_head_mfma_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(sn_head_mfma_kernel, dim3(mfma_grid(npts, 1)), dim3(512), lds, s, *x, nt2, nfc, npts, wfiP, bfiP, wdT,
                        bd, out);
   } else {

@@ -144,18 +144,37 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
     const unsigned oa = tt * sda;
 
     // ---- phase A: gate gradients of every hidden slice ---------------------------------------
-    for (int sl = 0; sl < NSL; ++sl) {
+    // the 7-9 operand loads of slice sl + 1 are requested before the arithmetic and the 5 stores of slice sl (rolled
+    // loop: the compiler does not move them across the back edge, and every slice started with a memory round trip)
+    struct SliceIn {
+      v4f ig, fg, gg, og, ct, cp, dh, dhc, dc;
+    };
+    auto load_slice = [&](int sl, SliceIn& in) {
       const int s = SPLIT > 1 ? part * NSL + sl : sl;
       const unsigned rb = (tt * NS + s) * (kReserveRecs * 1024);
-      const v4f ig = bld4(rres, vlane, rb), fg = bld4(rres, vlane, rb + 1024);
-      const v4f gg = bld4(rres, vlane, rb + 2048), og = bld4(rres, vlane, rb + 3072);
-      const v4f ct = bld4(rres, vlane, rb + 4096);
-      v4f cp = zero4, dh = bld4(rdh, vdh, tt * sdh + 64 * s), dc = zero4;
-      if (has_prev) cp = bld4(rres, vlane, (tp * NS + s) * (kReserveRecs * 1024) + 4096);
+      in.ig = bld4(rres, vlane, rb);
+      in.fg = bld4(rres, vlane, rb + 1024);
+      in.gg = bld4(rres, vlane, rb + 2048);
+      in.og = bld4(rres, vlane, rb + 3072);
+      in.ct = bld4(rres, vlane, rb + 4096);
+      in.dh = bld4(rdh, vdh, tt * sdh + 64 * s);
+      in.cp = zero4;
+      in.dhc = zero4;
+      in.dc = zero4;
+      if (has_prev) in.cp = bld4(rres, vlane, (tp * NS + s) * (kReserveRecs * 1024) + 4096);
       if (step > 0) {
-        dh += bld4(rsc, vlane, s * 1024);
-        dc = bld4(rsc, vlane, (NS + s) * 1024);
+        in.dhc = bld4(rsc, vlane, s * 1024);
+        in.dc = bld4(rsc, vlane, (NS + s) * 1024);
       }
+    };
+    SliceIn nxt;
+    load_slice(0, nxt);
+    for (int sl = 0; sl < NSL; ++sl) {
+      const int s = SPLIT > 1 ? part * NSL + sl : sl;
+      const SliceIn in = nxt;
+      if (sl + 1 < NSL) load_slice(sl + 1, nxt);
+      const v4f ig = in.ig, fg = in.fg, gg = in.gg, og = in.og, ct = in.ct, cp = in.cp;
+      v4f dh = in.dh + in.dhc, dc = in.dc;
       const v4f tc = tanh4(ct);
       const v4f one = v4f{1.f, 1.f, 1.f, 1.f};
       dc += dh * og * (one - tc * tc);

@@ -1105,3 +1105,24 @@ def test_conv3x3_bf16x_random_shapes_against_first_bf16_kernel(dev):
         if got.numel():
             err = (got - ref).abs().max().item()
             assert err <= 3e-5 * max(1.0, ref.abs().max().item()), (it, ca, cb, cout, nb, nf, nt, pool, act, err)
+
+
+def test_timing_select_brackets_one_kernel_name(dev):
+    """fnssl_timing_select: with a name selected only launches of that kernel are bracketed (what bench.py does inside
+    its timed region); None restores all."""
+    from fnssl import ops
+    x = to_dev(rs_randn(5900, (2, 3, 24, 128)), dev)
+    ops.timing_collect()
+    ops.timing_select("avgpool_time")
+    ops.timing_enable(True)
+    ops.avgpool_time(x, 3)
+    ops.nchw_to_seq(to_dev(rs_randn(5901, (1, 4, 8, 6)), dev))
+    ops.timing_enable(False)
+    got = ops.timing_collect()
+    assert set(got) == {"avgpool_time"} and got["avgpool_time"]["count"] == 1
+    ops.timing_select(None)
+    ops.timing_enable(True)
+    ops.avgpool_time(x, 3)
+    ops.nchw_to_seq(to_dev(rs_randn(5901, (1, 4, 8, 6)), dev))
+    ops.timing_enable(False)
+    assert set(ops.timing_collect()) == {"avgpool_time", "nchw_to_seq"}

@@ -281,6 +281,12 @@ class IPDnet(nn.Module):
         self.cnn_inp_dim = hidden_size + input_size
         self.conv = CausCnnBlock(inp_dim=self.cnn_inp_dim, out_dim=self.cnn_out_dim)
         self.n = n_seg
+        self._side = None                                           # streams of the two half-batches (bf16 wide path)
+
+    def _two_streams(self, nb):
+        """Two half-batches on two streams: the wide bf16 path at a batch whose launches leave partial rounds
+        (``FNSSL_IPDNET_ONE_STREAM=1`` keeps a single stream)."""
+        return (_is_bf16(self) and self.block_1._wide() and nb >= 8 and not os.environ.get("FNSSL_IPDNET_ONE_STREAM"))
 
     @ops.on_device
     def forward(self, x, offline_inference=False):
@@ -303,10 +309,34 @@ class IPDnet(nn.Module):
             nb, nt = nb * nseg, self.n
         xs = ops.nchw_to_seq(x)                                     # [nb, nt, nf, C]  (:93)
         xp = _pad_channels(xs, _ceil16(nc)) if _is_bf16(self) else xs   # bf16 kernels read whole 16-channel blocks
-        y = self.block_1.run(None, xp)
-        y = self.block_2.run(y, xp)                                 # logical [nb, nt, nf, Hn], stored [nb, nf, nt, Hn]
-        xc = xp if _is_bf16(self) else xp[..., :nc]               # (bf16: the padded channels meet zero weights)
-        c = self.conv.run(y.permute(0, 2, 1, 3), xc.permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
+
+        def trunk(xq):
+            y = self.block_1.run(None, xq)
+            y = self.block_2.run(y, xq)                             # logical [nb, nt, nf, Hn], stored [nb, nf, nt, Hn]
+            xc = xq if _is_bf16(self) else xq[..., :nc]           # (bf16: the padded channels meet zero weights)
+            return self.conv.run(y.permute(0, 2, 1, 3), xc.permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
+
+        if self._two_streams(nb):
+            # Utterances are independent, and the layers' launches do not divide the chip evenly (config 3: 600
+            # full-band workgroups on 256 CUs = 2.34 rounds run as 3; 256 narrow-band workgroups = exactly one): the two
+            # halves of the batch go down two streams, so one half's partial round shares the chip with the other
+            # half's kernels instead of leaving CUs idle.  Same kernels, same results (batch slices).
+            cur = torch.cuda.current_stream()
+            ns = max(2, min(int(os.environ.get("FNSSL_IPDNET_STREAMS", "2")), nb))
+            if self._side is None or len(self._side) != ns:
+                self._side = tuple(torch.cuda.Stream(device=x.device) for _ in range(ns))
+            bounds = [nb * i // ns for i in range(ns + 1)]
+            parts = []
+            for st, lo, hi in zip(self._side, bounds[:-1], bounds[1:]):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    parts.append(trunk(xp[lo:hi]))
+            for st, cpart in zip(self._side, parts):
+                cur.wait_stream(st)
+                cpart.record_stream(cur)
+            c = torch.cat(parts, dim=0)
+        else:
+            c = trunk(xp)
         nt2 = nt // 12
         c = c[..., :self.cnn_out_dim].permute(0, 2, 1, 3)           # = conv(x).permute(0,3,2,1)  (:113)
         c = c.reshape(nb, nt2, nf, 2, -1).permute(0, 1, 3, 2, 4)

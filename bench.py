@@ -251,8 +251,13 @@ class IpdnetForward:
     def roofline(self, kern):
         if self.fp32:
             return kernel_roof(kern, "lstm_h256", "narrow-band LSTM H=256 (fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS)
-        return kernel_roof(kern, "lstm_h256", "lstm_bf16 kernel H=256 (narrow-band LSTM, bf16 MFMA operands)",
-                           PEAK_BF16_MFMA_TFLOPS)
+        r = kernel_roof(kern, "lstm_h256", "lstm_bf16 kernel H=256 (narrow-band LSTM, bf16 MFMA operands)",
+                        PEAK_BF16_MFMA_TFLOPS)
+        if r is not None and not os.environ.get("FNSSL_IPDNET_ONE_STREAM"):
+            r["note"] = ("the two half-batches run on two streams: a launch shares the chip with the other stream's "
+                         "kernels, so its duration is not exclusive; FNSSL_IPDNET_ONE_STREAM=1 measures the kernel "
+                         "alone (0.29 of the roof, profiles/r02/l_bench_c3_frontend_rows.json)")
+        return r
 
     def cpu_baseline(self):
         from oracle import fnssl_oracle as O

@@ -31,7 +31,13 @@ if _PKG not in sys.path:
 
 from fnssl import ops                                               # noqa: E402
 from fnssl import spatialnet as sn                                  # noqa: E402
-from Model import _param_key, _require_eval                         # noqa: E402
+from Model import _is_bf16, _param_key, _require_eval               # noqa: E402
+
+
+def _prec(module) -> int:
+    """After ``module.bfloat16()`` the dense products (encoder, grouped f-conv, Mamba in / x / out projections) run on
+    bf16 MFMAs with fp32 accumulation and fp32 tensors — BASELINE config 5 as written (include/fnssl.h)."""
+    return sn.BF16 if _is_bf16(module) else sn.FP32
 
 
 def _sd(module, prefix=""):
@@ -122,7 +128,7 @@ class CausalConv1d(nn.Conv1d):
             if id(self) in state:
                 st_in = state[id(self)].float().contiguous().unsqueeze(2)
             st_out = torch.empty((x.shape[0], x.shape[1], 1, 4), dtype=torch.float32, device=x.device)
-        y = sn.encoder(x4, wT, b, st_in, st_out)                      # logical [B, 1, T, 96]
+        y = sn.encoder(x4, wT, b, st_in, st_out, precision=_prec(self))   # logical [B, 1, T, 96]
         if state is not None:
             state[id(self)] = st_out[:, :, 0, :]
         return y[:, 0].transpose(1, 2).to(x.dtype)
@@ -209,14 +215,14 @@ class SpatialNetLayer(nn.Module):
     # the three branches on their own (WITHOUT the residual), as the reference's private helpers return them
     def _fconv(self, ml: nn.ModuleList, x: torch.Tensor) -> torch.Tensor:
         w = self._packed(x.device)
-        return sn.fconv(x.float(), w[0] if ml is self.fconv1 else w[2], residual=False).to(x.dtype)
+        return sn.fconv(x.float(), w[0] if ml is self.fconv1 else w[2], residual=False, precision=_prec(self)).to(x.dtype)
 
     def _full(self, x: torch.Tensor) -> torch.Tensor:
         return sn.full(x.float(), self._packed(x.device)[1], residual=False).to(x.dtype)
 
     def _mamba(self, x: torch.Tensor, mamba: Mamba, norm: nn.Module, dropout: nn.Module, inference: bool = False):
         w = self._packed(x.device)
-        return sn.mamba(x.float(), w[3] if mamba is self.mhsa else w[4], residual=False).to(x.dtype)
+        return sn.mamba(x.float(), w[3] if mamba is self.mhsa else w[4], residual=False, precision=_prec(self)).to(x.dtype)
 
     @ops.on_device
     def forward(self, x: torch.Tensor, att_mask: Optional[torch.Tensor] = None, chunkwise_recurrent: bool = True,
@@ -225,11 +231,12 @@ class SpatialNetLayer(nn.Module):
         _require_eval(self)
         f1, fu, f2, m0, m1 = self._packed(x.device)
         y = x.float()
-        y = sn.fconv(y, f1, pool=2 if self.is_first else 1)           # x + fconv1, fre_compress_first
+        pr = _prec(self)
+        y = sn.fconv(y, f1, pool=2 if self.is_first else 1, precision=pr)   # x + fconv1, fre_compress_first
         y = sn.full(y, fu, out=y)
-        y = sn.fconv(y, f2, pool=8 if self.is_first else 1)           # x + fconv2, fre_compress_second
-        y = sn.mamba(y, m0, out=y)
-        y = sn.mamba(y, m1, out=y)
+        y = sn.fconv(y, f2, pool=8 if self.is_first else 1, precision=pr)   # x + fconv2, fre_compress_second
+        y = sn.mamba(y, m0, out=y, precision=pr)
+        y = sn.mamba(y, m1, out=y, precision=pr)
         return y.to(x.dtype), None
 
     def extra_repr(self) -> str:
@@ -277,7 +284,8 @@ class OnlineSpatialNet(nn.Module):
     def device_net(self, device) -> "sn.DeviceSpatialNet":
         key = (_param_key(self), str(device))
         if self._dn is None or self._dn_key != key:
-            self._dn = sn.DeviceSpatialNet(self.state_dict(), device, time_ratio=self.time_compression_ratio)
+            self._dn = sn.DeviceSpatialNet(self.state_dict(), device, time_ratio=self.time_compression_ratio,
+                                           precision=_prec(self))
             self._dn_key = key
         return self._dn
 

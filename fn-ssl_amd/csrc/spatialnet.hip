@@ -365,63 +365,113 @@ sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const floa
 //   D[output 4*og + r][point n]: a lane stores 4 consecutive outputs of its point (16 bytes).
 // ---------------------------------------------------------------------------------------------------------
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
+typedef __bf16 v4bf_t __attribute__((ext_vector_type(4)));
+
+// FNSSL_PRECISION_BF16 (BF = true): the same kernels with both operands of the product rounded to bf16 (round to
+// nearest even) as they enter the matrix pipe, fp32 accumulation, fp32 tensors — one v_mfma_f32_16x16x32_bf16 takes the
+// place of eight v_mfma_f32_16x16x4_f32.  The lane's K/4 channels stay where they are: MFMA m consumes the lane's
+// values 8 m .. 8 m + 7 (zero past K/4), and the weight image holds the matching 8 weights per (lane, m) as one
+// 16-byte item, so an output tile costs ceil(K/32) LDS reads and MFMAs instead of K/16 reads and K/4 MFMAs.
+__device__ __forceinline__ v8bf_t pack8_bf16(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                             float a7) {
+  const v4f_t lo = {a0, a1, a2, a3}, hi = {a4, a5, a6, a7};
+  const v4bf_t l = __builtin_convertvector(lo, v4bf_t), h = __builtin_convertvector(hi, v4bf_t);
+  return __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// 1-KiB items (64 lanes x 16 bytes) of one 16-output tile in the LDS weight image
+template <int K, bool BF>
+__host__ __device__ constexpr int w_items() {
+  return BF ? (K / 4 + 7) / 8 : K / 16;
+}
+template <int K, int N, bool BF>
+__host__ __device__ constexpr int w_lds_floats() {
+  return (N / 16) * w_items<K, BF>() * 256;
+}
 
 // sk / so: element strides of the input (k) and output (o) index in the source matrix.  BD = threads of the workgroup
 // (compile-time: the trips are fully unrolled, so all of a thread's loads — 4 per 16-byte item, up to 12 items — are in
 // flight together.  Rolled, a trip was one L2 round trip and the 147 KB image of in_proj took 21 us per workgroup: half
 // of a small launch.)  LDS order, one conflict-free 16-byte write per item; an item's 4 values are 4 consecutive k of one
 // output, and the 16 lanes of an output tile read 64 contiguous bytes of each source row (the matrix is L2-resident).
-template <int K, int N, int BD>
+template <int K, int N, int BD, bool BF = false>
 __device__ __forceinline__ void fill_w_lds_strided(float* lds, const float* __restrict__ w, int sk, int so, int kvalid,
                                                    int nvalid) {
-  constexpr int KQ = K / 4, G = KQ / 4, TOTAL = (N / 16) * G * 64, TRIPS = (TOTAL + BD - 1) / BD;
   static_assert(K % 16 == 0 && N % 16 == 0, "whole k-step groups and output tiles");
-  float v[TRIPS][4];
+  constexpr int KQ = K / 4, G = w_items<K, BF>(), TOTAL = (N / 16) * G * 64, TRIPS = (TOTAL + BD - 1) / BD;
+  constexpr int PER = BF ? 8 : 4;                                    // k values of one item
+  float v[TRIPS][PER];
 #pragma unroll
   for (int u = 0; u < TRIPS; ++u) {
     const int idx = (int)threadIdx.x + u * BD;
     const int lane = idx & 63, g = (idx >> 6) % G, j = (idx >> 6) / G;
-    const int k0 = (lane >> 4) * KQ + 4 * g, o = 16 * j + (lane & 15);
+    const int kl = PER * g, k0 = (lane >> 4) * KQ + kl, o = 16 * j + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      v[u][i] = (idx < TOTAL && k0 + i < kvalid && o < nvalid) ? w[(long long)(k0 + i) * sk + (long long)o * so] : 0.f;
+    for (int i = 0; i < PER; ++i)
+      v[u][i] = (idx < TOTAL && kl + i < KQ && k0 + i < kvalid && o < nvalid) ? w[(long long)(k0 + i) * sk + (long long)o * so]
+                                                                             : 0.f;
   }
 #pragma unroll
   for (int u = 0; u < TRIPS; ++u) {
     const int idx = (int)threadIdx.x + u * BD;
-    if (idx < TOTAL) *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+    if (idx < TOTAL) {
+      if constexpr (BF)
+        *reinterpret_cast<v8bf_t*>(lds + idx * 4) =
+            pack8_bf16(v[u][0], v[u][1], v[u][2], v[u][3], v[u][PER - 4], v[u][PER - 3], v[u][PER - 2], v[u][PER - 1]);
+      else
+        *reinterpret_cast<float4*>(lds + idx * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+    }
   }
 }
 
-template <int K, int N, int BD>
+template <int K, int N, int BD, bool BF = false>
 __device__ __forceinline__ void fill_w_lds(float* lds, const float* __restrict__ wT, int ldw, int kvalid, int nvalid) {
-  fill_w_lds_strided<K, N, BD>(lds, wT, ldw, 1, kvalid, nvalid);
+  fill_w_lds_strided<K, N, BD, BF>(lds, wT, ldw, 1, kvalid, nvalid);
 }
 
 // acc[jj] += W-tile (j0 + jj) . x   for NJ output tiles at once (independent accumulators keep the pipe busy)
-template <int K, int NJ>
+template <int K, int NJ, bool BF = false>
 __device__ __forceinline__ void mfma_tiles(const float (&a)[K / 4], const float* ldsw_lane, int j0, v4f_t (&acc)[NJ]) {
-  constexpr int G = K / 16;
+  constexpr int G = w_items<K, BF>();
+  if constexpr (BF) {
+    constexpr int KQ = K / 4;
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    v4f_t w[NJ];
+    for (int m = 0; m < G; ++m) {
+      float t[8];
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) w[jj] = *reinterpret_cast<const v4f_t*>(ldsw_lane + ((j0 + jj) * G + g) * 256);
+      for (int e = 0; e < 8; ++e) t[e] = 8 * m + e < KQ ? a[8 * m + e < KQ ? 8 * m + e : 0] : 0.f;
+      const v8bf_t b = pack8_bf16(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int jj = 0; jj < NJ; ++jj) {
+        const v8bf_t w = *reinterpret_cast<const v8bf_t*>(ldsw_lane + ((j0 + jj) * G + m) * 256);
+        acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc[jj], 0, 0, 0);
+      }
+    }
+  } else {
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][i], a[4 * g + i], acc[jj], 0, 0, 0);
-    // keep the scheduler from hoisting every group's LDS reads to the top (it spills the operand registers)
-    if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < G; ++g) {
+      v4f_t w[NJ];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) w[jj] = *reinterpret_cast<const v4f_t*>(ldsw_lane + ((j0 + jj) * G + g) * 256);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+          acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[jj][i], a[4 * g + i], acc[jj], 0, 0, 0);
+      // keep the scheduler from hoisting every group's LDS reads to the top (it spills the operand registers)
+      if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
 // Mamba, phase 1 on the matrix pipe: xz[p, 0:384] = in_proj(LayerNorm(x_p)),  p = (b*nf + f)*nt + t
+template <bool BF>
 __global__ void __launch_bounds__(1024)
 sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const float* __restrict__ ln_w,
                         const float* __restrict__ ln_b, const float* __restrict__ winT, float* __restrict__ xz) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 24 tiles x 6 groups x 1 KiB
-  fill_w_lds<H, 2 * E, 1024>(ldsw, winT, 2 * E, H, 2 * E);
+  fill_w_lds<H, 2 * E, 1024, BF>(ldsw, winT, 2 * E, H, 2 * E);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -472,7 +522,7 @@ sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const
       v4f_t acc[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-      mfma_tiles<H, 4>(a, ldsw_lane, j0, acc);
+      mfma_tiles<H, 4, BF>(a, ldsw_lane, j0, acc);
       if (p < npts) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -488,27 +538,39 @@ sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const
 // D[4 q + r][n] of the group's product, so residual and pooling never leave the lane.  LayerNorm'd rows go to an LDS
 // image [frame][bin + 2 (zero rows either side)][100] once; per group the lane gathers its 16 of the 64 (60 used)
 // patch values (tap, channel) = the B operand, the group's [16 x 64] weights are A operands resident in LDS.
-template <int POOL>
+template <int POOL, bool BF>
 __global__ void __launch_bounds__(1024)
 sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nframes, long long nblk, fnssl_sn_fconv_w w,
                      int residual, float* out, long long o_sb, long long o_st, long long o_sf) {
   constexpr int YS = 100;                                          // row stride of the LDS image (floats)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldw = lds;                                                // 8 groups x 4 k-groups x 1 KiB
-  float* par = lds + NG * 1024;                                    // ln_w | ln_b | bias | prelu (L1 latency per use otherwise)
+  constexpr int GW = w_lds_floats<64, 16, BF>();                   // a group's image: 4 (bf16: 2) items of 1 KiB
+  float* ldw = lds;                                                // 8 groups
+  float* par = lds + NG * GW;                                      // ln_w | ln_b | bias | prelu (L1 latency per use otherwise)
   float* ytile = par + 4 * H;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int g = 0; g < NG; g += 4) {                                  // 4 groups x 256 items = one item per thread
-    const int gg = g + (tid >> 8);
-    const int idx = tid & 255;
-    const int lane = idx & 63, kg = idx >> 6;
-    const int k0 = (lane >> 4) * 16 + 4 * kg, o = lane & 15;
+  if constexpr (BF) {                                                // 8 groups x 2 items x 64 lanes = one item per thread
+    const int gg = tid >> 7, idx = tid & 127;
+    const int ln = idx & 63, m = idx >> 6;
+    const int k0 = (ln >> 4) * 16 + 8 * m, o = ln & 15;
     const float* wg = w.wT + gg * (KF * CG * CG);
-    float v[4];
+    float v[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (k0 + i < KF * CG && o < CG) ? wg[(k0 + i) * CG + o] : 0.f;
-    *reinterpret_cast<float4*>(ldw + gg * 1024 + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < KF * CG && o < CG) ? wg[(k0 + i) * CG + o] : 0.f;
+    *reinterpret_cast<v8bf_t*>(ldw + gg * GW + idx * 4) = pack8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int g = 0; g < NG; g += 4) {                                // 4 groups x 256 items = one item per thread
+      const int gg = g + (tid >> 8);
+      const int idx = tid & 255;
+      const int ln = idx & 63, kg = idx >> 6;
+      const int k0 = (ln >> 4) * 16 + 4 * kg, o = ln & 15;
+      const float* wg = w.wT + gg * (KF * CG * CG);
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (k0 + i < KF * CG && o < CG) ? wg[(k0 + i) * CG + o] : 0.f;
+      *reinterpret_cast<float4*>(ldw + gg * GW + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
   if (tid < 4 * H) {
     const float* src = tid < H ? w.ln_w : (tid < 2 * H ? w.ln_b : (tid < 3 * H ? w.bias : w.prelu));
@@ -613,7 +675,7 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
         a[4 * j + 3] = v.w;
       }
       v4f_t acc[1] = {v4f_t{0.f, 0.f, 0.f, 0.f}};
-      mfma_tiles<64, 1>(a, ldw_lane + g * 1024, 0, acc);
+      mfma_tiles<64, 1, BF>(a, ldw_lane + g * GW, 0, acc);
       if (q < 3) {
         const float4 bv = *reinterpret_cast<const float4*>(par + 2 * H + CG * g + 4 * q);
         const float4 pv = *reinterpret_cast<const float4*>(par + 3 * H + CG * g + 4 * q);
@@ -877,12 +939,13 @@ sn_mamba_conv_kernel(const float* __restrict__ xz, int nt, long long npts, const
 }
 
 // Mamba, phase 2b on the matrix pipe: dbl[p, 0:40] = x_proj(u_p)
+template <bool BF>
 __global__ void __launch_bounds__(512)
 sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const float* __restrict__ wxT,
                            float* __restrict__ dbl) {
   constexpr int XN = 48;                                           // 40 outputs in 3 tiles
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 3 tiles x 12 groups x 1 KiB
-  fill_w_lds<E, XN, 512>(ldsw, wxT, XP, E, XP);
+  fill_w_lds<E, XN, 512, BF>(ldsw, wxT, XP, E, XP);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -903,7 +966,7 @@ sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const fl
     v4f_t acc[3];
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-    mfma_tiles<E, 3>(a, ldsw_lane, 0, acc);
+    mfma_tiles<E, 3, BF>(a, ldsw_lane, 0, acc);
     if (p < npts) {
       float* dst = dbl + p * XP + 4 * kq;
 #pragma unroll
@@ -915,12 +978,13 @@ sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const fl
 }
 
 // Mamba, phase 4 on the matrix pipe: out = pool_T(x) + out_proj(pool_T(y)),  p = s*nt2 + t2
+template <bool BF>
 __global__ void __launch_bounds__(512)
 sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, int nt2, int nf, int tp,
                          long long nout, const float* __restrict__ woT, int residual, float* out, long long o_sb,
                          long long o_st, long long o_sf) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x 12 groups x 1 KiB
-  fill_w_lds<E, H, 512>(ldsw, woT, H, E, H);
+  fill_w_lds<E, H, 512, BF>(ldsw, woT, H, E, H);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -958,7 +1022,7 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
       v4f_t acc[3];
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-      mfma_tiles<E, 3>(a, ldsw_lane, j0, acc);
+      mfma_tiles<E, 3, BF>(a, ldsw_lane, j0, acc);
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
         float4 o4 = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
@@ -981,14 +1045,14 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
 
 // Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP (80 or 160: KP / 4 a multiple of the 5 taps);
 // p = (b*nf + f)*nt + t
-template <int KP>
+template <int KP, bool BF>
 __global__ void __launch_bounds__(512)
 sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, long long sf, long long st, int cin,
                        int nf, int nt, long long npts, const float* __restrict__ wT, const float* __restrict__ bias,
                        const float* __restrict__ state_in, float* __restrict__ out, long long o_sb, long long o_st,
                        long long o_sf) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x KP/16 groups x 1 KiB
-  fill_w_lds<KP, H, 512>(ldsw, wT, H, cin * KE, H);
+  fill_w_lds<KP, H, 512, BF>(ldsw, wT, H, cin * KE, H);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
@@ -1039,7 +1103,7 @@ sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, 
         const float4 bv = *reinterpret_cast<const float4*>(bias + 16 * (j0 + jj) + 4 * kq);
         acc[jj] = v4f_t{bv.x, bv.y, bv.z, bv.w};
       }
-      mfma_tiles<KP, 3>(a, ldsw_lane, j0, acc);
+      mfma_tiles<KP, 3, BF>(a, ldsw_lane, j0, acc);
       if (p < npts) {
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj)
@@ -1422,6 +1486,8 @@ inline MambaWs carve_mamba(float* ws, long long npts) {
 
 // workgroups of the matrix-pipe kernels: 8 waves x one 16-point tile each per pass, per_cu workgroups per CU (what
 // the kernel's LDS weight image allows)
+static bool precision_ok(int p) { return p == FNSSL_PRECISION_FP32 || p == FNSSL_PRECISION_BF16; }
+
 static unsigned mfma_grid(long long npts, int per_cu, int waves = 8) {
   const long long wgs = ((npts + 15) / 16 + waves - 1) / waves;
   const long long cap = (long long)fnssl::device_cus() * per_cu;
@@ -1445,8 +1511,9 @@ int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, co
 
 int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x_sf, long long x_st, int nb, int cin,
                      int nf, int nt, const float* wT, const float* bias, const float* state_in, float* state_out,
-                     float* out, long long o_sb, long long o_st, long long o_sf, void* stream) {
+                     float* out, long long o_sb, long long o_st, long long o_sf, int precision, void* stream) {
   FNSSL_REQUIRE(x && wT && bias, "sn_encoder: null pointer");
+  FNSSL_REQUIRE(precision_ok(precision), "sn_encoder: precision %d (FNSSL_PRECISION_FP32 or _BF16)", precision);
   FNSSL_REQUIRE(nb > 0 && cin > 0 && nf > 0 && nt > 0, "sn_encoder: empty problem");
   FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_encoder: output must be 16-byte aligned with strides %% 4 == 0");
   const long long npts = (long long)nb * nf * nt;
@@ -1458,19 +1525,23 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
     // the matrix-pipe kernel addresses a (b, f) row's channels and frames with 32-bit element offsets
     const bool off32 = (long double)cin * (x_sc < 0 ? -x_sc : x_sc) + (long double)nt * (x_st < 0 ? -x_st : x_st) < 2.0e9L &&
                        (long double)cin * nf * (KE - 1) + nt < 2.0e9L;
-    if (!getenv("FNSSL_SN_SCALAR") && kk <= 160 && off32) {
-#define FNSSL_SN_ENC(KP)                                                                                            \
+    const bool bf = precision == FNSSL_PRECISION_BF16;
+    FNSSL_REQUIRE(!bf || (kk <= 160 && off32), "sn_encoder: FNSSL_PRECISION_BF16 needs cin * 5 <= 160 (cin %d) and 32-bit offsets",
+                  cin);
+    if ((bf || !getenv("FNSSL_SN_SCALAR")) && kk <= 160 && off32) {
+#define FNSSL_SN_ENC(KP, BF)                                                                                        \
   do {                                                                                                              \
-    const size_t lds = (size_t)KP * H * sizeof(float);                                                              \
-    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(sn_encoder_mfma_kernel<KP>, dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, x_sc, x_sf, \
-                       x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);                         \
+    const size_t lds = (size_t)w_lds_floats<KP, H, BF>() * sizeof(float);                                           \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP, BF>),                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    hipLaunchKernelGGL((sn_encoder_mfma_kernel<KP, BF>), dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, x_sc, \
+                       x_sf, x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);                   \
   } while (0)
-      if (kk <= 80)
-        FNSSL_SN_ENC(80);
-      else
-        FNSSL_SN_ENC(160);
+      if (kk <= 80) {
+        if (bf) FNSSL_SN_ENC(80, true); else FNSSL_SN_ENC(80, false);
+      } else {
+        if (bf) FNSSL_SN_ENC(160, true); else FNSSL_SN_ENC(160, false);
+      }
 #undef FNSSL_SN_ENC
     } else {
       hipLaunchKernelGGL(sn_encoder_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, x, x_sb, x_sc, x_sf, x_st, cin, nf, nt,
@@ -1488,8 +1559,9 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
 }
 
 int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_fconv_w* w, int residual, int pool,
-                   float* out, long long o_sb, long long o_st, long long o_sf, void* stream) {
+                   float* out, long long o_sb, long long o_st, long long o_sf, int precision, void* stream) {
   FNSSL_REQUIRE(view_ok(x), "sn_fconv: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(precision_ok(precision), "sn_fconv: precision %d (FNSSL_PRECISION_FP32 or _BF16)", precision);
   FNSSL_REQUIRE(w && w->ln_w && w->ln_b && w->wT && w->bias && w->prelu, "sn_fconv: null weights");
   FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_fconv: output must be 16-byte aligned with strides %% 4 == 0");
   FNSSL_REQUIRE(nb > 0 && nt > 0, "sn_fconv: empty problem");
@@ -1502,15 +1574,22 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl(nf > 128 ? "sn_fconv_f256" : (nf > 16 ? "sn_fconv_f128" : "sn_fconv_f16"), s,
                         2.0 * nframes * nf * H * CG * KF);
-  const bool mfma = !getenv("FNSSL_SN_SCALAR") && nf >= 16;
-  const size_t lds = (size_t)(NG * 1024 + 4 * H + (256 + 4 * (256 >> lg)) * 100) * sizeof(float);
+  const bool bf = precision == FNSSL_PRECISION_BF16;
+  FNSSL_REQUIRE(!bf || nf >= 16, "sn_fconv: FNSSL_PRECISION_BF16 needs nf >= 16, got %d", nf);
+  const bool mfma = (bf || !getenv("FNSSL_SN_SCALAR")) && nf >= 16;
+  const size_t lds = (size_t)(NG * (bf ? w_lds_floats<64, 16, true>() : w_lds_floats<64, 16, false>()) + 4 * H +
+                              (256 + 4 * (256 >> lg)) * 100) * sizeof(float);
+  const long long cus = fnssl::device_cus();
+#define FNSSL_SN_FCONV_M(P, BF)                                                                                   \
+  do {                                                                                                            \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_fconv_mfma_kernel<P, BF>),                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+    hipLaunchKernelGGL((sn_fconv_mfma_kernel<P, BF>), dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(1024), lds, s, *x, \
+                       nt, nf, lg, nframes, nblk, *w, residual, out, o_sb, o_st, o_sf);                           \
+  } while (0)
 #define FNSSL_SN_FCONV(P)                                                                                         \
   if (mfma) {                                                                                                     \
-    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_fconv_mfma_kernel<P>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    const long long cus = fnssl::device_cus();                                                                    \
-    hipLaunchKernelGGL(sn_fconv_mfma_kernel<P>, dim3((unsigned)(nblk < cus ? nblk : cus)), dim3(1024), lds, s, *x, nt, nf, \
-                       lg, nframes, nblk, *w, residual, out, o_sb, o_st, o_sf);                                   \
+    if (bf) FNSSL_SN_FCONV_M(P, true); else FNSSL_SN_FCONV_M(P, false);                                           \
   } else                                                                                                          \
     hipLaunchKernelGGL(sn_fconv_kernel<P>, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, \
                        out, o_sb, o_st, o_sf)
@@ -1522,6 +1601,7 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
     FNSSL_SN_FCONV(8);
   }
 #undef FNSSL_SN_FCONV
+#undef FNSSL_SN_FCONV_M
   FNSSL_CHECK_LAUNCH("sn_fconv_kernel");
   return FNSSL_OK;
 }
@@ -1573,8 +1653,9 @@ size_t fnssl_sn_mamba_workspace_bytes(int nb, int nt, int nf) {
 
 int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_mamba_w* w, int residual,
                    int time_pool, float* conv_state, float* ssm_state, int carry, float* out, long long o_sb,
-                   long long o_st, long long o_sf, void* workspace, size_t workspace_bytes, void* stream) {
+                   long long o_st, long long o_sf, void* workspace, size_t workspace_bytes, int precision, void* stream) {
   FNSSL_REQUIRE(view_ok(x), "sn_mamba: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(precision_ok(precision), "sn_mamba: precision %d (FNSSL_PRECISION_FP32 or _BF16)", precision);
   FNSSL_REQUIRE(w && w->ln_w && w->ln_b && w->winT && w->conv_w && w->conv_b && w->wxT && w->wdt && w->bdt && w->a &&
                     w->d && w->woT, "sn_mamba: null weights");
   FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_mamba: output must be 16-byte aligned with strides %% 4 == 0");
@@ -1589,16 +1670,25 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   FNSSL_REQUIRE(blocks_of(npts) < (1u << 31) && nseq < (1ll << 31), "sn_mamba: too many points");
   const MambaWs m = carve_mamba(static_cast<float*>(workspace), npts);
   hipStream_t s = fnssl::as_stream(stream);
-  const bool mfma = !getenv("FNSSL_SN_SCALAR");   // A/B: the scalar-operand kernels
+  const bool bf = precision == FNSSL_PRECISION_BF16;
+  const bool mfma = bf || !getenv("FNSSL_SN_SCALAR");   // A/B (fp32 only): the scalar-operand kernels
   {
     fnssl::TimedLaunch tl("sn_mamba_in", s, 2.0 * npts * H * 2 * E);
     if (mfma) {
       const unsigned nwg = mfma_grid(npts, 1, 16);
-      const size_t lds = (size_t)H * 2 * E * sizeof(float);
-      FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_in_mfma_kernel),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(sn_mamba_in_mfma_kernel, dim3(nwg), dim3(1024), lds, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
-                         w->winT, m.xz);
+      if (bf) {
+        const size_t lds = (size_t)w_lds_floats<H, 2 * E, true>() * sizeof(float);
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_in_mfma_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(sn_mamba_in_mfma_kernel<true>, dim3(nwg), dim3(1024), lds, s, *x, nt, nf, npts, w->ln_w,
+                           w->ln_b, w->winT, m.xz);
+      } else {
+        const size_t lds = (size_t)w_lds_floats<H, 2 * E, false>() * sizeof(float);
+        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_in_mfma_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(sn_mamba_in_mfma_kernel<false>, dim3(nwg), dim3(1024), lds, s, *x, nt, nf, npts, w->ln_w,
+                           w->ln_b, w->winT, m.xz);
+      }
     } else {
       hipLaunchKernelGGL(sn_mamba_in_kernel, dim3(blocks_of(npts), 4), dim3(256), 0, s, *x, nt, nf, npts, w->ln_w, w->ln_b,
                          w->winT, m.xz);
@@ -1613,8 +1703,14 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
       hipLaunchKernelGGL(sn_mamba_conv_kernel, dim3(blocks_of(nq)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
                          carry ? conv_state : nullptr, m.y);
       FNSSL_CHECK_LAUNCH("sn_mamba_conv_kernel");
-      const size_t lds = (size_t)E * 48 * sizeof(float);
-      hipLaunchKernelGGL(sn_mamba_xproj_mfma_kernel, dim3(mfma_grid(npts, 4)), dim3(512), lds, s, m.y, npts, w->wxT, m.dbl);
+      constexpr size_t lds_bf = (size_t)w_lds_floats<E, 48, true>() * sizeof(float);
+      constexpr size_t lds_f32 = (size_t)w_lds_floats<E, 48, false>() * sizeof(float);
+      if (bf)
+        hipLaunchKernelGGL(sn_mamba_xproj_mfma_kernel<true>, dim3(mfma_grid(npts, 4)), dim3(512), lds_bf, s, m.y, npts,
+                           w->wxT, m.dbl);
+      else
+        hipLaunchKernelGGL(sn_mamba_xproj_mfma_kernel<false>, dim3(mfma_grid(npts, 4)), dim3(512), lds_f32, s, m.y, npts,
+                           w->wxT, m.dbl);
     } else {
       hipLaunchKernelGGL(sn_mamba_xproj_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
                          w->wxT, carry ? conv_state : nullptr, m.dbl);
@@ -1633,11 +1729,17 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
     if (nout > 0) {
       fnssl::TimedLaunch tl("sn_mamba_out", s, 2.0 * nout * E * H);
       if (mfma) {
-        const size_t lds = (size_t)E * H * sizeof(float);
-        FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(sn_mamba_out_mfma_kernel, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt, nt2, nf,
-                           time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
+        if (bf) {
+          const size_t lds = (size_t)w_lds_floats<E, H, true>() * sizeof(float);
+          hipLaunchKernelGGL(sn_mamba_out_mfma_kernel<true>, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt, nt2,
+                             nf, time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
+        } else {
+          const size_t lds = (size_t)w_lds_floats<E, H, false>() * sizeof(float);
+          FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(sn_mamba_out_mfma_kernel<false>, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt,
+                             nt2, nf, time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
+        }
       } else {
         hipLaunchKernelGGL(sn_mamba_out_kernel, dim3(blocks_of(nout), 2), dim3(256), 0, s, m.y, *x, nt, nt2, nf, time_pool,
                            nout, w->woT, residual, out, o_sb, o_st, o_sf);
@@ -1696,6 +1798,8 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
   FNSSL_REQUIRE(net->num_layers >= 1 && net->num_layers <= FNSSL_SN_MAX_LAYERS, "sn_forward: 1..%d layers", FNSSL_SN_MAX_LAYERS);
   FNSSL_REQUIRE(net->time_ratio >= 1 && net->time_ratio <= 16, "sn_forward: time_ratio in [1, 16]");
   FNSSL_REQUIRE(nb > 0 && nt > 0, "sn_forward: empty problem");
+  FNSSL_REQUIRE(precision_ok(net->precision), "sn_forward: net->precision %d (FNSSL_PRECISION_FP32 or _BF16)", net->precision);
+  const int prec = net->precision;
   FNSSL_REQUIRE(nf == 128 || nf == 256, "sn_forward: num_freqs must be 128 or 256 (got %d)", nf);
   FNSSL_REQUIRE(!carry || state, "sn_forward: carry needs the state buffer");
   FNSSL_REQUIRE(!state || nt % net->time_ratio == 0, "sn_forward: streaming chunks must be multiples of %d frames", net->time_ratio);
@@ -1732,31 +1836,31 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
   long long sb, st, sf, sb2, st2, sf2;
   strides(nf, sb, st, sf, nt);
   FNSSL_SN_TRY(fnssl_sn_encoder(x, x_sb, x_sc, x_sf, x_st, nb, net->dim_input, nf, nt, net->enc_wT, net->enc_b,
-                                carry ? st_enc : nullptr, st_enc, a0, sb, st, sf, stream));
+                                carry ? st_enc : nullptr, st_enc, a0, sb, st, sf, prec, stream));
   const fnssl_sn_layer* L = &net->layers[0];
   fnssl_btf_view v0 = {a0, sb, st, sf};
   strides(nf / 2, sb2, st2, sf2, nt);
-  FNSSL_SN_TRY(fnssl_sn_fconv(&v0, nb, nt, nf, &L->fconv1, 1, 2, a1, sb2, st2, sf2, stream));
+  FNSSL_SN_TRY(fnssl_sn_fconv(&v0, nb, nt, nf, &L->fconv1, 1, 2, a1, sb2, st2, sf2, prec, stream));
   fnssl_btf_view v1 = {a1, sb2, st2, sf2};
   FNSSL_SN_TRY(fnssl_sn_full(&v1, nb, nt, nf / 2, &L->full, 1, a1, sb2, st2, sf2, stream));
   strides(nfc, sb, st, sf, nt);
-  FNSSL_SN_TRY(fnssl_sn_fconv(&v1, nb, nt, nf / 2, &L->fconv2, 1, 8, a2, sb, st, sf, stream));
+  FNSSL_SN_TRY(fnssl_sn_fconv(&v1, nb, nt, nf / 2, &L->fconv2, 1, 8, a2, sb, st, sf, prec, stream));
   fnssl_btf_view v2 = {a2, sb, st, sf};
   FNSSL_SN_TRY(fnssl_sn_mamba(&v2, nb, nt, nfc, &L->mamba[0], 1, 1, conv_st(0, 0), ssm_st(0, 0), carry, a2, sb, st, sf,
-                              mws, mws_bytes, stream));
+                              mws, mws_bytes, prec, stream));
   if (nt2 == 0) return FNSSL_OK;                 // fewer frames than one pooled step: empty output (AvgPool floor)
   strides(nfc, sb2, st2, sf2, nt2);
   FNSSL_SN_TRY(fnssl_sn_mamba(&v2, nb, nt, nfc, &L->mamba[1], 1, ratio, conv_st(0, 1), ssm_st(0, 1), carry, a3, sb2, st2,
-                              sf2, mws, mws_bytes, stream));
+                              sf2, mws, mws_bytes, prec, stream));
   fnssl_btf_view v3 = {a3, sb2, st2, sf2};
   for (int l = 1; l < net->num_layers; ++l) {
     L = &net->layers[l];
-    FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv1, 1, 1, a3, sb2, st2, sf2, stream));
+    FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv1, 1, 1, a3, sb2, st2, sf2, prec, stream));
     FNSSL_SN_TRY(fnssl_sn_full(&v3, nb, nt2, nfc, &L->full, 1, a3, sb2, st2, sf2, stream));
-    FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv2, 1, 1, a3, sb2, st2, sf2, stream));
+    FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv2, 1, 1, a3, sb2, st2, sf2, prec, stream));
     for (int j = 0; j < 2; ++j)
       FNSSL_SN_TRY(fnssl_sn_mamba(&v3, nb, nt2, nfc, &L->mamba[j], 1, 1, conv_st(l, j), ssm_st(l, j), carry, a3, sb2, st2,
-                                  sf2, mws, mws_bytes, stream));
+                                  sf2, mws, mws_bytes, prec, stream));
   }
 #undef FNSSL_SN_TRY
   return fnssl_sn_head(&v3, nb, nt2, nfc, net->wfiP, net->bfiP, net->wdT, net->bd, out, stream);

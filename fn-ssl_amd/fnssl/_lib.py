@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -117,7 +117,8 @@ class SnNet(C.Structure):
     _fields_ = [("dim_input", C.c_int), ("num_layers", C.c_int), ("time_ratio", C.c_int),
                 ("enc_wT", C.c_void_p), ("enc_b", C.c_void_p),
                 ("layers", SnLayer * SN_MAX_LAYERS),
-                ("wfiP", C.c_void_p), ("bfiP", C.c_void_p), ("wdT", C.c_void_p), ("bd", C.c_void_p)]
+                ("wfiP", C.c_void_p), ("bfiP", C.c_void_p), ("wdT", C.c_void_p), ("bd", C.c_void_p),
+                ("precision", C.c_int)]
 
 
 _lib = None
@@ -223,12 +224,12 @@ def load():
     lib.fnssl_train_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, C.c_uint, f, f, f, f, i, vp, vp, sz, vp]
     PV = C.POINTER(BtfView)
     lib.fnssl_sn_layernorm.argtypes = [vp, ll, i, vp, vp, f, vp, vp]
-    lib.fnssl_sn_encoder.argtypes = [vp, ll, ll, ll, ll, i, i, i, i, vp, vp, vp, vp, vp, ll, ll, ll, vp]
-    lib.fnssl_sn_fconv.argtypes = [PV, i, i, i, C.POINTER(SnFconvW), i, i, vp, ll, ll, ll, vp]
+    lib.fnssl_sn_encoder.argtypes = [vp, ll, ll, ll, ll, i, i, i, i, vp, vp, vp, vp, vp, ll, ll, ll, i, vp]
+    lib.fnssl_sn_fconv.argtypes = [PV, i, i, i, C.POINTER(SnFconvW), i, i, vp, ll, ll, ll, i, vp]
     lib.fnssl_sn_full.argtypes = [PV, i, i, i, C.POINTER(SnFullW), i, vp, ll, ll, ll, vp]
     lib.fnssl_sn_mamba_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_sn_mamba_workspace_bytes.restype = sz
-    lib.fnssl_sn_mamba.argtypes = [PV, i, i, i, C.POINTER(SnMambaW), i, i, vp, vp, i, vp, ll, ll, ll, vp, sz, vp]
+    lib.fnssl_sn_mamba.argtypes = [PV, i, i, i, C.POINTER(SnMambaW), i, i, vp, vp, i, vp, ll, ll, ll, vp, sz, i, vp]
     lib.fnssl_sn_head.argtypes = [PV, i, i, i, vp, vp, vp, vp, vp, vp]
     lib.fnssl_sn_forward_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_sn_forward_workspace_bytes.restype = sz

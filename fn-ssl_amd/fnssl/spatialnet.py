@@ -18,6 +18,7 @@ from ._lib import BtfView, SnFconvW, SnFullW, SnMambaW, SnNet, check
 from .ops import _need_dev, _ptr, _stream, _workspace, on_device
 
 H, HS, E, NST, RK, KC, XP, DO = 96, 8, 192, 16, 6, 4, 40, 16
+FP32, BF16 = 0, 1                      # FNSSL_PRECISION_FP32 / _BF16
 
 
 def _t(a, device):
@@ -138,20 +139,22 @@ def layernorm(x, w, b, eps: float = 1e-5):
 
 
 @on_device
-def encoder(x, wT, bias, state_in=None, state_out=None):
-    """x [B, C, F, T] (any strides) -> logical [B, F, T, 96]; wT [C][5][96].  state_*: [B, C, F, 4] or None."""
+def encoder(x, wT, bias, state_in=None, state_out=None, precision: int = FP32):
+    """x [B, C, F, T] (any strides) -> logical [B, F, T, 96]; wT [C][5][96].  state_*: [B, C, F, 4] or None.
+    ``precision``: FP32, or BF16 = bf16 MFMA operands, fp32 accumulate (include/fnssl.h, fnssl_sn_encoder)."""
     _need_dev(x, wT, bias, state_in, state_out)
     nb, cin, nf, nt = x.shape
     out = _new_bfth(nb, nf, nt, x.device)
     v = _view(out)
     sb, sc, sf, st = x.stride()
     check(_lib.load().fnssl_sn_encoder(_ptr(x), sb, sc, sf, st, nb, cin, nf, nt, _ptr(wT), _ptr(bias),
-                                       _ptr(state_in), _ptr(state_out), v.p, v.sb, v.st, v.sf, _stream()), "sn_encoder")
+                                       _ptr(state_in), _ptr(state_out), v.p, v.sb, v.st, v.sf, int(precision), _stream()),
+          "sn_encoder")
     return out
 
 
 @on_device
-def fconv(x, w: SnFconvW, residual: bool = True, pool: int = 1, out=None):
+def fconv(x, w: SnFconvW, residual: bool = True, pool: int = 1, out=None, precision: int = FP32):
     """x + PReLU(Conv_g(LN(x))) along F (+ AvgPool over F).  x logical [B, F, T, 96]; returns logical
     [B, F // pool, T, 96].  ``out`` may be x itself when pool == 1."""
     _need_dev(x, out)
@@ -161,7 +164,7 @@ def fconv(x, w: SnFconvW, residual: bool = True, pool: int = 1, out=None):
         out = _new_bfth(nb, nf // pool, nt, x.device)
     xv, ov = _view(x), _view(out)
     check(_lib.load().fnssl_sn_fconv(C.byref(xv), nb, nt, nf, C.byref(w), int(residual), pool, ov.p, ov.sb, ov.st, ov.sf,
-                                     _stream()), "sn_fconv")
+                                     int(precision), _stream()), "sn_fconv")
     return out
 
 
@@ -186,7 +189,8 @@ def mamba_state(nb: int, nf: int, device):
 
 
 @on_device
-def mamba(x, w: SnMambaW, residual: bool = True, time_pool: int = 1, state=None, carry: bool = False, out=None):
+def mamba(x, w: SnMambaW, residual: bool = True, time_pool: int = 1, state=None, carry: bool = False, out=None,
+          precision: int = FP32):
     """x + Mamba(LN(x)) along T for every (b, f) (+ AvgPool over T).  state = mamba_state(...) or None."""
     _need_dev(x, out)
     x = _conform(x)
@@ -199,7 +203,7 @@ def mamba(x, w: SnMambaW, residual: bool = True, time_pool: int = 1, state=None,
     cs, ss = state if state is not None else (None, None)
     _need_dev(cs, ss)
     check(lib.fnssl_sn_mamba(C.byref(xv), nb, nt, nf, C.byref(w), int(residual), time_pool, _ptr(cs), _ptr(ss),
-                             int(carry), ov.p, ov.sb, ov.st, ov.sf, _ptr(ws), ws.numel(), _stream()), "sn_mamba")
+                             int(carry), ov.p, ov.sb, ov.st, ov.sf, _ptr(ws), ws.numel(), int(precision), _stream()), "sn_mamba")
     return out
 
 
@@ -222,8 +226,9 @@ def head(x, head_ptrs):
 class DeviceSpatialNet:
     """Device-resident re-laid-out parameters of an OnlineSpatialNet (the ``fnssl_sn_net`` struct)."""
 
-    def __init__(self, state: dict, device, prefix: str = "", time_ratio: int = 5):
+    def __init__(self, state: dict, device, prefix: str = "", time_ratio: int = 5, precision: int = FP32):
         self.device = torch.device(device)
+        self.precision = int(precision)
         sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
         self.keep = _Keep()
         net = SnNet()
@@ -235,6 +240,7 @@ class DeviceSpatialNet:
         if self.num_layers > _lib.SN_MAX_LAYERS:
             raise RuntimeError("fnssl.spatialnet: at most %d layers" % _lib.SN_MAX_LAYERS)
         net.dim_input, net.num_layers, net.time_ratio = self.dim_input, self.num_layers, int(time_ratio)
+        net.precision = self.precision
         self.enc_wT = enc.permute(1, 2, 0).contiguous()                 # [c][k][o]
         self.enc_b = _t(sd["encoder.bias"], self.device)
         net.enc_wT, net.enc_b = self.keep.add(self.enc_wT), self.keep.add(self.enc_b)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 8
+#define FNSSL_ABI_VERSION 9
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -476,11 +476,17 @@ int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, co
  *   state_in   [nb, cin, nf, 4]: the 4 input frames before this chunk (NULL: zero left padding, :69)
  *   state_out  [nb, cin, nf, 4]: written with the last 4 input frames (NULL: not wanted)
  *   out        view [nb, nt, nf, 96]
+ *   precision  FNSSL_PRECISION_FP32 (exact fp32 MFMA), or FNSSL_PRECISION_BF16: both operands of the product
+ *              are rounded to bf16 (nearest even) as they enter the matrix pipe, fp32 accumulation, fp32
+ *              tensors — BASELINE config 5 as written; needs cin * 5 <= 160.  The same argument of
+ *              fnssl_sn_fconv (the grouped conv) and fnssl_sn_mamba (in_proj, x_proj, out_proj) means the
+ *              same; LayerNorm, the depthwise conv, dt_proj, the scan, the full-band branch and the head are
+ *              fp32 in both modes.
  */
 int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x_sf, long long x_st,
                      int nb, int cin, int nf, int nt, const float* wT, const float* bias,
                      const float* state_in, float* state_out,
-                     float* out, long long o_sb, long long o_st, long long o_sf, void* stream);
+                     float* out, long long o_sb, long long o_st, long long o_sf, int precision, void* stream);
 
 /* One f-conv branch (IPDnet2.py:105-109): LayerNorm(96) -> Conv1d(96, 96, k 5, groups 8, 'same' zero padding)
  * along F -> PReLU(96). */
@@ -499,7 +505,7 @@ typedef struct {
  */
 int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_fconv_w* w,
                    int residual, int pool, float* out, long long o_sb, long long o_st, long long o_sf,
-                   void* stream);
+                   int precision, void* stream);
 
 /* The full-band branch (IPDnet2.py:111-118): LayerNorm -> Conv1d(96 -> 8, 1) + SiLU -> Linear(nf, nf) over F ->
  * Conv1d(8 -> 96, 1) + SiLU. */
@@ -542,7 +548,7 @@ size_t fnssl_sn_mamba_workspace_bytes(int nb, int nt, int nf);
 int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_mamba_w* w, int residual,
                    int time_pool, float* conv_state, float* ssm_state, int carry,
                    float* out, long long o_sb, long long o_st, long long o_sf,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   void* workspace, size_t workspace_bytes, int precision, void* stream);
 
 /*
  * Replaces FreqInverse + tanh + decoder + the output re-ordering (IPDnet2.py:23-43, 355-364).
@@ -566,6 +572,7 @@ typedef struct {
   const float *enc_wT, *enc_b;
   fnssl_sn_layer layers[FNSSL_SN_MAX_LAYERS];
   const float *wfiP, *bfiP, *wdT, *bd;
+  int precision;                           /* FNSSL_PRECISION_FP32 / _BF16, see fnssl_sn_encoder */
 } fnssl_sn_net;
 
 size_t fnssl_sn_forward_workspace_bytes(int nb, int nf, int nt);

@@ -27,6 +27,38 @@ import numpy as np
 
 F32 = np.float32
 
+_BF16 = False
+
+
+def bf16_round(a) -> np.ndarray:
+    """fp32 -> nearest-even bf16, returned as fp32 (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(a, dtype=F32).view(np.uint32).astype(np.uint64)
+    r = ((u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xFFFF0000)).astype(np.uint32)
+    return r.view(F32).reshape(np.shape(a))
+
+
+class bf16_products:
+    """``with bf16_products():`` restates FNSSL_PRECISION_BF16 (include/fnssl.h, fnssl_sn_encoder): BOTH operands of the
+    encoder conv, the grouped frequency conv and the Mamba in / x / out projections are rounded to bf16 where they
+    enter the product; accumulation, biases, LayerNorm, the depthwise conv, dt_proj, the scan, the full-band branch,
+    FreqInverse and the decoder stay fp32.  (In layer 0 the device applies the 5x time pooling to the operand of
+    out_proj before it is rounded, this restatement after the product — the same rounding noise, not the same bits.)"""
+
+    def __enter__(self):
+        global _BF16
+        self._old, _BF16 = _BF16, True
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16
+        _BF16 = self._old
+        return False
+
+
+def _q(a):
+    """An operand of a product that runs on bf16 MFMAs in FNSSL_PRECISION_BF16."""
+    return bf16_round(a) if _BF16 else a
+
 
 def _f(a):
     return np.asarray(a, dtype=F32)
@@ -64,7 +96,7 @@ def causal_conv1d(x, w, b, state=None):
     T = x.shape[2]
     y = np.zeros((x.shape[0], w.shape[0], T), F32)
     for k in range(K):
-        y += np.einsum("oc,bct->bot", w[:, :, k], xp[:, :, k:k + T]).astype(F32)
+        y += np.einsum("oc,bct->bot", _q(w[:, :, k]), _q(xp[:, :, k:k + T])).astype(F32)
     return (y + _f(b)[None, :, None]).astype(F32), xp[:, :, -(K - 1):].copy()
 
 
@@ -79,8 +111,8 @@ def grouped_conv_same(x, w, b, groups):
     og = C // groups
     for g in range(groups):
         for k in range(K):
-            y[:, g * og:(g + 1) * og] += np.einsum("oc,ncf->nof", w[g * og:(g + 1) * og, :, k],
-                                                   xp[:, g * cg:(g + 1) * cg, k:k + F]).astype(F32)
+            y[:, g * og:(g + 1) * og] += np.einsum("oc,ncf->nof", _q(w[g * og:(g + 1) * og, :, k]),
+                                                   _q(xp[:, g * cg:(g + 1) * cg, k:k + F])).astype(F32)
     return (y + _f(b)[None, :, None]).astype(F32)
 
 
@@ -133,7 +165,7 @@ def mamba(sd, p, x, state=None):
     S, T, _ = x.shape
     w_in = _f(sd[p + "in_proj.weight"])
     E = w_in.shape[0] // 2
-    xz = (x @ w_in.T).astype(F32)
+    xz = (_q(x) @ _q(w_in).T).astype(F32)
     xi, z = xz[..., :E], xz[..., E:]
     wc, bc = _f(sd[p + "conv1d.weight"])[:, 0, :], _f(sd[p + "conv1d.bias"])
     K = wc.shape[1]
@@ -147,7 +179,7 @@ def mamba(sd, p, x, state=None):
     a_log = _f(sd[p + "A_log"])
     N = a_log.shape[1]
     R = wx.shape[0] - 2 * N
-    dbl = (u @ wx.T).astype(F32)
+    dbl = (_q(u) @ _q(wx).T).astype(F32)
     dt = softplus((dbl[..., :R] @ _f(sd[p + "dt_proj.weight"]).T).astype(F32) + _f(sd[p + "dt_proj.bias"]))
     Bm, Cm = dbl[..., R:R + N], dbl[..., R + N:]
     A = -np.exp(a_log)
@@ -159,7 +191,7 @@ def mamba(sd, p, x, state=None):
         h = (dA * h + (dt[:, t, :, None] * Bm[:, t, None, :]) * u[:, t, :, None]).astype(F32)
         y[:, t] = (h * Cm[:, t, None, :]).sum(-1, dtype=F32) + Dp * u[:, t]
     y = (y * silu(z)).astype(F32)
-    out = (y @ _f(sd[p + "out_proj.weight"]).T).astype(F32)
+    out = (_q(y) @ _q(_f(sd[p + "out_proj.weight"])).T).astype(F32)
     return out, (xp[:, -(K - 1):].copy(), h)
 
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.fnssl_abi_version() == 8
+    assert lib.fnssl_abi_version() == 9
 
 
 def test_shape_helpers_match_reference_formulas():
@@ -125,15 +125,17 @@ def test_spatialnet_entry_points_validate_before_touching_the_device():
     lib = _lib.load()
     v = _lib.BtfView(0, 0, 0, 0)
     w = _lib.SnFconvW()
-    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 1, None, 0, 0, 0, None) == -1
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 1, None, 0, 0, 0, 0, None) == -1
     assert b"aligned" in lib.fnssl_last_error() or b"null" in lib.fnssl_last_error()
     buf = np.zeros(64, np.float32)
     v = _lib.BtfView(buf.ctypes.data // 16 * 16, 96, 96, 96)
     for name in ("ln_w", "ln_b", "wT", "bias", "prelu"):
         setattr(w, name, buf.ctypes.data)
-    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 24, C.byref(w), 1, 1, v.p, 96, 96, 96, None) == -1   # nf not 2^k
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 24, C.byref(w), 1, 1, v.p, 96, 96, 96, 0, None) == -1   # nf not 2^k
     assert b"power of two" in lib.fnssl_last_error()
-    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 3, v.p, 96, 96, 96, None) == -1   # pool 3
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 3, v.p, 96, 96, 96, 0, None) == -1   # pool 3
+    assert lib.fnssl_sn_fconv(C.byref(v), 1, 1, 16, C.byref(w), 1, 1, v.p, 96, 96, 96, 5, None) == -1   # precision 5
+    assert b"precision" in lib.fnssl_last_error()
     assert lib.fnssl_sn_mamba_workspace_bytes(2, 10, 16) == 2 * 10 * 16 * (384 + 40 + 192) * 4
     assert lib.fnssl_sn_forward_workspace_bytes(0, 256, 10) == 0
     net = _lib.SnNet()
@@ -142,6 +144,10 @@ def test_spatialnet_entry_points_validate_before_touching_the_device():
     assert lib.fnssl_sn_forward(C.byref(net), buf.ctypes.data, 0, 0, 0, 1, 1, 200, 10, None, 0, buf.ctypes.data, None, 0,
                                 None) == -1
     assert b"num_freqs" in lib.fnssl_last_error()
+    net.precision = 3
+    assert lib.fnssl_sn_forward(C.byref(net), buf.ctypes.data, 0, 0, 0, 1, 1, 256, 10, None, 0, buf.ctypes.data, None, 0,
+                                None) == -1
+    assert b"precision" in lib.fnssl_last_error()
 
 
 def test_ipdnet2_dropin_keeps_reference_names_and_rejects_cpu():

@@ -35,8 +35,9 @@ from Model import _is_bf16, _param_key, _require_eval               # noqa: E402
 
 
 def _prec(module) -> int:
-    """After ``module.bfloat16()`` the dense products (encoder, grouped f-conv, Mamba in / x / out projections) run on
-    bf16 MFMAs with fp32 accumulation and fp32 tensors — BASELINE config 5 as written (include/fnssl.h)."""
+    """After ``module.bfloat16()`` the dense products (encoder, grouped f-conv, full-band branch, Mamba in / x / out
+    projections) run on bf16 MFMAs with fp32 accumulation and fp32 tensors — BASELINE config 5 as written
+    (include/fnssl.h)."""
     return sn.BF16 if _is_bf16(module) else sn.FP32
 
 
@@ -218,7 +219,7 @@ class SpatialNetLayer(nn.Module):
         return sn.fconv(x.float(), w[0] if ml is self.fconv1 else w[2], residual=False, precision=_prec(self)).to(x.dtype)
 
     def _full(self, x: torch.Tensor) -> torch.Tensor:
-        return sn.full(x.float(), self._packed(x.device)[1], residual=False).to(x.dtype)
+        return sn.full(x.float(), self._packed(x.device)[1], residual=False, precision=_prec(self)).to(x.dtype)
 
     def _mamba(self, x: torch.Tensor, mamba: Mamba, norm: nn.Module, dropout: nn.Module, inference: bool = False):
         w = self._packed(x.device)
@@ -233,7 +234,7 @@ class SpatialNetLayer(nn.Module):
         y = x.float()
         pr = _prec(self)
         y = sn.fconv(y, f1, pool=2 if self.is_first else 1, precision=pr)   # x + fconv1, fre_compress_first
-        y = sn.full(y, fu, out=y)
+        y = sn.full(y, fu, out=y, precision=pr)
         y = sn.fconv(y, f2, pool=8 if self.is_first else 1, precision=pr)   # x + fconv2, fre_compress_second
         y = sn.mamba(y, m0, out=y, precision=pr)
         y = sn.mamba(y, m1, out=y, precision=pr)

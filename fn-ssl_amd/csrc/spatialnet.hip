@@ -364,6 +364,7 @@ sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const floa
 //   lane (i, kq) reads W[kq*K/4 + 4g .. +3][16 j + i] with one ds_read_b128 — filled once per workgroup;
 //   D[output 4*og + r][point n]: a lane stores 4 consecutive outputs of its point (16 bytes).
 // ---------------------------------------------------------------------------------------------------------
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
 typedef __bf16 v4bf_t __attribute__((ext_vector_type(4)));
@@ -723,33 +724,46 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
 //                                    s goes through LDS transposed per frame ([frame][c][f], f contiguous = the B operand)
 //   unsqueeze out[96] = Wu . y       K = 8 (16), 8 output tiles whose rows are permuted to the ownership order, so the
 //                                    D fragment lands on the lane that holds the residual row
-template <int NF, int POOLDUMMY>
+template <int NF, bool BF>
 __global__ void __launch_bounds__(1024)
 sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk, fnssl_sn_full_w w, int residual,
                     float* out, long long o_sb, long long o_st, long long o_sf) {
   constexpr int LG = NF == 128 ? 7 : (NF == 64 ? 6 : (NF == 32 ? 5 : 4));
   constexpr int FPB = 256 / NF;                                     // frames per block
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* ldwf = lds;                                                // (NF/16)^2 KiB
-  float* ldws = ldwf + (NF / 16) * (NF / 16) * 256;                 // 8 KiB
-  float* ldwu = ldws + 8 * 256;                                     // 8 KiB
+  float* ldwf = lds;                                                // (NF/16)^2 KiB (bf16: NF/16 * ceil(NF/32))
+  float* ldws = ldwf + w_lds_floats<NF, NF, BF>();                  // 8 KiB (bf16: 4)
+  float* ldwu = ldws + w_lds_floats<128, 16, BF>();                 // 8 KiB
   float* par = ldwu + 8 * 256;                                      // ln_w 96 | ln_b 96 | bu 96 | bs 16 | bf NF
   float* st_img = par + 3 * H + 16 + NF;                            // [frame][8][NF]
   float* y_img = st_img + 256 * 8;                                  // [point][8]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
-  fill_w_lds<NF, NF, 1024>(ldwf, w.wfT, NF, NF, NF);
+  fill_w_lds<NF, NF, 1024, BF>(ldwf, w.wfT, NF, NF, NF);
   if (tid < 512) {                                                  // squeeze image: 8 k-groups x 64 lanes
     const int ln = tid & 63, gk = tid >> 6, o = ln & 15, kq = ln >> 4;
-    float v[4];
+    if constexpr (BF) {                                             // bf16: 4 items of 8 = the k-groups 2 m, 2 m + 1
+      if (tid < 256) {
+        float v[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (kq < 3 && o < HS) ? w.wsT[(CG * gk + 4 * kq + i) * HS + o] : 0.f;
-    *reinterpret_cast<float4*>(ldws + tid * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < 8; ++i)
+          v[i] = (kq < 3 && o < HS) ? w.wsT[(CG * (2 * gk + (i >> 2)) + 4 * kq + (i & 3)) * HS + o] : 0.f;
+        *reinterpret_cast<v8bf_t*>(ldws + tid * 4) = pack8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+      }
+    } else {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (kq < 3 && o < HS) ? w.wsT[(CG * gk + 4 * kq + i) * HS + o] : 0.f;
+      *reinterpret_cast<float4*>(ldws + tid * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   } else {                                                          // unsqueeze image: 8 output tiles x 64 lanes
     const int t2 = tid - 512, ln = t2 & 63, g = t2 >> 6, orow = ln & 15, kq = ln >> 4, og = orow >> 2, r = orow & 3;
     float v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (og < 3 && 4 * kq + i < HS) ? w.wuT[(4 * kq + i) * H + CG * g + 4 * og + r] : 0.f;
-    *reinterpret_cast<float4*>(ldwu + t2 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (BF)                                               // K = 16 is half of one bf16 k-step: 4 zeros follow
+      *reinterpret_cast<v8bf_t*>(ldwu + t2 * 4) = pack8_bf16(v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f);
+    else
+      *reinterpret_cast<float4*>(ldwu + t2 * 4) = make_float4(v[0], v[1], v[2], v[3]);
   }
   for (int i = tid; i < 3 * H + 16 + NF; i += 1024) {
     float v;
@@ -813,21 +827,39 @@ sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk
     var += __shfl_xor(var, 16, 64);
     var += __shfl_xor(var, 32, 64);
     const float rstd = 1.f / sqrtf(var * (1.f / H) + kEps);
-    float a[32];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    auto ln_row = [&](int g, float (&o)[4]) {
       const float4 lw = *reinterpret_cast<const float4*>(par + CG * g + 4 * (q < 3 ? q : 0));
       const float4 lb = *reinterpret_cast<const float4*>(par + H + CG * g + 4 * (q < 3 ? q : 0));
       const float m = q < 3 ? 1.f : 0.f;
-      a[4 * g] = ((xr[g][0] - mean) * rstd * lw.x + lb.x) * m;
-      a[4 * g + 1] = ((xr[g][1] - mean) * rstd * lw.y + lb.y) * m;
-      a[4 * g + 2] = ((xr[g][2] - mean) * rstd * lw.z + lb.z) * m;
-      a[4 * g + 3] = ((xr[g][3] - mean) * rstd * lw.w + lb.w) * m;
-    }
+      o[0] = ((xr[g][0] - mean) * rstd * lw.x + lb.x) * m;
+      o[1] = ((xr[g][1] - mean) * rstd * lw.y + lb.y) * m;
+      o[2] = ((xr[g][2] - mean) * rstd * lw.z + lb.z) * m;
+      o[3] = ((xr[g][3] - mean) * rstd * lw.w + lb.w) * m;
+    };
     // ---- squeeze -> SiLU -> transposed image [frame][c][f]
     {
       v4f_t acc[1] = {v4f_t{0.f, 0.f, 0.f, 0.f}};
-      mfma_tiles<128, 1>(a, ldws_lane, 0, acc);
+      if constexpr (BF) {                                           // a pair of groups is packed and consumed at once:
+#pragma unroll
+        for (int m = 0; m < NG / 2; ++m) {                          // the 32 normalised values are never all live
+          float lo[4], hi[4];
+          ln_row(2 * m, lo);
+          ln_row(2 * m + 1, hi);
+          const v8bf_t bq = pack8_bf16(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+          const v8bf_t wq = *reinterpret_cast<const v8bf_t*>(ldws_lane + m * 256);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, bq, acc[0], 0, 0, 0);
+        }
+      } else {
+        float a[32];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          float o[4];
+          ln_row(g, o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[4 * g + r] = o[r];
+        }
+        mfma_tiles<128, 1, false>(a, ldws_lane, 0, acc);
+      }
       if (q < 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -841,18 +873,30 @@ sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk
       constexpr int CT = 128 / NF;                                  // column tiles
       const int mt = wv / CT, ct = wv % CT;
       const int cfr = 2 * ct + (n >> 3), cc = n & 7;
-      float bv[NF / 4];
       const float4* src = reinterpret_cast<const float4*>(st_img + (cfr * HS + cc) * NF + q * (NF / 4));
-#pragma unroll
-      for (int i = 0; i < NF / 16; ++i) {
-        const float4 v = src[i];
-        bv[4 * i] = v.x;
-        bv[4 * i + 1] = v.y;
-        bv[4 * i + 2] = v.z;
-        bv[4 * i + 3] = v.w;
-      }
       v4f_t acc[1] = {v4f_t{0.f, 0.f, 0.f, 0.f}};
-      mfma_tiles<NF, 1>(bv, ldwf_lane, mt, acc);
+      if constexpr (BF) {
+        constexpr int M = w_items<NF, true>();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const float4 lo = src[NF >= 32 ? 2 * m : 0];
+          const float4 hi = NF >= 32 ? src[NF >= 32 ? 2 * m + 1 : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const v8bf_t bq = pack8_bf16(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
+          const v8bf_t wq = *reinterpret_cast<const v8bf_t*>(ldwf_lane + (mt * M + m) * 256);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, bq, acc[0], 0, 0, 0);
+        }
+      } else {
+        float bv[NF / 4];
+#pragma unroll
+        for (int i = 0; i < NF / 16; ++i) {
+          const float4 v = src[i];
+          bv[4 * i] = v.x;
+          bv[4 * i + 1] = v.y;
+          bv[4 * i + 2] = v.z;
+          bv[4 * i + 3] = v.w;
+        }
+        mfma_tiles<NF, 1, false>(bv, ldwf_lane, mt, acc);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int fo = 16 * mt + 4 * q + r;
@@ -874,7 +918,7 @@ sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk
         v4f_t acc[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
-        mfma_tiles<16, 4>(yv, ldwu_lane, g0, acc);
+        mfma_tiles<16, 4, BF>(yv, ldwu_lane, g0, acc);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const float4 bu4 = *reinterpret_cast<const float4*>(par + 2 * H + CG * (g0 + jj) + 4 * (q < 3 ? q : 0));
@@ -977,12 +1021,16 @@ sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const fl
   }
 }
 
-// Mamba, phase 4 on the matrix pipe: out = pool_T(x) + out_proj(pool_T(y)),  p = s*nt2 + t2
-template <bool BF>
+// Mamba, phase 4 on the matrix pipe: out = pool_T(x) + out_proj(pool_T(y)),  p = s*nt2 + t2.
+// TP = the time pooling when it is 1 or 5 (0: any, taken from tp_rt): a run-time trip count left the pooled frames as
+// 60 dependent load - wait - add round trips per tile (237 us for layer 0's pooled block against 141 us for the
+// unpooled one with five times the tiles).
+template <bool BF, int TP>
 __global__ void __launch_bounds__(512)
-sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, int nt2, int nf, int tp,
+sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int nt, int nt2, int nf, int tp_rt,
                          long long nout, const float* __restrict__ woT, int residual, float* out, long long o_sb,
                          long long o_st, long long o_sf) {
+  const int tp = TP ? TP : tp_rt;
   extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x 12 groups x 1 KiB
   fill_w_lds<E, H, 512, BF>(ldsw, woT, H, E, H);
   __syncthreads();
@@ -1002,6 +1050,7 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
 #pragma unroll
     for (int e4 = 0; e4 < E / 16; ++e4) {
       float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
       for (int i = 0; i < tp; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(yb + (long long)i * E + e4 * 4);
         yv.x += v.x;
@@ -1013,10 +1062,17 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
       a[4 * e4 + 1] = yv.y * inv;
       a[4 * e4 + 2] = yv.z * inv;
       a[4 * e4 + 3] = yv.w * inv;
-      if ((e4 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      // loads in flight: 4 float4 per lane, pooled (tp of them per e4) 2 * tp — held there by a compiler-level memory
+      // barrier (a scheduling barrier alone let all 60 be issued ahead of the first add: 240 registers)
+      if (TP >= 4) {
+        if (e4 % 2 == 1) asm volatile("" ::: "memory");
+      } else if ((e4 & 3) == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     const float* xb = xv.p + b * xv.sb + (long long)t2 * tp * xv.st + f * xv.sf + 4 * kq;
     float* dst = out + b * o_sb + t2 * o_st + f * o_sf + 4 * kq;
+    if (TP >= 4) asm volatile("" ::: "memory");
 #pragma unroll
     for (int j0 = 0; j0 < H / 16; j0 += 3) {
       v4f_t acc[3];
@@ -1028,6 +1084,7 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
         float4 o4 = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
         if (residual) {
           float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
           for (int i = 0; i < tp; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(xb + (long long)i * xv.st + 16 * (j0 + jj));
             r.x += v.x;
@@ -1039,8 +1096,15 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
         }
         if (p < nout) *reinterpret_cast<float4*>(dst + 16 * (j0 + jj)) = o4;
       }
+      if (TP >= 4) asm volatile("" ::: "memory");                  // not both halves' 30 residual loads at once
     }
   }
+}
+
+// lane n of a 16-lane row reads lane n - j (row_shr:j = 0x110 + j) or n + j (row_shl:j = 0x100 + j); 0 outside the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 // Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP (80 or 160: KP / 4 a multiple of the 5 taps);
@@ -1090,10 +1154,57 @@ sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, 
         if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (state_in)
+    if (state_in) {
       build(std::true_type{});
-    else
+    } else if (nt < KE - 1) {
       build(std::false_type{});
+    } else {
+      // Whole-signal case: ONE load per channel (the lane's current frame) plus, in the lanes n < 4, the frame of the
+      // point p - 4 (the halo of the tile); the other four taps of a lane are the current frames of its left neighbours,
+      // which are its own earlier frames whenever t >= shift (points are consecutive along t) — DPP row shifts within
+      // the tile's 16 lanes.  2 loads + 12 moves per channel instead of 5 loads: the build was bound by the number
+      // of load instructions (40 per lane and tile).
+      const float* hr = xr + (t - (KE - 1)) * ist;                   // halo point p - 4: same row, or the end of the row before
+      bool hok = n < KE - 1;
+      if (t < KE - 1) {
+        const long long sq = pc / nt - 1;
+        hok = hok && sq >= 0;
+        const long long sqc = sq >= 0 ? sq : 0;
+        hr = x + (sqc / nf) * sb + (sqc % nf) * sf + (nt + t - (KE - 1)) * ist;
+      }
+      float cur[KP / 20], halo[KP / 20];
+#pragma unroll
+      for (int ci = 0; ci < KP / 20; ++ci) {
+        const bool cok = lane_c + ci < cin;
+        cur[ci] = xr[cok ? lane_off + ci * isc : 0];
+        cur[ci] = cok ? cur[ci] : 0.f;
+        halo[ci] = 0.f;
+      }
+      if (hok) {
+#pragma unroll
+        for (int ci = 0; ci < KP / 20; ++ci) {
+          const bool cok = lane_c + ci < cin;
+          const float v = hr[cok ? (lane_c + ci) * isc : 0];
+          halo[ci] = cok ? v : 0.f;
+        }
+      }
+#pragma unroll
+      for (int ci = 0; ci < KP / 20; ++ci) {
+        a[KE * ci + KE - 1] = cur[ci];
+        // all shifts first, with every lane active; then the per-lane choice
+        const float r1 = dpp_f<0x111>(cur[ci]), r2 = dpp_f<0x112>(cur[ci]), r3 = dpp_f<0x113>(cur[ci]),
+                    r4 = dpp_f<0x114>(cur[ci]);                                    // row_shr:1..4
+        const float h1 = dpp_f<0x103>(halo[ci]), h2 = dpp_f<0x102>(halo[ci]), h3 = dpp_f<0x101>(halo[ci]);   // row_shl:3..1
+        const float s1 = n >= 1 ? r1 : h1;
+        const float s2 = n >= 2 ? r2 : h2;
+        const float s3 = n >= 3 ? r3 : h3;
+        const float s4 = n >= 4 ? r4 : halo[ci];
+        a[KE * ci + 3] = t >= 1 ? s1 : 0.f;
+        a[KE * ci + 2] = t >= 2 ? s2 : 0.f;
+        a[KE * ci + 1] = t >= 3 ? s3 : 0.f;
+        a[KE * ci + 0] = t >= 4 ? s4 : 0.f;
+      }
+    }
     float* dst = out + b * o_sb + t * o_st + f * o_sf + 4 * kq;
 #pragma unroll
     for (int j0 = 0; j0 < H / 16; j0 += 3) {
@@ -1180,14 +1291,17 @@ sn_mamba_scan_kernel(const float* __restrict__ xz, const float* __restrict__ dbl
                      float* ybuf, int have_u) {
   const long long s = blockIdx.x;
   const int e = threadIdx.x;
-  float A[NST], h[NST], wd[RK], cw[KC];
+  // the states as pairs: the update of two states is three packed-fp32 instructions (v_pk_mul_f32 / v_pk_fma_f32)
+  // next to its two v_exp_f32
+  v2f_t A[NST / 2], h[NST / 2];
+  float wd[RK], cw[KC];
 #pragma unroll
   for (int n = 0; n < NST; ++n) {
     // exp(dt A) = 2^(dt * A log2 e): the factor is folded into A once, and the step uses the bare v_exp_f32 (the
     // library exp adds a denormal-range rescue per call, 5 more operations on each of the 16 states of a step;
     // a decay below 1e-38 is zero either way)
-    A[n] = a[e * NST + n] * 1.44269504088896340736f;
-    h[n] = (carry && ssm_state) ? ssm_state[(s * E + e) * NST + n] : 0.f;
+    A[n >> 1][n & 1] = a[e * NST + n] * 1.44269504088896340736f;
+    h[n >> 1][n & 1] = (carry && ssm_state) ? ssm_state[(s * E + e) * NST + n] : 0.f;
   }
 #pragma unroll
   for (int r = 0; r < RK; ++r) wd[r] = wdt[e * RK + r];
@@ -1246,19 +1360,24 @@ sn_mamba_scan_kernel(const float* __restrict__ xz, const float* __restrict__ dbl
       dt = u1 == 1.f ? ex : __logf(u1) * __fdividef(ex, u1 - 1.f);
     }
     const float dtu = dt * u;
-    float y = 0.f;
+    const v2f_t dt2 = {dt, dt}, dtu2 = {dtu, dtu};
+    v2f_t y2 = {0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < NST; ++n) {
-      const float dA = __builtin_amdgcn_exp2f(dt * A[n]);
-      h[n] = fmaf(dA, h[n], dtu * row[RK + n]);
-      y = fmaf(h[n], row[RK + NST + n], y);
+    for (int n = 0; n < NST / 2; ++n) {
+      const v2f_t ex = dt2 * A[n];
+      const v2f_t dA = {__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
+      const v2f_t bt = {row[RK + 2 * n], row[RK + 2 * n + 1]};
+      const v2f_t ct = {row[RK + NST + 2 * n], row[RK + NST + 2 * n + 1]};
+      h[n] = __builtin_elementwise_fma(dA, h[n], dtu2 * bt);
+      y2 = __builtin_elementwise_fma(h[n], ct, y2);
     }
+    float y = y2[0] + y2[1];
     y = fmaf(dp, u, y) * silu_f(z);
     yrow[(long long)t * E] = y;
   }
   if (ssm_state) {
 #pragma unroll
-    for (int n = 0; n < NST; ++n) ssm_state[(s * E + e) * NST + n] = h[n];
+    for (int n = 0; n < NST; ++n) ssm_state[(s * E + e) * NST + n] = h[n >> 1][n & 1];
   }
   if (conv_state && have_u) {                            // the last three xi of the chunk (older ones: the carried state)
     float xs[3];
@@ -1607,8 +1726,9 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
 }
 
 int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_full_w* w, int residual, float* out,
-                  long long o_sb, long long o_st, long long o_sf, void* stream) {
+                  long long o_sb, long long o_st, long long o_sf, int precision, void* stream) {
   FNSSL_REQUIRE(view_ok(x), "sn_full: x must be 16-byte aligned with strides %% 4 == 0");
+  FNSSL_REQUIRE(precision_ok(precision), "sn_full: precision %d (FNSSL_PRECISION_FP32 or _BF16)", precision);
   FNSSL_REQUIRE(w && w->ln_w && w->ln_b && w->wsT && w->bs && w->wfT && w->bf && w->wuT && w->bu, "sn_full: null weights");
   FNSSL_REQUIRE(out_ok(out, o_sb, o_st, o_sf), "sn_full: output must be 16-byte aligned with strides %% 4 == 0");
   FNSSL_REQUIRE(nb > 0 && nt > 0, "sn_full: empty problem");
@@ -1619,17 +1739,23 @@ int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_s
   FNSSL_REQUIRE(nblk < (1ll << 31), "sn_full: too many frames");
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl("sn_full", s, 2.0 * nframes * nf * (2.0 * H * HS + (double)HS * nf));
-  const bool mfma = !getenv("FNSSL_SN_SCALAR") && (nf == 16 || nf == 64 || nf == 128);
+  const bool bf = precision == FNSSL_PRECISION_BF16;
+  FNSSL_REQUIRE(!bf || nf == 16 || nf == 64 || nf == 128, "sn_full: FNSSL_PRECISION_BF16 needs nf 16, 64 or 128, got %d", nf);
+  const bool mfma = (bf || !getenv("FNSSL_SN_SCALAR")) && (nf == 16 || nf == 64 || nf == 128);
   if (mfma) {
     const long long cus = fnssl::device_cus();
     const unsigned grid = (unsigned)(nblk < cus ? nblk : cus);
     const size_t lds = (size_t)((nf / 16) * (nf / 16) * 256 + 16 * 256 + 3 * H + 16 + nf + 2 * 256 * 8) * sizeof(float);
+#define FNSSL_SN_FULL_P(NFV, BF)                                                                                   \
+  do {                                                                                                             \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_full_mfma_kernel<NFV, BF>),                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                       \
+    hipLaunchKernelGGL((sn_full_mfma_kernel<NFV, BF>), dim3(grid), dim3(1024), lds, s, *x, nt, nframes, nblk, *w,  \
+                       residual, out, o_sb, o_st, o_sf);                                                           \
+  } while (0)
 #define FNSSL_SN_FULL(NFV)                                                                                         \
   do {                                                                                                             \
-    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_full_mfma_kernel<NFV, 0>), \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    hipLaunchKernelGGL((sn_full_mfma_kernel<NFV, 0>), dim3(grid), dim3(1024), lds, s, *x, nt, nframes, nblk, *w, residual, \
-                       out, o_sb, o_st, o_sf);                                                                     \
+    if (bf) FNSSL_SN_FULL_P(NFV, true); else FNSSL_SN_FULL_P(NFV, false);                                          \
   } while (0)
     if (nf == 16)
       FNSSL_SN_FULL(16);
@@ -1638,6 +1764,7 @@ int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_s
     else
       FNSSL_SN_FULL(128);
 #undef FNSSL_SN_FULL
+#undef FNSSL_SN_FULL_P
   } else {
     hipLaunchKernelGGL(sn_full_kernel, dim3((unsigned)nblk), dim3(256), 0, s, *x, nt, nf, lg, nframes, *w, residual, out,
                        o_sb, o_st, o_sf);
@@ -1729,17 +1856,20 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
     if (nout > 0) {
       fnssl::TimedLaunch tl("sn_mamba_out", s, 2.0 * nout * E * H);
       if (mfma) {
+#define FNSSL_SN_OUT(BF, TP)                                                                                        \
+  do {                                                                                                              \
+    const size_t lds = (size_t)w_lds_floats<E, H, BF>() * sizeof(float);                                            \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel<BF, TP>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    hipLaunchKernelGGL((sn_mamba_out_mfma_kernel<BF, TP>), dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt, \
+                       nt2, nf, time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);                          \
+  } while (0)
         if (bf) {
-          const size_t lds = (size_t)w_lds_floats<E, H, true>() * sizeof(float);
-          hipLaunchKernelGGL(sn_mamba_out_mfma_kernel<true>, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt, nt2,
-                             nf, time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
+          if (time_pool == 1) FNSSL_SN_OUT(true, 1); else if (time_pool == 5) FNSSL_SN_OUT(true, 5); else FNSSL_SN_OUT(true, 0);
         } else {
-          const size_t lds = (size_t)w_lds_floats<E, H, false>() * sizeof(float);
-          FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_mamba_out_mfma_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL(sn_mamba_out_mfma_kernel<false>, dim3(mfma_grid(nout, 2)), dim3(512), lds, s, m.y, *x, nt,
-                             nt2, nf, time_pool, nout, w->woT, residual, out, o_sb, o_st, o_sf);
+          if (time_pool == 1) FNSSL_SN_OUT(false, 1); else if (time_pool == 5) FNSSL_SN_OUT(false, 5); else FNSSL_SN_OUT(false, 0);
         }
+#undef FNSSL_SN_OUT
       } else {
         hipLaunchKernelGGL(sn_mamba_out_kernel, dim3(blocks_of(nout), 2), dim3(256), 0, s, m.y, *x, nt, nt2, nf, time_pool,
                            nout, w->woT, residual, out, o_sb, o_st, o_sf);
@@ -1842,7 +1972,7 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
   strides(nf / 2, sb2, st2, sf2, nt);
   FNSSL_SN_TRY(fnssl_sn_fconv(&v0, nb, nt, nf, &L->fconv1, 1, 2, a1, sb2, st2, sf2, prec, stream));
   fnssl_btf_view v1 = {a1, sb2, st2, sf2};
-  FNSSL_SN_TRY(fnssl_sn_full(&v1, nb, nt, nf / 2, &L->full, 1, a1, sb2, st2, sf2, stream));
+  FNSSL_SN_TRY(fnssl_sn_full(&v1, nb, nt, nf / 2, &L->full, 1, a1, sb2, st2, sf2, prec, stream));
   strides(nfc, sb, st, sf, nt);
   FNSSL_SN_TRY(fnssl_sn_fconv(&v1, nb, nt, nf / 2, &L->fconv2, 1, 8, a2, sb, st, sf, prec, stream));
   fnssl_btf_view v2 = {a2, sb, st, sf};
@@ -1856,7 +1986,7 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
   for (int l = 1; l < net->num_layers; ++l) {
     L = &net->layers[l];
     FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv1, 1, 1, a3, sb2, st2, sf2, prec, stream));
-    FNSSL_SN_TRY(fnssl_sn_full(&v3, nb, nt2, nfc, &L->full, 1, a3, sb2, st2, sf2, stream));
+    FNSSL_SN_TRY(fnssl_sn_full(&v3, nb, nt2, nfc, &L->full, 1, a3, sb2, st2, sf2, prec, stream));
     FNSSL_SN_TRY(fnssl_sn_fconv(&v3, nb, nt2, nfc, &L->fconv2, 1, 1, a3, sb2, st2, sf2, prec, stream));
     for (int j = 0; j < 2; ++j)
       FNSSL_SN_TRY(fnssl_sn_mamba(&v3, nb, nt2, nfc, &L->mamba[j], 1, 1, conv_st(l, j), ssm_st(l, j), carry, a3, sb2, st2,

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -226,7 +226,7 @@ def load():
     lib.fnssl_sn_layernorm.argtypes = [vp, ll, i, vp, vp, f, vp, vp]
     lib.fnssl_sn_encoder.argtypes = [vp, ll, ll, ll, ll, i, i, i, i, vp, vp, vp, vp, vp, ll, ll, ll, i, vp]
     lib.fnssl_sn_fconv.argtypes = [PV, i, i, i, C.POINTER(SnFconvW), i, i, vp, ll, ll, ll, i, vp]
-    lib.fnssl_sn_full.argtypes = [PV, i, i, i, C.POINTER(SnFullW), i, vp, ll, ll, ll, vp]
+    lib.fnssl_sn_full.argtypes = [PV, i, i, i, C.POINTER(SnFullW), i, vp, ll, ll, ll, i, vp]
     lib.fnssl_sn_mamba_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_sn_mamba_workspace_bytes.restype = sz
     lib.fnssl_sn_mamba.argtypes = [PV, i, i, i, C.POINTER(SnMambaW), i, i, vp, vp, i, vp, ll, ll, ll, vp, sz, i, vp]

@@ -169,7 +169,7 @@ def fconv(x, w: SnFconvW, residual: bool = True, pool: int = 1, out=None, precis
 
 
 @on_device
-def full(x, w: SnFullW, residual: bool = True, out=None):
+def full(x, w: SnFullW, residual: bool = True, out=None, precision: int = FP32):
     """x + SiLU(unsqueeze(Linear_F(SiLU(squeeze(LN(x))))))   (IPDnet2.py:235-253)."""
     _need_dev(x, out)
     x = _conform(x)
@@ -178,7 +178,7 @@ def full(x, w: SnFullW, residual: bool = True, out=None):
         out = _new_bfth(nb, nf, nt, x.device)
     xv, ov = _view(x), _view(out)
     check(_lib.load().fnssl_sn_full(C.byref(xv), nb, nt, nf, C.byref(w), int(residual), ov.p, ov.sb, ov.st, ov.sf,
-                                    _stream()), "sn_full")
+                                    int(precision), _stream()), "sn_full")
     return out
 
 

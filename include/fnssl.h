@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 9
+#define FNSSL_ABI_VERSION 10
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -479,9 +479,9 @@ int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, co
  *   precision  FNSSL_PRECISION_FP32 (exact fp32 MFMA), or FNSSL_PRECISION_BF16: both operands of the product
  *              are rounded to bf16 (nearest even) as they enter the matrix pipe, fp32 accumulation, fp32
  *              tensors — BASELINE config 5 as written; needs cin * 5 <= 160.  The same argument of
- *              fnssl_sn_fconv (the grouped conv) and fnssl_sn_mamba (in_proj, x_proj, out_proj) means the
- *              same; LayerNorm, the depthwise conv, dt_proj, the scan, the full-band branch and the head are
- *              fp32 in both modes.
+ *              fnssl_sn_fconv (the grouped conv), fnssl_sn_full (squeeze, Linear over F, unsqueeze; nf 16, 64
+ *              or 128) and fnssl_sn_mamba (in_proj, x_proj, out_proj) means the same; LayerNorm, biases and
+ *              activations, the depthwise conv, dt_proj, the scan and the head are fp32 in both modes.
  */
 int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x_sf, long long x_st,
                      int nb, int cin, int nf, int nt, const float* wT, const float* bias,
@@ -519,7 +519,7 @@ typedef struct {
 /* Replaces `x + self._full(x)` (IPDnet2.py:150,235-253; dropout_full off).  nf a power of two, 8 <= nf <= 256.
  * out may alias x. */
 int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_sn_full_w* w, int residual,
-                  float* out, long long o_sb, long long o_st, long long o_sf, void* stream);
+                  float* out, long long o_sb, long long o_st, long long o_sf, int precision, void* stream);
 
 /* One Mamba block with its LayerNorm (IPDnet2.py:126-132; mamba_ssm.Mamba(d_model 96, d_state 16, d_conv 4)). */
 typedef struct {

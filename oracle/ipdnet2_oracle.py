@@ -39,9 +39,9 @@ def bf16_round(a) -> np.ndarray:
 
 class bf16_products:
     """``with bf16_products():`` restates FNSSL_PRECISION_BF16 (include/fnssl.h, fnssl_sn_encoder): BOTH operands of the
-    encoder conv, the grouped frequency conv and the Mamba in / x / out projections are rounded to bf16 where they
-    enter the product; accumulation, biases, LayerNorm, the depthwise conv, dt_proj, the scan, the full-band branch,
-    FreqInverse and the decoder stay fp32.  (In layer 0 the device applies the 5x time pooling to the operand of
+    encoder conv, the grouped frequency conv, the three products of the full-band branch (squeeze, Linear over F,
+    unsqueeze) and the Mamba in / x / out projections are rounded to bf16 where they enter the product; accumulation,
+    biases, activations, LayerNorm, the depthwise conv, dt_proj, the scan, FreqInverse and the decoder stay fp32.  (In layer 0 the device applies the 5x time pooling to the operand of
     out_proj before it is rounded, this restatement after the product — the same rounding noise, not the same bits.)"""
 
     def __enter__(self):
@@ -134,11 +134,11 @@ def full(sd, p, x):
     x = _f(x)
     y = layer_norm(x, sd[p + "norm_full.weight"], sd[p + "norm_full.bias"])
     ws, bs = _f(sd[p + "squeeze.0.weight"])[:, :, 0], _f(sd[p + "squeeze.0.bias"])
-    s = silu(np.einsum("bfth,qh->bftq", y, ws).astype(F32) + bs)        # [B, F, T, H']
+    s = silu(np.einsum("bfth,qh->bftq", _q(y), _q(ws)).astype(F32) + bs)        # [B, F, T, H']
     wf, bf = _f(sd[p + "full.weight"]), _f(sd[p + "full.bias"])
-    s = (np.einsum("bftq,gf->bgtq", s, wf).astype(F32) + bf[None, :, None, None]).astype(F32)   # Linear over F
+    s = (np.einsum("bftq,gf->bgtq", _q(s), _q(wf)).astype(F32) + bf[None, :, None, None]).astype(F32)   # Linear over F
     wu, bu = _f(sd[p + "unsqueeze.0.weight"])[:, :, 0], _f(sd[p + "unsqueeze.0.bias"])
-    return silu(np.einsum("bftq,hq->bfth", s, wu).astype(F32) + bu)
+    return silu(np.einsum("bftq,hq->bfth", _q(s), _q(wu)).astype(F32) + bu)
 
 
 def avgpool_f(x, k):

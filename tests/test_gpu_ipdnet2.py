@@ -277,6 +277,17 @@ def test_bf16_ops_vs_oracle_restating_the_rounding(dev):
         with O2.bf16_products():
             want = O2.avgpool_f(x + O2.fconv(sd, "layers.0.fconv1", x), pool)
         assert_close(got, want, BF_RTOL, BF_ATOL, "fconv bf16 nf %d pool %d" % (nf, pool))
+    # full-band branch (squeeze, Linear over F, unsqueeze on bf16 operands) at the three sizes of the matrix-pipe kernel
+    for nf, lp, seed in ((128, "layers.0.", 2514), (16, "layers.1.", 2515)):
+        x = rs_randn(seed, (2, nf, 6, 96))
+        wl = (net.layers[0] if nf == 128 else net.layers[1])._packed(dev)
+        got = sn.full(to_dev(x, dev), wl[1], residual=True, precision=sn.BF16).cpu().numpy()
+        with O2.bf16_products():
+            want = x + O2.full(sd, lp, x)
+        assert_close(got, want, BF_RTOL, BF_ATOL, "full bf16 nf %d" % nf)
+        assert np.abs(got - (x + O2.full(sd, lp, x))).max() > 1e-6, "bf16 mode did not change the product"
+    with pytest.raises(RuntimeError):
+        sn.full(to_dev(rs_randn(1, (1, 32, 2, 96)), dev), w0[1], precision=sn.BF16)   # no bf16 kernel at 32 bins
     # Mamba block: LN + in_proj / x_proj / out_proj on bf16 operands, scan fp32; + residual + time pooling; streaming
     x = rs_randn(2520, (3, 35, 96))
     xs = to_dev(x, dev).unsqueeze(0)

@@ -364,6 +364,20 @@ sn_mamba_in_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const floa
 //   lane (i, kq) reads W[kq*K/4 + 4g .. +3][16 j + i] with one ds_read_b128 — filled once per workgroup;
 //   D[output 4*og + r][point n]: a lane stores 4 consecutive outputs of its point (16 bytes).
 // ---------------------------------------------------------------------------------------------------------
+// q = p / d, r = p % d (p >= 0, d > 0) in 32-bit arithmetic whenever p fits: a 64-bit division by a run-time value is
+// ~150 VALU instructions, and the three per point of the index split were most of the instruction stream of the
+// matrix-pipe kernels (counters, profiles/r02/m_: 1 200 VALU instructions per 16-point tile of the encoder).
+__device__ __forceinline__ long long divmod(long long p, int d, int& r) {
+  if (p < (1ll << 31)) {
+    const unsigned pu = (unsigned)p, q = pu / (unsigned)d;
+    r = (int)(pu - q * (unsigned)d);
+    return (long long)q;
+  }
+  const long long q = p / d;
+  r = (int)(p - q * d);
+  return q;
+}
+
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef __bf16 v8bf_t __attribute__((ext_vector_type(8)));
@@ -409,9 +423,12 @@ __device__ __forceinline__ void fill_w_lds_strided(float* lds, const float* __re
     const int lane = idx & 63, g = (idx >> 6) % G, j = (idx >> 6) / G;
     const int kl = PER * g, k0 = (lane >> 4) * KQ + kl, o = 16 * j + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < PER; ++i)
-      v[u][i] = (idx < TOTAL && kl + i < KQ && k0 + i < kvalid && o < nvalid) ? w[(long long)(k0 + i) * sk + (long long)o * so]
-                                                                             : 0.f;
+    for (int i = 0; i < PER; ++i) {
+      // unconditional load from a clamped address, then the choice: a conditional load is a branch and a wait per element
+      const bool ok = idx < TOTAL && kl + i < KQ && k0 + i < kvalid && o < nvalid;
+      const float x = w[ok ? (long long)(k0 + i) * sk + (long long)o * so : 0];
+      v[u][i] = ok ? x : 0.f;
+    }
   }
 #pragma unroll
   for (int u = 0; u < TRIPS; ++u) {
@@ -429,6 +446,31 @@ __device__ __forceinline__ void fill_w_lds_strided(float* lds, const float* __re
 template <int K, int N, int BD, bool BF = false>
 __device__ __forceinline__ void fill_w_lds(float* lds, const float* __restrict__ wT, int ldw, int kvalid, int nvalid) {
   fill_w_lds_strided<K, N, BD, BF>(lds, wT, ldw, 1, kvalid, nvalid);
+}
+
+// bf16: the lane's K/4 values as ceil(K/32) packed operands (done once when several calls share them)
+template <int K>
+__device__ __forceinline__ void pack_operand(const float (&a)[K / 4], v8bf_t (&b)[w_items<K, true>()]) {
+  constexpr int KQ = K / 4;
+#pragma unroll
+  for (int m = 0; m < w_items<K, true>(); ++m) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = 8 * m + e < KQ ? a[8 * m + e < KQ ? 8 * m + e : 0] : 0.f;
+    b[m] = pack8_bf16(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+  }
+}
+template <int K, int NJ>
+__device__ __forceinline__ void mfma_tiles_packed(const v8bf_t (&b)[w_items<K, true>()], const float* ldsw_lane, int j0,
+                                                  v4f_t (&acc)[NJ]) {
+  constexpr int G = w_items<K, true>();
+#pragma unroll
+  for (int m = 0; m < G; ++m)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const v8bf_t w = *reinterpret_cast<const v8bf_t*>(ldsw_lane + ((j0 + jj) * G + m) * 256);
+      acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b[m], acc[jj], 0, 0, 0);
+    }
 }
 
 // acc[jj] += W-tile (j0 + jj) . x   for NJ output tiles at once (independent accumulators keep the pipe busy)
@@ -486,9 +528,8 @@ sn_mamba_in_mfma_kernel(fnssl_btf_view xv, int nt, int nf, long long npts, const
   for (long long tile = (long long)blockIdx.x * 16 + w; tile < ntiles; tile += (long long)gridDim.x * 16) {
     const long long p = tile * 16 + n;
     const long long pc = p < npts ? p : npts - 1;
-    const int t = (int)(pc % nt);
-    const int f = (int)((pc / nt) % nf);
-    const long long b = pc / ((long long)nt * nf);
+    int t, f;
+    const long long b = divmod(divmod(pc, nt, t), nf, f);
     const float4* row = reinterpret_cast<const float4*>(xv.p + b * xv.sb + t * xv.st + f * xv.sf + kq * (H / 4));
     float a[H / 4];
 #pragma unroll
@@ -557,7 +598,11 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
     const float* wg = w.wT + gg * (KF * CG * CG);
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < KF * CG && o < CG) ? wg[(k0 + i) * CG + o] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = k0 + i < KF * CG && o < CG;
+      const float x = wg[ok ? (k0 + i) * CG + o : 0];
+      v[i] = ok ? x : 0.f;
+    }
     *reinterpret_cast<v8bf_t*>(ldw + gg * GW + idx * 4) = pack8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
   } else {
 #pragma unroll
@@ -569,7 +614,11 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
       const float* wg = w.wT + gg * (KF * CG * CG);
       float v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = (k0 + i < KF * CG && o < CG) ? wg[(k0 + i) * CG + o] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = k0 + i < KF * CG && o < CG;
+        const float x = wg[ok ? (k0 + i) * CG + o : 0];
+        v[i] = ok ? x : 0.f;
+      }
       *reinterpret_cast<float4*>(ldw + gg * GW + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
@@ -606,7 +655,9 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
     const long long frame = blk * (256 >> lg_nf) + fr;
     const bool ok = blk < nblk && frame < nframes && q < 3;
     const long long fc = ok ? frame : 0;
-    const float* row = xv.p + (fc / nt) * xv.sb + (fc % nt) * xv.st + f * xv.sf + 4 * q;
+    int fct;
+    const long long fcb = divmod(fc, nt, fct);
+    const float* row = xv.p + fcb * xv.sb + fct * xv.st + f * xv.sf + 4 * q;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -629,8 +680,8 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
       for (int r = 0; r < 4; ++r) xr[g][r] = xn[g][r];
     const long long frame = blk * (256 >> lg_nf) + fr;
     const bool valid = frame < nframes;
-    const long long b = frame / nt;
-    const int t = (int)(frame % nt);
+    int t;
+    const long long b = divmod(frame, nt, t);
     // LayerNorm over the bin's 96 channels: 32 in each of the lanes q = 0..2 (q = 3 holds zeros)
     float sum = 0.f;
 #pragma unroll
@@ -745,21 +796,32 @@ sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk
       if (tid < 256) {
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          v[i] = (kq < 3 && o < HS) ? w.wsT[(CG * (2 * gk + (i >> 2)) + 4 * kq + (i & 3)) * HS + o] : 0.f;
+        for (int i = 0; i < 8; ++i) {
+          const bool ok = kq < 3 && o < HS;
+          const float x = w.wsT[ok ? (CG * (2 * gk + (i >> 2)) + 4 * kq + (i & 3)) * HS + o : 0];
+          v[i] = ok ? x : 0.f;
+        }
         *reinterpret_cast<v8bf_t*>(ldws + tid * 4) = pack8_bf16(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
       }
     } else {
       float v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = (kq < 3 && o < HS) ? w.wsT[(CG * gk + 4 * kq + i) * HS + o] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = kq < 3 && o < HS;
+        const float x = w.wsT[ok ? (CG * gk + 4 * kq + i) * HS + o : 0];
+        v[i] = ok ? x : 0.f;
+      }
       *reinterpret_cast<float4*>(ldws + tid * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   } else {                                                          // unsqueeze image: 8 output tiles x 64 lanes
     const int t2 = tid - 512, ln = t2 & 63, g = t2 >> 6, orow = ln & 15, kq = ln >> 4, og = orow >> 2, r = orow & 3;
     float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (og < 3 && 4 * kq + i < HS) ? w.wuT[(4 * kq + i) * H + CG * g + 4 * og + r] : 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = og < 3 && 4 * kq + i < HS;
+      const float x = w.wuT[ok ? (4 * kq + i) * H + CG * g + 4 * og + r : 0];
+      v[i] = ok ? x : 0.f;
+    }
     if constexpr (BF)                                               // K = 16 is half of one bf16 k-step: 4 zeros follow
       *reinterpret_cast<v8bf_t*>(ldwu + t2 * 4) = pack8_bf16(v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f);
     else
@@ -784,7 +846,9 @@ sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk
     const long long frame = blk * FPB + fr;
     const bool ok = blk < nblk && frame < nframes && q < 3;
     const long long fc = ok ? frame : 0;
-    const float* row = xv.p + (fc / nt) * xv.sb + (fc % nt) * xv.st + f * xv.sf + 4 * q;
+    int fct;
+    const long long fcb = divmod(fc, nt, fct);
+    const float* row = xv.p + fcb * xv.sb + fct * xv.st + f * xv.sf + 4 * q;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -805,8 +869,8 @@ sn_full_mfma_kernel(fnssl_btf_view xv, int nt, long long nframes, long long nblk
       for (int r = 0; r < 4; ++r) xr[g][r] = xn[g][r];
     const long long frame = blk * FPB + fr;
     const bool valid = frame < nframes;
-    const long long b = frame / nt;
-    const int t = (int)(frame % nt);
+    int t;
+    const long long b = divmod(frame, nt, t);
     // LayerNorm (32 channels in each of the lanes q = 0..2)
     float sum = 0.f;
 #pragma unroll
@@ -949,10 +1013,10 @@ sn_mamba_conv_kernel(const float* __restrict__ xz, int nt, long long npts, const
                      const float* __restrict__ conv_b, const float* __restrict__ conv_state, float* __restrict__ u) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= npts * (E / 4)) return;
-  const int e0 = (int)(idx % (E / 4)) * 4;
-  const long long p = idx / (E / 4);
-  const int t = (int)(p % nt);
-  const long long sq = p / nt;
+  int e4, t;
+  const long long p = divmod(idx, E / 4, e4);
+  const int e0 = e4 * 4;
+  const long long sq = divmod(p, nt, t);
   float4 v[KC];
 #pragma unroll
   for (int k = 0; k < KC; ++k) {
@@ -1041,10 +1105,9 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
   for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
     const long long p = tile * 16 + n;
     const long long pc = p < nout ? p : nout - 1;
-    const int t2 = (int)(pc % nt2);
-    const long long sq = pc / nt2;
-    const int f = (int)(sq % nf);
-    const long long b = sq / nf;
+    int t2, f;
+    const long long sq = divmod(pc, nt2, t2);
+    const long long b = divmod(sq, nf, f);
     const float* yb = ybuf + (sq * nt + (long long)t2 * tp) * E + kq * (E / 4);
     float a[E / 4];
 #pragma unroll
@@ -1109,24 +1172,120 @@ __device__ __forceinline__ float dpp_f(float v) {
 
 // Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP (80 or 160: KP / 4 a multiple of the 5 taps);
 // p = (b*nf + f)*nt + t
-template <int KP, bool BF>
-__global__ void __launch_bounds__(512)
+// PIPE: the whole-signal formulation (no carried frames, nt >= 4) — its own instantiation so that each path gets its own
+// register allocation
+template <int KP, bool BF, bool PIPE>
+__global__ void __launch_bounds__(512, PIPE ? 4 : 1)                 // PIPE: two workgroups per CU = 4 waves per SIMD
 sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, long long sf, long long st, int cin,
                        int nf, int nt, long long npts, const float* __restrict__ wT, const float* __restrict__ bias,
                        const float* __restrict__ state_in, float* __restrict__ out, long long o_sb, long long o_st,
                        long long o_sf) {
-  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x KP/16 groups x 1 KiB
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];     // 6 tiles x KP/16 groups x 1 KiB (+ PIPE: bias)
   fill_w_lds<KP, H, 512, BF>(ldsw, wT, H, cin * KE, H);
+  float* ldsb = ldsw + w_lds_floats<KP, H, BF>();
+  if (PIPE && threadIdx.x < H) ldsb[threadIdx.x] = bias[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
   const float* ldsw_lane = ldsw + lane * 4;
   const long long ntiles = (npts + 15) / 16;
+  if constexpr (PIPE) {
+    // Whole-signal case.  ONE load per channel (the lane's current frame) plus, in the lanes n < 4, the frame of the
+    // point p - 4 (the halo of the tile); the other four taps of a lane are the current frames of its left neighbours,
+    // which are its own earlier frames whenever t >= shift (points are consecutive along t) — DPP row shifts within
+    // the tile's 16 lanes: 2 loads + 12 moves per channel instead of 5 loads.  The NEXT tile's loads are issued before
+    // this tile's products and stores (raw values only: arithmetic on a loaded value would make the wave wait where
+    // it is loaded); the bias comes from LDS and element offsets are 32-bit from the uniform base (the host checks the
+    // tensor's extent), so nothing else in the loop uses the memory counter or needs sixteen 64-bit addresses.
+    // (Tiles of one (b, f) row with the workgroup's waves on adjacent bins — 3-KB output runs instead of 98-KB-strided
+    // 384-byte chunks — measured slower: 0.72 against 0.63 ms.)
+    constexpr int NC = KP / 20;
+    const int isc = (int)sc, ist = (int)st, lane_c = NC * kq;
+    float cur[NC], halo[NC];
+    int t = 0;
+    float* dst = out;
+    bool pok = false;
+    auto fetch = [&](long long tile) {
+      const long long p = tile * 16 + n;
+      pok = p < npts;
+      const long long pc = pok ? p : npts - 1;
+      int f;
+      const long long row = divmod(pc, nt, t);                      // (b, f) row of the point
+      const long long b = divmod(row, nf, f);
+      const int rowoff = (int)b * (int)sb + f * (int)sf + lane_c * isc;
+      int off = rowoff + t * ist;
+      int hoff = off - (KE - 1) * ist;                              // halo point p - 4: same row, or the end of the row before
+      bool hok = n < KE - 1;
+      if (t < KE - 1) {
+        hok = hok && row >= 1;
+        int hf;
+        const long long hb = divmod(row >= 1 ? row - 1 : 0, nf, hf);
+        hoff = (int)hb * (int)sb + hf * (int)sf + lane_c * isc + (nt + t - (KE - 1)) * ist;
+      }
+      asm volatile("" : "+v"(off), "+v"(hoff));                     // not hoisted as NC separate offsets
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        cur[ci] = x[(unsigned)(lane_c + ci < cin ? off + ci * isc : 0)];
+        halo[ci] = 0.f;
+      }
+      if (hok) {
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) halo[ci] = x[(unsigned)(lane_c + ci < cin ? hoff + ci * isc : 0)];
+      }
+      dst = out + b * o_sb + t * o_st + f * o_sf + 4 * kq;
+    };
+    const long long stride = (long long)gridDim.x * 8;
+    long long tile = (long long)blockIdx.x * 8 + w;
+    if (tile < ntiles) fetch(tile);
+    while (tile < ntiles) {
+      float a[KP / 4];
+#pragma unroll
+      for (int ci = 0; ci < NC; ++ci) {
+        // all shifts first, with every lane active; then the per-lane choice (the lanes of a row share kq, hence cok)
+        const bool cok = lane_c + ci < cin;
+        const float cv = cok ? cur[ci] : 0.f, hv = cok ? halo[ci] : 0.f;
+        const float r1 = dpp_f<0x111>(cv), r2 = dpp_f<0x112>(cv), r3 = dpp_f<0x113>(cv), r4 = dpp_f<0x114>(cv);   // row_shr:1..4
+        const float h1 = dpp_f<0x103>(hv), h2 = dpp_f<0x102>(hv), h3 = dpp_f<0x101>(hv);                           // row_shl:3..1
+        a[KE * ci + 4] = cv;
+        a[KE * ci + 3] = t >= 1 ? (n >= 1 ? r1 : h1) : 0.f;
+        a[KE * ci + 2] = t >= 2 ? (n >= 2 ? r2 : h2) : 0.f;
+        a[KE * ci + 1] = t >= 3 ? (n >= 3 ? r3 : h3) : 0.f;
+        a[KE * ci + 0] = t >= 4 ? (n >= 4 ? r4 : hv) : 0.f;
+      }
+      v8bf_t ab[w_items<KP, true>()];
+      if constexpr (BF) pack_operand<KP>(a, ab);                     // once for both halves of the outputs
+      float* const dcur = dst;
+      const bool okc = pok;
+      const long long next = tile + stride;
+      if (next < ntiles) fetch(next);
+#pragma unroll
+      for (int j0 = 0; j0 < H / 16; j0 += 3) {
+        v4f_t acc[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          const float4 bv = *reinterpret_cast<const float4*>(ldsb + 16 * (j0 + jj) + 4 * kq);
+          acc[jj] = v4f_t{bv.x, bv.y, bv.z, bv.w};
+        }
+        if constexpr (BF)
+          mfma_tiles_packed<KP, 3>(ab, ldsw_lane, j0, acc);
+        else
+          mfma_tiles<KP, 3, false>(a, ldsw_lane, j0, acc);
+        if (okc) {
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj)
+            *reinterpret_cast<float4*>(dcur + 16 * (j0 + jj)) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
+        }
+      }
+      tile = next;
+    }
+    return;
+  }
+  if constexpr (!PIPE)
   for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
     const long long p = tile * 16 + n;
     const long long pc = p < npts ? p : npts - 1;
-    const int t = (int)(pc % nt);
-    const int f = (int)((pc / nt) % nf);
-    const long long b = pc / ((long long)nt * nf);
+    int t, f;
+    const long long row = divmod(pc, nt, t);                        // (b, f) row of the point
+    const long long b = divmod(row, nf, f);
     // K index k = kq * KQ + i is (channel, tap) = (KQ/5 * kq + i / 5, i % 5): KQ is a multiple of the 5 taps, so the
     // split is compile-time per i and an element offset is  lane part (channel block, frame) + a wave-uniform term —
     // 32-bit; the generic form (a division and a 64-bit multiply-add per element) cost more cycles than the MFMAs.
@@ -1154,57 +1313,10 @@ sn_encoder_mfma_kernel(const float* __restrict__ x, long long sb, long long sc, 
         if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
       }
     };
-    if (state_in) {
+    if (state_in)
       build(std::true_type{});
-    } else if (nt < KE - 1) {
+    else
       build(std::false_type{});
-    } else {
-      // Whole-signal case: ONE load per channel (the lane's current frame) plus, in the lanes n < 4, the frame of the
-      // point p - 4 (the halo of the tile); the other four taps of a lane are the current frames of its left neighbours,
-      // which are its own earlier frames whenever t >= shift (points are consecutive along t) — DPP row shifts within
-      // the tile's 16 lanes.  2 loads + 12 moves per channel instead of 5 loads: the build was bound by the number
-      // of load instructions (40 per lane and tile).
-      const float* hr = xr + (t - (KE - 1)) * ist;                   // halo point p - 4: same row, or the end of the row before
-      bool hok = n < KE - 1;
-      if (t < KE - 1) {
-        const long long sq = pc / nt - 1;
-        hok = hok && sq >= 0;
-        const long long sqc = sq >= 0 ? sq : 0;
-        hr = x + (sqc / nf) * sb + (sqc % nf) * sf + (nt + t - (KE - 1)) * ist;
-      }
-      float cur[KP / 20], halo[KP / 20];
-#pragma unroll
-      for (int ci = 0; ci < KP / 20; ++ci) {
-        const bool cok = lane_c + ci < cin;
-        cur[ci] = xr[cok ? lane_off + ci * isc : 0];
-        cur[ci] = cok ? cur[ci] : 0.f;
-        halo[ci] = 0.f;
-      }
-      if (hok) {
-#pragma unroll
-        for (int ci = 0; ci < KP / 20; ++ci) {
-          const bool cok = lane_c + ci < cin;
-          const float v = hr[cok ? (lane_c + ci) * isc : 0];
-          halo[ci] = cok ? v : 0.f;
-        }
-      }
-#pragma unroll
-      for (int ci = 0; ci < KP / 20; ++ci) {
-        a[KE * ci + KE - 1] = cur[ci];
-        // all shifts first, with every lane active; then the per-lane choice
-        const float r1 = dpp_f<0x111>(cur[ci]), r2 = dpp_f<0x112>(cur[ci]), r3 = dpp_f<0x113>(cur[ci]),
-                    r4 = dpp_f<0x114>(cur[ci]);                                    // row_shr:1..4
-        const float h1 = dpp_f<0x103>(halo[ci]), h2 = dpp_f<0x102>(halo[ci]), h3 = dpp_f<0x101>(halo[ci]);   // row_shl:3..1
-        const float s1 = n >= 1 ? r1 : h1;
-        const float s2 = n >= 2 ? r2 : h2;
-        const float s3 = n >= 3 ? r3 : h3;
-        const float s4 = n >= 4 ? r4 : halo[ci];
-        a[KE * ci + 3] = t >= 1 ? s1 : 0.f;
-        a[KE * ci + 2] = t >= 2 ? s2 : 0.f;
-        a[KE * ci + 1] = t >= 3 ? s3 : 0.f;
-        a[KE * ci + 0] = t >= 4 ? s4 : 0.f;
-      }
-    }
     float* dst = out + b * o_sb + t * o_st + f * o_sf + 4 * kq;
 #pragma unroll
     for (int j0 = 0; j0 < H / 16; j0 += 3) {
@@ -1535,9 +1647,8 @@ sn_head_mfma_kernel(fnssl_btf_view xv, int nt2, int nfc, long long npts, const f
   for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
     const long long p = tile * 16 + n;
     const long long pc = p < npts ? p : npts - 1;
-    const int fc = (int)(pc % nfc);
-    const int t2 = (int)((pc / nfc) % nt2);
-    const long long b = pc / ((long long)nfc * nt2);
+    int fc, t2;
+    const long long b = divmod(divmod(pc, nfc, fc), nt2, t2);
     const float4* row = reinterpret_cast<const float4*>(xv.p + b * xv.sb + t2 * xv.st + fc * xv.sf + q * (H / 4));
     float a[H / 4];
 #pragma unroll
@@ -1644,23 +1755,31 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
     // the matrix-pipe kernel addresses a (b, f) row's channels and frames with 32-bit element offsets
     const bool off32 = (long double)cin * (x_sc < 0 ? -x_sc : x_sc) + (long double)nt * (x_st < 0 ? -x_st : x_st) < 2.0e9L &&
                        (long double)cin * nf * (KE - 1) + nt < 2.0e9L;
+    // the whole-signal kernel addresses every element as a non-negative 32-bit offset from x
+    const bool pos32 = x_sb >= 0 && x_sc >= 0 && x_sf >= 0 && x_st >= 0 &&
+                       (long double)nb * x_sb + (long double)cin * x_sc + (long double)nf * x_sf + (long double)nt * x_st < 2.0e9L;
     const bool bf = precision == FNSSL_PRECISION_BF16;
     FNSSL_REQUIRE(!bf || (kk <= 160 && off32), "sn_encoder: FNSSL_PRECISION_BF16 needs cin * 5 <= 160 (cin %d) and 32-bit offsets",
                   cin);
     if ((bf || !getenv("FNSSL_SN_SCALAR")) && kk <= 160 && off32) {
+#define FNSSL_SN_ENC_P(KP, BF, PIPE)                                                                                \
+  do {                                                                                                              \
+    const size_t lds = (size_t)(w_lds_floats<KP, H, BF>() + H) * sizeof(float);                                     \
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP, BF, PIPE>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    hipLaunchKernelGGL((sn_encoder_mfma_kernel<KP, BF, PIPE>), dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, \
+                       x_sc, x_sf, x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);             \
+  } while (0)
 #define FNSSL_SN_ENC(KP, BF)                                                                                        \
   do {                                                                                                              \
-    const size_t lds = (size_t)w_lds_floats<KP, H, BF>() * sizeof(float);                                           \
-    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_encoder_mfma_kernel<KP, BF>),                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-    hipLaunchKernelGGL((sn_encoder_mfma_kernel<KP, BF>), dim3(mfma_grid(npts, 2)), dim3(512), lds, s, x, x_sb, x_sc, \
-                       x_sf, x_st, cin, nf, nt, npts, wT, bias, state_in, out, o_sb, o_st, o_sf);                   \
+    if (!state_in && nt >= KE - 1 && pos32) FNSSL_SN_ENC_P(KP, BF, true); else FNSSL_SN_ENC_P(KP, BF, false);       \
   } while (0)
       if (kk <= 80) {
         if (bf) FNSSL_SN_ENC(80, true); else FNSSL_SN_ENC(80, false);
       } else {
         if (bf) FNSSL_SN_ENC(160, true); else FNSSL_SN_ENC(160, false);
       }
+#undef FNSSL_SN_ENC_P
 #undef FNSSL_SN_ENC
     } else {
       hipLaunchKernelGGL(sn_encoder_kernel, dim3(blocks_of(npts)), dim3(256), 0, s, x, x_sb, x_sc, x_sf, x_st, cin, nf, nt,

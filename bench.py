@@ -432,9 +432,15 @@ class Ipdnet2Forward:
             return None
         on_bf16 = not self.fp32 and (dom in ("sn_encoder", "sn_mamba_in", "sn_mamba_xproj", "sn_mamba_out") or
                                      dom.startswith("sn_fconv"))
-        return kernel_roof(kern, dom, "%s (dominant kernel of the step%s)" % (dom, ", bf16 MFMA operands" if on_bf16 else
-                                                                              ", fp32 arithmetic"),
-                           PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS)
+        r = kernel_roof(kern, dom, "%s (dominant kernel of the step%s)" % (dom, ", bf16 MFMA operands" if on_bf16 else
+                                                                           ", fp32 arithmetic"),
+                        PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS)
+        if r is not None and dom == "sn_mamba_scan":
+            r["note"] = ("the selective scan has no matrix product: per (sequence, channel, step) 16 decays exp2(dt*A_n) + softplus + "
+                         "SiLU = 22 quarter-rate transcendentals (352 issue cycles per wave) next to ~60 packed / scalar fp32 "
+                         "instructions (~250 cycles); its ceiling is VALU issue, ~0.25 of the fp32 roof quoted here, and the "
+                         "3 072 waves of a launch (1 024 sequences x 192 channels) are 3 per SIMD (DESIGN section 10)")
+        return r
 
     def cpu_baseline(self):
         from oracle import ipdnet2_oracle as O2

@@ -448,6 +448,12 @@ __device__ __forceinline__ void fill_w_lds(float* lds, const float* __restrict__
   fill_w_lds_strided<K, N, BD, BF>(lds, wT, ldw, 1, kvalid, nvalid);
 }
 
+// lane n of a 16-lane row reads lane n - j (row_shr:j = 0x110 + j) or n + j (row_shl:j = 0x100 + j); 0 outside the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // bf16: the lane's K/4 values as ceil(K/32) packed operands (done once when several calls share them)
 template <int K>
 __device__ __forceinline__ void pack_operand(const float (&a)[K / 4], v8bf_t (&b)[w_items<K, true>()]) {
@@ -1085,6 +1091,72 @@ sn_mamba_xproj_mfma_kernel(const float* __restrict__ u, long long npts, const fl
   }
 }
 
+// Mamba, phases 2a + 2b in one pass (whole sequences, no carried taps): dbl[p, 0:40] = x_proj(SiLU(conv4(xi)))(p).
+// A tile = 16 consecutive frames t0 .. t0 + 15 of ONE sequence with t0 = 13 k - 3: the lanes n >= 3 are the tile's 13
+// outputs, the lanes 0..2 only carry the three frames before them — every tap of the depthwise conv is then the own
+// frame of a left neighbour (DPP row shifts), frames before the start of the sequence load as zero, and nothing is
+// masked.  u is NOT written: the scan recomputes it from xz (4 FMAs + SiLU per step, have_u = 0), which is cheaper
+// than a 2 x 197-MB round trip and a launch.  Conv taps / bias of the lane's 48 channels come from an LDS image
+// (four addresses per read: the 16 lanes of a row share kq).
+template <bool BF>
+__global__ void __launch_bounds__(512)
+sn_mamba_convx_mfma_kernel(const float* __restrict__ xz, int nt, long long nseq, const float* __restrict__ conv_w,
+                           const float* __restrict__ conv_b, const float* __restrict__ wxT, float* __restrict__ dbl) {
+  constexpr int XN = 48, OUTS = 16 - (KC - 1);
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];
+  float* ldcw = ldsw + w_lds_floats<E, XN, BF>();                   // [E][4] taps, then [E] bias
+  float* ldcb = ldcw + E * KC;
+  fill_w_lds<E, XN, 512, BF>(ldsw, wxT, XP, E, XP);
+  for (int i = threadIdx.x; i < E * KC; i += 512) ldcw[i] = conv_w[i];
+  if (threadIdx.x < E) ldcb[threadIdx.x] = conv_b[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+  const float* ldsw_lane = ldsw + lane * 4;
+  const int tps = (nt + OUTS - 1) / OUTS;                           // tiles per sequence
+  const long long ntiles = nseq * tps;
+  for (long long tile = (long long)blockIdx.x * 8 + w; tile < ntiles; tile += (long long)gridDim.x * 8) {
+    int k;
+    const long long sq = divmod(tile, tps, k);                      // wave-uniform
+    const int t = OUTS * k - (KC - 1) + n;
+    const bool in = t >= 0 && t < nt;
+    const long long p = sq * nt + (in ? t : 0);
+    const float4* row = reinterpret_cast<const float4*>(xz + p * (2 * E) + kq * (E / 4));
+    float4 xi[E / 16];
+#pragma unroll
+    for (int i = 0; i < E / 16; ++i) xi[i] = row[i];                // raw (a frame outside the sequence is zeroed below)
+    float a[E / 4];
+#pragma unroll
+    for (int i = 0; i < E / 16; ++i) {
+      const float x3[4] = {in ? xi[i].x : 0.f, in ? xi[i].y : 0.f, in ? xi[i].z : 0.f, in ? xi[i].w : 0.f};
+      const float4 cb4 = *reinterpret_cast<const float4*>(ldcb + kq * (E / 4) + 4 * i);
+      const float cbv[4] = {cb4.x, cb4.y, cb4.z, cb4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 cw = *reinterpret_cast<const float4*>(ldcw + (kq * (E / 4) + 4 * i + c) * KC);
+        const float x2 = dpp_f<0x111>(x3[c]), x1 = dpp_f<0x112>(x3[c]), x0 = dpp_f<0x113>(x3[c]);   // frames t-1, t-2, t-3
+        float u = cbv[c];
+        u = fmaf(cw.x, x0, u);
+        u = fmaf(cw.y, x1, u);
+        u = fmaf(cw.z, x2, u);
+        u = fmaf(cw.w, x3[c], u);
+        a[4 * i + c] = silu_f(u);
+      }
+      asm volatile("" ::: "memory");                                // the 48 tap reads are not all hoisted to the top
+    }
+    v4f_t acc[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) acc[jj] = v4f_t{0.f, 0.f, 0.f, 0.f};
+    mfma_tiles<E, 3, BF>(a, ldsw_lane, 0, acc);
+    if (in && n >= KC - 1) {
+      float* dst = dbl + p * XP + 4 * kq;
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+        if (16 * jj + 4 * kq < XP)
+          *reinterpret_cast<float4*>(dst + 16 * jj) = make_float4(acc[jj][0], acc[jj][1], acc[jj][2], acc[jj][3]);
+    }
+  }
+}
+
 // Mamba, phase 4 on the matrix pipe: out = pool_T(x) + out_proj(pool_T(y)),  p = s*nt2 + t2.
 // TP = the time pooling when it is 1 or 5 (0: any, taken from tp_rt): a run-time trip count left the pooled frames as
 // 60 dependent load - wait - add round trips per tile (237 us for layer 0's pooled block against 141 us for the
@@ -1162,12 +1234,6 @@ sn_mamba_out_mfma_kernel(const float* __restrict__ ybuf, fnssl_btf_view xv, int 
       if (TP >= 4) asm volatile("" ::: "memory");                  // not both halves' 30 residual loads at once
     }
   }
-}
-
-// lane n of a 16-lane row reads lane n - j (row_shr:j = 0x110 + j) or n + j (row_shl:j = 0x100 + j); 0 outside the row
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
 // Encoder on the matrix pipe: K = cin * 5 taps (c-major) padded to KP (80 or 160: KP / 4 a multiple of the 5 taps);
@@ -1943,7 +2009,18 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   }
   {
     fnssl::TimedLaunch tl("sn_mamba_xproj", s, 2.0 * npts * E * (XP - 2 + KC));
-    if (mfma) {
+    if (mfma && !carry) {                                 // whole sequences: conv + x_proj in one pass, u not materialised
+      const long long tiles = nseq * ((nt + 12) / 13);
+      if (bf) {
+        constexpr size_t lds = (size_t)(w_lds_floats<E, 48, true>() + E * KC + E) * sizeof(float);
+        hipLaunchKernelGGL(sn_mamba_convx_mfma_kernel<true>, dim3(mfma_grid(tiles * 16, 4)), dim3(512), lds, s, m.xz, nt, nseq,
+                           w->conv_w, w->conv_b, w->wxT, m.dbl);
+      } else {
+        constexpr size_t lds = (size_t)(w_lds_floats<E, 48, false>() + E * KC + E) * sizeof(float);
+        hipLaunchKernelGGL(sn_mamba_convx_mfma_kernel<false>, dim3(mfma_grid(tiles * 16, 4)), dim3(512), lds, s, m.xz, nt, nseq,
+                           w->conv_w, w->conv_b, w->wxT, m.dbl);
+      }
+    } else if (mfma) {
       const long long nq = npts * (E / 4);
       FNSSL_REQUIRE(blocks_of(nq) < (1u << 31), "sn_mamba: too many points");
       hipLaunchKernelGGL(sn_mamba_conv_kernel, dim3(blocks_of(nq)), dim3(256), 0, s, m.xz, nt, npts, w->conv_w, w->conv_b,
@@ -1966,7 +2043,7 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   {
     fnssl::TimedLaunch tl("sn_mamba_scan", s, (double)npts * E * (7.0 * NST + 2 * RK + 2 * KC));
     hipLaunchKernelGGL(sn_mamba_scan_kernel, dim3((unsigned)nseq), dim3(E), 0, s, m.xz, m.dbl, nt, w->conv_w, w->conv_b,
-                       w->wdt, w->bdt, w->a, w->d, conv_state, ssm_state, carry, m.y, mfma ? 1 : 0);
+                       w->wdt, w->bdt, w->a, w->d, conv_state, ssm_state, carry, m.y, mfma && carry ? 1 : 0);
     FNSSL_CHECK_LAUNCH("sn_mamba_scan_kernel");
   }
   {

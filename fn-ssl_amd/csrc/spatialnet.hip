@@ -637,13 +637,14 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
   const int fr = pt >> lg_nf, f = pt & (nf - 1);
   const int rows = nf + 4;
   // patch element k = 16 q + i of a group = (tap k / 12, channel k % 12): 12 is a multiple of 4, so the lane's 16
-  // elements are four aligned float4 of the image (offset tap * YS + channel from the bin's row - 2); k >= 60 is padding
+  // elements are four aligned float4 of the image (offset tap * YS + channel from the bin's row - 2); k >= 60 is padding:
+  // its weights are zero, so it reads the (initialised, finite) start of the row instead of being masked per value
   int poff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = 16 * q + 4 * j;
     const int tap = (k * 171) >> 11;                               // k / 12 for k < 64
-    poff[j] = k < KF * CG ? tap * YS + (k - CG * tap) : -1;
+    poff[j] = k < KF * CG ? tap * YS + (k - CG * tap) : 0;
   }
   float* yrow = ytile + (fr * rows + f + 2) * YS + 4 * q;
   const float* ybase = ytile + (fr * rows + f) * YS;
@@ -689,33 +690,38 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
     int t;
     const long long b = divmod(frame, nt, t);
     // LayerNorm over the bin's 96 channels: 32 in each of the lanes q = 0..2 (q = 3 holds zeros)
-    float sum = 0.f;
+    // (two channels per instruction: the kernel is bound by instruction issue, counters in profiles/r02/m_)
+    v2f_t sum2 = {0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < NG; ++g) sum += (xr[g][0] + xr[g][1]) + (xr[g][2] + xr[g][3]);
+    for (int g = 0; g < NG; ++g) sum2 += v2f_t{xr[g][0], xr[g][1]} + v2f_t{xr[g][2], xr[g][3]};
+    float sum = sum2[0] + sum2[1];
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float mean = sum * (1.f / H);
-    float var = 0.f;
+    const v2f_t mean2 = {mean, mean};
+    v2f_t var2 = {0.f, 0.f};
     if (q < 3) {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = xr[g][r] - mean;
-          var = fmaf(d, d, var);
+        for (int h = 0; h < 2; ++h) {
+          const v2f_t d = v2f_t{xr[g][2 * h], xr[g][2 * h + 1]} - mean2;
+          var2 = __builtin_elementwise_fma(d, d, var2);
         }
     }
+    float var = var2[0] + var2[1];
     var += __shfl_xor(var, 16, 64);
     var += __shfl_xor(var, 32, 64);
     const float rstd = 1.f / sqrtf(var * (1.f / H) + kEps);
+    const v2f_t rstd2 = {rstd, rstd};
     if (q < 3) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const float4 lw = *reinterpret_cast<const float4*>(par + CG * g + 4 * q);
         const float4 lb = *reinterpret_cast<const float4*>(par + H + CG * g + 4 * q);
-        *reinterpret_cast<float4*>(yrow + CG * g) =
-            make_float4((xr[g][0] - mean) * rstd * lw.x + lb.x, (xr[g][1] - mean) * rstd * lw.y + lb.y,
-                        (xr[g][2] - mean) * rstd * lw.z + lb.z, (xr[g][3] - mean) * rstd * lw.w + lb.w);
+        const v2f_t y0 = __builtin_elementwise_fma((v2f_t{xr[g][0], xr[g][1]} - mean2) * rstd2, v2f_t{lw.x, lw.y}, v2f_t{lb.x, lb.y});
+        const v2f_t y1 = __builtin_elementwise_fma((v2f_t{xr[g][2], xr[g][3]} - mean2) * rstd2, v2f_t{lw.z, lw.w}, v2f_t{lb.z, lb.w});
+        *reinterpret_cast<float4*>(yrow + CG * g) = make_float4(y0[0], y0[1], y1[0], y1[1]);
       }
     }
     __syncthreads();
@@ -725,8 +731,7 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
       float a[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (poff[j] >= 0) v = *reinterpret_cast<const float4*>(ybase + CG * g + poff[j]);
+        const float4 v = *reinterpret_cast<const float4*>(ybase + CG * g + poff[j]);
         a[4 * j] = v.x;
         a[4 * j + 1] = v.y;
         a[4 * j + 2] = v.z;
@@ -739,11 +744,13 @@ sn_fconv_mfma_kernel(fnssl_btf_view xv, int nt, int nf, int lg_nf, long long nfr
         const float4 pv = *reinterpret_cast<const float4*>(par + 3 * H + CG * g + 4 * q);
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[0][r] + bb[r];
-          v = v >= 0.f ? v : pp[r] * v;
-          float& xs = xr[g][r];
-          xs = residual ? xs + v : v;
+        for (int h = 0; h < 2; ++h) {
+          const v2f_t v = v2f_t{acc[0][2 * h], acc[0][2 * h + 1]} + v2f_t{bb[2 * h], bb[2 * h + 1]};
+          const v2f_t nv = v2f_t{pp[2 * h], pp[2 * h + 1]} * v;
+          v2f_t o = {v[0] >= 0.f ? v[0] : nv[0], v[1] >= 0.f ? v[1] : nv[1]};
+          if (residual) o += v2f_t{xr[g][2 * h], xr[g][2 * h + 1]};
+          xr[g][2 * h] = o[0];
+          xr[g][2 * h + 1] = o[1];
         }
       }
     }

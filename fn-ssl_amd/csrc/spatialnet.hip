@@ -1885,8 +1885,8 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl(nf > 128 ? "sn_fconv_f256" : (nf > 16 ? "sn_fconv_f128" : "sn_fconv_f16"), s,
                         2.0 * nframes * nf * H * CG * KF);
-  const bool bf = precision == FNSSL_PRECISION_BF16;
-  FNSSL_REQUIRE(!bf || nf >= 16, "sn_fconv: FNSSL_PRECISION_BF16 needs nf >= 16, got %d", nf);
+  // below 16 bins there is no matrix-pipe kernel: the product stays exact fp32 in both modes (include/fnssl.h)
+  const bool bf = precision == FNSSL_PRECISION_BF16 && nf >= 16;
   const bool mfma = (bf || !getenv("FNSSL_SN_SCALAR")) && nf >= 16;
   const size_t lds = (size_t)(NG * (bf ? w_lds_floats<64, 16, true>() : w_lds_floats<64, 16, false>()) + 4 * H +
                               (256 + 4 * (256 >> lg)) * 100) * sizeof(float);
@@ -1931,8 +1931,8 @@ int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_s
   FNSSL_REQUIRE(nblk < (1ll << 31), "sn_full: too many frames");
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl("sn_full", s, 2.0 * nframes * nf * (2.0 * H * HS + (double)HS * nf));
-  const bool bf = precision == FNSSL_PRECISION_BF16;
-  FNSSL_REQUIRE(!bf || nf == 16 || nf == 64 || nf == 128, "sn_full: FNSSL_PRECISION_BF16 needs nf 16, 64 or 128, got %d", nf);
+  // the matrix-pipe kernel exists for 16, 64 and 128 bins; elsewhere the products stay exact fp32 in both modes
+  const bool bf = precision == FNSSL_PRECISION_BF16 && (nf == 16 || nf == 64 || nf == 128);
   const bool mfma = (bf || !getenv("FNSSL_SN_SCALAR")) && (nf == 16 || nf == 64 || nf == 128);
   if (mfma) {
     const long long cus = fnssl::device_cus();

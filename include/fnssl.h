@@ -479,9 +479,11 @@ int fnssl_sn_layernorm(const float* x, long long rows, int h, const float* w, co
  *   precision  FNSSL_PRECISION_FP32 (exact fp32 MFMA), or FNSSL_PRECISION_BF16: both operands of the product
  *              are rounded to bf16 (nearest even) as they enter the matrix pipe, fp32 accumulation, fp32
  *              tensors — BASELINE config 5 as written; needs cin * 5 <= 160.  The same argument of
- *              fnssl_sn_fconv (the grouped conv), fnssl_sn_full (squeeze, Linear over F, unsqueeze; nf 16, 64
- *              or 128) and fnssl_sn_mamba (in_proj, x_proj, out_proj) means the same; LayerNorm, biases and
- *              activations, the depthwise conv, dt_proj, the scan and the head are fp32 in both modes.
+ *              fnssl_sn_fconv (the grouped conv; nf >= 16), fnssl_sn_full (squeeze, Linear over F, unsqueeze;
+ *              nf 16, 64 or 128) and fnssl_sn_mamba (in_proj, x_proj, out_proj) means the same — at other
+ *              nf these two have no matrix-pipe kernel and compute in exact fp32 whatever the argument;
+ *              LayerNorm, biases and activations, the depthwise conv, dt_proj, the scan and the head are fp32
+ *              in both modes.
  */
 int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x_sf, long long x_st,
                      int nb, int cin, int nf, int nt, const float* wT, const float* bias,

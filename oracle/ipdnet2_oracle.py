@@ -41,13 +41,33 @@ class bf16_products:
     """``with bf16_products():`` restates FNSSL_PRECISION_BF16 (include/fnssl.h, fnssl_sn_encoder): BOTH operands of the
     encoder conv, the grouped frequency conv, the three products of the full-band branch (squeeze, Linear over F,
     unsqueeze) and the Mamba in / x / out projections are rounded to bf16 where they enter the product; accumulation,
-    biases, activations, LayerNorm, the depthwise conv, dt_proj, the scan, FreqInverse and the decoder stay fp32.  (In layer 0 the device applies the 5x time pooling to the operand of
+    biases, activations, LayerNorm, the depthwise conv, dt_proj, the scan, FreqInverse and the decoder stay fp32.
+    As on the device, the frequency conv below 16 bins and the full-band branch at other than 16 / 64 / 128 bins have
+    no bf16 form and stay exact (only networks with fewer than 256 bins get there).  (In layer 0 the device applies the 5x time pooling to the operand of
     out_proj before it is rounded, this restatement after the product — the same rounding noise, not the same bits.)"""
 
     def __enter__(self):
         global _BF16
         self._old, _BF16 = _BF16, True
         return self
+
+    def __exit__(self, *exc):
+        global _BF16
+        _BF16 = self._old
+        return False
+
+
+class _exact_if:
+    """Switches the bf16 rounding off inside the block when ``cond`` (shapes without a bf16 kernel on the device)."""
+
+    def __init__(self, cond):
+        self.cond = cond
+
+    def __enter__(self):
+        global _BF16
+        self._old = _BF16
+        if self.cond:
+            _BF16 = False
 
     def __exit__(self, *exc):
         global _BF16
@@ -123,7 +143,8 @@ def fconv(sd, p, x, groups=8):
     y = layer_norm(x, sd[p + ".0.weight"], sd[p + ".0.bias"])          # LN over H at every (b, f, t)
     B, F, T, H = y.shape
     y = y.transpose(0, 2, 3, 1).reshape(B * T, H, F)
-    y = grouped_conv_same(y, sd[p + ".1.weight"], sd[p + ".1.bias"], groups)
+    with _exact_if(F < 16):
+        y = grouped_conv_same(y, sd[p + ".1.weight"], sd[p + ".1.bias"], groups)
     a = _f(sd[p + ".2.weight"])[None, :, None]
     y = np.where(y >= 0, y, a * y).astype(F32)                           # PReLU, one slope per channel
     return y.reshape(B, T, H, F).transpose(0, 3, 1, 2)
@@ -134,11 +155,12 @@ def full(sd, p, x):
     x = _f(x)
     y = layer_norm(x, sd[p + "norm_full.weight"], sd[p + "norm_full.bias"])
     ws, bs = _f(sd[p + "squeeze.0.weight"])[:, :, 0], _f(sd[p + "squeeze.0.bias"])
-    s = silu(np.einsum("bfth,qh->bftq", _q(y), _q(ws)).astype(F32) + bs)        # [B, F, T, H']
-    wf, bf = _f(sd[p + "full.weight"]), _f(sd[p + "full.bias"])
-    s = (np.einsum("bftq,gf->bgtq", _q(s), _q(wf)).astype(F32) + bf[None, :, None, None]).astype(F32)   # Linear over F
-    wu, bu = _f(sd[p + "unsqueeze.0.weight"])[:, :, 0], _f(sd[p + "unsqueeze.0.bias"])
-    return silu(np.einsum("bftq,hq->bfth", _q(s), _q(wu)).astype(F32) + bu)
+    with _exact_if(x.shape[1] not in (16, 64, 128)):
+        s = silu(np.einsum("bfth,qh->bftq", _q(y), _q(ws)).astype(F32) + bs)        # [B, F, T, H']
+        wf, bf = _f(sd[p + "full.weight"]), _f(sd[p + "full.bias"])
+        s = (np.einsum("bftq,gf->bgtq", _q(s), _q(wf)).astype(F32) + bf[None, :, None, None]).astype(F32)   # Linear over F
+        wu, bu = _f(sd[p + "unsqueeze.0.weight"])[:, :, 0], _f(sd[p + "unsqueeze.0.bias"])
+        return silu(np.einsum("bftq,hq->bfth", _q(s), _q(wu)).astype(F32) + bu)
 
 
 def avgpool_f(x, k):

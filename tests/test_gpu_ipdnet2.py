@@ -226,8 +226,9 @@ def test_matrix_pipe_kernels_equal_scalar_kernels_at_ragged_sizes(dev, monkeypat
 
 
 # ------------------------------------------------------------------------------------------------------------ #
-# FNSSL_PRECISION_BF16 (BASELINE config 5 as written): bf16 MFMA operands in the encoder, the grouped frequency conv
-# and the Mamba in / x / out projections; fp32 accumulation, fp32 tensors, everything else fp32.  No reference exists
+# FNSSL_PRECISION_BF16 (BASELINE config 5 as written): bf16 MFMA operands in the encoder, the grouped frequency conv,
+# the full-band branch and the Mamba in / x / out projections; fp32 accumulation, fp32 tensors, everything else fp32
+# (LayerNorm, biases / activations, depthwise conv, dt_proj, scan, FreqInverse, decoder).  No reference exists
 # for it: the kernels are held (i) to the oracle's restatement of exactly this rounding
 # (ipdnet2_oracle.bf16_products) at BF_RTOL / BF_ATOL per op — differences are operands that sit within one fp32
 # rounding of a bf16 tie and fall to the other side (measured: 1e-6 typical, 8e-4 where one flips; outputs O(1)) — and
@@ -286,8 +287,6 @@ def test_bf16_ops_vs_oracle_restating_the_rounding(dev):
             want = x + O2.full(sd, lp, x)
         assert_close(got, want, BF_RTOL, BF_ATOL, "full bf16 nf %d" % nf)
         assert np.abs(got - (x + O2.full(sd, lp, x))).max() > 1e-6, "bf16 mode did not change the product"
-    with pytest.raises(RuntimeError):
-        sn.full(to_dev(rs_randn(1, (1, 32, 2, 96)), dev), w0[1], precision=sn.BF16)   # no bf16 kernel at 32 bins
     # Mamba block: LN + in_proj / x_proj / out_proj on bf16 operands, scan fp32; + residual + time pooling; streaming
     x = rs_randn(2520, (3, 35, 96))
     xs = to_dev(x, dev).unsqueeze(0)
@@ -367,3 +366,27 @@ def test_bf16_config5_full_batch_independence_and_closeness_to_fp32(dev):
     assert outside < 1e-5, "fraction outside rtol %g / atol %g: %.2e" % (NET_LOOSE_RTOL, NET_LOOSE_ATOL, outside)
     assert err.max().item() < 5e-2, "max abs deviation from the fp32 kernels %.3e" % err.max().item()
     assert err.pow(2).mean().sqrt().item() < 4e-3
+
+
+@pytest.mark.parametrize("nb,nf,nt,layers", [(1, 256, 5, 2), (3, 128, 15, 2), (2, 256, 35, 3)])
+def test_bf16_network_at_ragged_sizes_and_128_bins(dev, nb, nf, nt, layers):
+    """The bf16 kernels at point counts that are not multiples of the 16-point tiles (and of the 13-output tiles of the
+    fused conv + x_proj pass), a 128-bin network (full-band kernel at 64 bins) and a single short utterance: against the
+    oracle's restatement of the rounding, and streamed (carried encoder / conv / scan state: the two-kernel conv path)
+    against whole."""
+    from oracle import ipdnet2_oracle as O2
+    sd, net = build_net(dev, 2800 + nf + nt, dim_input=10, num_layers=layers, num_freqs=nf)
+    net = net.bfloat16()
+    x = rs_randn(2801 + nt, (nb, 10, nf, nt), 0.7)
+    xd = to_dev(x, dev)
+    whole = net(xd)
+    assert tuple(whole.shape) == (nb, nt // 5, 2 * nf, 4, 2)
+    with O2.bf16_products():
+        want = O2.forward(_bf16_sd(sd), x, fre_compression_ratio=16)
+    assert_close(whole.cpu().numpy(), want, NET_BF_RTOL, NET_BF_ATOL, "bf16 network nf %d nt %d" % (nf, nt))
+    st, outs, t0 = None, [], 0
+    for n in ([5] * (nt // 5)):
+        o, st = net.forward_stream(xd[..., t0:t0 + n], st)
+        outs.append(o)
+        t0 += n
+    assert (torch.cat(outs, 1) - whole).abs().max().item() <= 2e-5

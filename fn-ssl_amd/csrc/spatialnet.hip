@@ -17,6 +17,14 @@
 // Every kernel takes strided [B, T, F, 96] views (channels contiguous), so the reference's permutes
 // (:222-233, :235-253, :333-335, :355-364) are never materialised and the residual adds, the frequency /
 // time poolings and the activations are fused into the producing kernel.
+//
+// That first formulation survives as the scalar-operand kernels below (FNSSL_SN_SCALAR=1: the A/B reference the
+// tests pin to the oracle and to the reference fixtures).  What runs by default is the second one, further down
+// ("Dense layers on the matrix pipe"): a wave owns 16 points, the layer's weights sit in LDS as MFMA A operands
+// for the whole launch, exact fp32 (v_mfma_f32_16x16x4_f32) or — FNSSL_PRECISION_BF16, BASELINE config 5 as
+// written — bf16 operands with fp32 accumulation (v_mfma_f32_16x16x32_bf16); taps along time (encoder, the
+// depthwise conv in front of x_proj) are DPP row shifts between the 16 lanes of a tile.  DESIGN.md section 10
+// has the measurements that led from one to the other.
 #include <cstdlib>
 #include <type_traits>
 

@@ -131,6 +131,9 @@ def test_mamba_block_vs_oracle_and_streaming(dev):
     # residual + time pooling (layer 0's tail): pool_T(x + branch)
     got = sn.mamba(xs, w[3], residual=True, time_pool=5).cpu().numpy()
     assert_close(got, O2.avgpool_t(x[None] + want, 5), RTOL, ATOL, "Mamba + residual + time pool")
+    for tp in (2, 3):                                                    # the generic (run-time) pooling instantiation
+        got = sn.mamba(xs, w[3], residual=True, time_pool=tp).cpu().numpy()
+        assert_close(got, O2.avgpool_t(x[None] + want, tp), RTOL, ATOL, "Mamba + residual + time pool %d" % tp)
     # carried state: chunks of 4 + 1 + 12 frames == whole sequence
     st = sn.mamba_state(1, 3, dev)
     parts, t0 = [], 0

@@ -166,6 +166,12 @@ def test_ipdnet2_dropin_keeps_reference_names_and_rejects_cpu():
     with pytest.raises(NotImplementedError):
         M.OnlineSpatialNet(dim_input=10, dim_output=16, num_layers=2, dim_hidden=96, dim_squeeze=8, num_freqs=256,
                            attention="mhsa(251)")
+    # .bfloat16() is what selects FNSSL_PRECISION_BF16 (BASELINE config 5), for the network and for every layer
+    from fnssl import spatialnet as sn
+    assert M._prec(net) == sn.FP32 == 0 and M._prec(net.layers[0]) == sn.FP32
+    net = net.bfloat16()
+    assert M._prec(net) == sn.BF16 == 1 and M._prec(net.layers[1]) == sn.BF16 and M._prec(net.encoder) == sn.BF16
+    assert _lib.SnNet.precision.offset > _lib.SnNet.bd.offset         # the field the C side reads last in fnssl_sn_net
 
 
 def test_predict_cli_accepts_the_reference_flag_surface():

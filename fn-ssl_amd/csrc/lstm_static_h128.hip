@@ -64,12 +64,14 @@ int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream
   TRY(16, 2, 16, 0, 1, 7, 2, kHas2 | kSum)
   TRY(12, 4, 16, 0, 1, 9, 1, kHas2 | kSum)
   TRY(8, 4, 16, 0, 1, 7, 2, kHas2 | kSum)
-  // smaller launches (fewer than 14 waves per CU): 13 / 12 / 8 / 4 waves per workgroup
+  // smaller launches (fewer than 14 waves per CU): 13 / 12 / 8 / 4 waves per workgroup.  12 waves: 27 virtual quads = 3
+  // chunks of 9 (one full round of 3 000 groups: 36.8 ms, against 37.1 ms with 5 chunks of 5 — and 48.9 ms for a round
+  // of 16-wave workgroups: a round is paced by its fullest SIMD, 3 waves against 4)
   TRY(13, 4, 16, 0, 0, 13, 1, kSum)
   TRY(13, 4, 16, 0, 0, 13, 1, 0)
-  TRY(12, 2, 16, 0, 0, 5, 0, kSum)
-  TRY(12, 2, 16, 0, 0, 5, 0, 0)
-  TRY(12, 2, 0, 1, 0, 5, 0, 0)
+  TRY(12, 4, 16, 0, 0, 9, 2, kSum)
+  TRY(12, 4, 16, 0, 0, 9, 2, 0)
+  TRY(12, 4, 0, 1, 0, 10, 0, 0)
   TRY(8, 4, 16, 0, 0, 7, 3, kSum)
   TRY(8, 4, 16, 0, 0, 7, 3, 0)
   TRY(8, 4, 0, 1, 0, 5, 0, 0)

@@ -460,51 +460,41 @@ class Ipdnet2Forward:
 WORKLOADS = {2: FnsslForward, 3: IpdnetForward, 4: FnsslTrain, 5: Ipdnet2Forward}
 
 
-def main():
-    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints a
-    # version banner at init) are pointed at stderr for the duration of the run
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks ourselves — one process per
+    GPU, RCCL — by re-executing this script through torch.distributed.run (the reference's equivalent: Lightning DDP
+    spawning one process per device, FN-SSL/Lightning/main.py:286-288).  Never falls back to fewer ranks: with fewer
+    than N visible devices it exits 2."""
+    import subprocess
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    shared = os.environ.get("FNSSL_BENCH_SHARED_GPU") == "1"      # test hook: N ranks on cuda:0 over gloo (see tests)
+    if ndev < args.gpus and not (shared and ndev >= 1):
+        log("--gpus %d but only %d ROCm device(s) visible: refusing to run with fewer ranks" % (args.gpus, ndev))
+        sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
     sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE.json configuration")
-    ap.add_argument("--nb", type=int, default=0, help="utterances per GPU (default: the configuration's batch)")
-    ap.add_argument("--nch", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=300)
-    ap.add_argument("--ch-mode", default="MM")
-    ap.add_argument("--chunk-pairs", type=int, default=0)
-    ap.add_argument("--offline", action="store_true", help="config 2: is_online=False (bidirectional narrow-band LSTM)")
-    ap.add_argument("--bf16", action="store_true",
-                    help="config 2, NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, "
-                         "fp32 accumulate/tensors); reported with dtype 'bf16' and its measured deviation")
-    ap.add_argument("--fp32", action="store_true", help="configs 3 and 5 in fp32 instead of bf16")
-    ap.add_argument("--c-step", action="store_true", help="config 4: the step as one C call (fnssl_train_step)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample (config 2)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample (config 2)")
-    args = ap.parse_args()
+    sys.exit(subprocess.call(cmd, env=env))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:       # launched by torch.distributed.run (also with one rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        log("rank %d: RCCL process group up, world size %d" % (rank, dist.get_world_size()))
 
+def run_workload(args, cfg, dev, rank, world, dist, backend, steps, warmup):
+    """Warm up, instrumented pass, timed region (barrier + synchronize on both sides, max over ranks), CPU baseline +
+    parity (rank 0, N = 1).  Returns (line dict on rank 0 / None elsewhere, parity_failed)."""
     from fnssl import ops
-    wl = WORKLOADS[args.config](args, dev, rank, world)
+    wl = WORKLOADS[cfg](args, dev, rank, world)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -513,13 +503,13 @@ def main():
             torch.cuda.synchronize()
 
     out = None
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = wl.step()
     sync_all()
     # Per-kernel breakdown: an instrumented pass of its own (every launch bracketed by HIP events), outside the timed
     # region — two event records per launch cost a 106-launch step (IPDnet2) 10 % of its time.  The timed region
     # below brackets only the roofline kernel, which is what `roofline.achieved` is computed from.
-    probe_steps = max(1, min(3, args.steps))
+    probe_steps = max(1, min(3, steps))
     ops.timing_select(None)
     ops.timing_enable(True)
     for _ in range(probe_steps):
@@ -531,9 +521,9 @@ def main():
     roof_name = roof_probe.get("name") if roof_probe else None
     ops.timing_select(roof_name)
     ops.timing_enable(roof_name is not None)     # HIP events on the launch stream around the roofline kernel only
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         ev[i][0].record()
         out = wl.step()
         ev[i][1].record()
@@ -543,20 +533,21 @@ def main():
     ops.timing_select(None)
     kern = ops.timing_collect()
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    log("rank %d: timed %d steps in %.3f s (median step %.3f ms by HIP events)" % (rank, args.steps, dt_local,
-                                                                                 step_ms[len(step_ms) // 2]))
-    dt, per_rank = dt_local, [round(dt_local / args.steps * 1e3, 3)]
+    log("config %d rank %d: timed %d steps in %.3f s (median step %.3f ms by HIP events)"
+        % (cfg, rank, steps, dt_local, step_ms[len(step_ms) // 2]))
+    dt, per_rank = dt_local, [round(dt_local / steps * 1e3, 3)]
     if dist is not None:
-        tmax = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([dt_local], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(allt, torch.tensor([dt_local], dtype=torch.float64, device=dev))
-        per_rank = [round(float(t.item()) / args.steps * 1e3, 3) for t in allt]
+        allt = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt_local], dtype=torch.float64, device=cdev))
+        per_rank = [round(float(t.item()) / steps * 1e3, 3) for t in allt]
     assert out is not None
     wl.check(out)
 
-    value = wl.frames_per_step * args.steps * world / dt
+    value = wl.frames_per_step * steps * world / dt
     roof = wl.roofline(kern) if roof_name else None      # from the events recorded inside the timed region
     if roof is not None:
         roof.pop("name", None)
@@ -569,18 +560,124 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, parity = wl.cpu_baseline()
     failed = parity is not None and not parity["ok"]
-
+    line = None
     if rank == 0:
         line = {
             "metric": wl.metric, "value": None if failed else round(value, 2), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
             "config": wl.config(), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "ms_per_step_median_hip_events": round(step_ms[len(step_ms) // 2], 3), "ms_per_step_per_rank": per_rank,
-            "rccl_world_size": dist.get_world_size() if dist is not None else 1, "kernels": breakdown,
+            "rccl_world_size": (dist.get_world_size() if backend == "nccl" else 0) if dist is not None else 1,
+            "backend": backend if dist is not None else None, "kernels": breakdown,
             "kernels_source": "separate instrumented pass of %d steps (every launch bracketed); the timed region brackets only the roofline kernel" % probe_steps,
         }
         line.update(extra)
+    # give the memory back before the next configuration (config 2 plans 90 GB, config 4 132 GB)
+    del wl, out
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line, failed
+
+
+def main():
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints a
+    # version banner at init) are pointed at stderr for the duration of the run
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(WORKLOADS), help="BASELINE.json configuration")
+    ap.add_argument("--other-configs", default=None,
+                    help="comma-separated configurations measured AFTER the primary one and nested under 'other_configs' "
+                         "of the same JSON line (default: 3,4,5 when the primary is the default config-2 headline run; "
+                         "'' = none); each runs its own BASELINE batch for at most --other-steps steps")
+    ap.add_argument("--other-steps", type=int, default=8)
+    ap.add_argument("--nb", type=int, default=0, help="utterances per GPU (default: the configuration's batch)")
+    ap.add_argument("--nch", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=300)
+    ap.add_argument("--ch-mode", default="MM")
+    ap.add_argument("--chunk-pairs", type=int, default=0)
+    ap.add_argument("--offline", action="store_true", help="config 2: is_online=False (bidirectional narrow-band LSTM)")
+    ap.add_argument("--bf16", action="store_true",
+                    help="config 2, NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, "
+                         "fp32 accumulate/tensors); reported with dtype 'bf16' and its measured deviation")
+    ap.add_argument("--fp32", action="store_true", help="configs 3 and 5 in fp32 instead of bf16")
+    ap.add_argument("--c-step", action="store_true", help="config 4: the step as one C call (fnssl_train_step)")
+    ap.add_argument("--features-in", action="store_true",
+                    help="config 5: start from features [B, 30, 256, T] already in HBM (round-2 behaviour) instead of waveforms")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample (config 2)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample (config 2)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)           # does not return
+
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the HIP path has no CPU fallback)")
+    shared = os.environ.get("FNSSL_BENCH_SHARED_GPU") == "1"      # test hook: all ranks on cuda:0, gloo instead of RCCL
+    if shared:
+        local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("%d ranks but only %d ROCm device(s) visible (one process per GPU)"
+                         % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist, backend = None, None
+    if world > 1 or "RANK" in os.environ:       # launched by torch.distributed.run (also with one rank)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if shared else "nccl"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        log("rank %d: %s process group up, world size %d" % (rank, "RCCL" if backend == "nccl" else backend,
+                                                             dist.get_world_size()))
+
+    others = args.other_configs
+    if others is None:
+        plain = not (args.nb or args.offline or args.bf16 or args.frames != 300 or args.nch != 4 or args.ch_mode != "MM"
+                     or args.chunk_pairs)
+        others = "3,4,5" if (args.config == 2 and plain) else ""
+    other_ids = [int(c) for c in others.split(",") if c.strip()]
+
+    line, failed = run_workload(args, args.config, dev, rank, world, dist, backend, args.steps, args.warmup)
+    nested = {}
+    for c in other_ids:
+        if c == args.config or c not in WORKLOADS:
+            continue
+        sub = argparse.Namespace(**vars(args))
+        sub.nb, sub.frames, sub.nch, sub.ch_mode, sub.chunk_pairs = 0, 300, 4, "MM", 0
+        sub.offline = sub.bf16 = sub.c_step = False
+        try:
+            l2, f2 = run_workload(sub, c, dev, rank, world, dist, backend, max(1, min(args.steps, args.other_steps)),
+                                  max(1, min(args.warmup, 2)))
+        except Exception as e:                                     # a secondary configuration must not lose the headline
+            log("config %d failed: %r" % (c, e))
+            l2, f2 = {"error": repr(e)}, False
+            if dist is not None:
+                raise
+        if l2 is not None:
+            nested[str(c)] = l2
+        if f2:
+            log("PARITY FAILED in config %d (its value is withheld; the headline stands)" % c)
+
+    if rank == 0:
+        if nested:
+            line["other_configs"] = nested
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()

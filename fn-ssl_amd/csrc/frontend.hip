@@ -31,9 +31,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
 
 // sig[b*sb + n*sn + c*sc] -> spec [nb, nch, nt, 257] (re, im), magsum [nb, nch, nt]
+// CENTER = torch.stft(center=True): frame t covers samples t*hop - 256 .. t*hop + 255 of the signal extended by
+// reflection (pad_mode 'reflect': x[-n] = x[n], x[ns-1+n] = x[ns-1-n]); the index is folded per sample, nothing is
+// padded in memory (IPDnet2/Module.py:62).
+template <bool CENTER>
 __global__ void __launch_bounds__(kFramesPerBlock * 64)
-stft_kernel(const float* __restrict__ sig, int nb, int nch, int nt, long long sb, long long sn, long long sc,
-            float2* __restrict__ spec, float* __restrict__ magsum) {
+stft_kernel(const float* __restrict__ sig, int nb, int nch, int nt, int ns, int hop, long long sb, long long sn,
+            long long sc, float2* __restrict__ spec, float* __restrict__ magsum) {
   __shared__ float2 tw[256];                       // exp(-2*pi*i*k/512), k = 0..255
   __shared__ float2 buf[kFramesPerBlock][256];
   const int tid = threadIdx.x;
@@ -50,15 +54,23 @@ stft_kernel(const float* __restrict__ sig, int nb, int nch, int nt, long long sb
   const int t = (int)(fr % nt);
   const int c = (int)((fr / nt) % nch);
   const int b = (int)(fr / ((long long)nt * nch));
-  const float* src = sig + b * sb + (long long)t * kHop * sn + c * sc;
+  const float* chan = sig + b * sb + c * sc;
+  const int n0 = t * hop - (CENTER ? kWin / 2 : 0);
   float2* z = buf[wave];
 
   // z[m] = w[2m] x[2m] + i w[2m+1] x[2m+1], stored bit-reversed for the DIT FFT
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int m = lane + 64 * r;
-    const float x0 = src[(long long)(2 * m) * sn];
-    const float x1 = src[(long long)(2 * m + 1) * sn];
+    int i0 = n0 + 2 * m, i1 = i0 + 1;
+    if (CENTER) {
+      i0 = i0 < 0 ? -i0 : i0;
+      i1 = i1 < 0 ? -i1 : i1;
+      i0 = i0 >= ns ? 2 * (ns - 1) - i0 : i0;
+      i1 = i1 >= ns ? 2 * (ns - 1) - i1 : i1;
+    }
+    const float x0 = chan[(long long)i0 * sn];
+    const float x1 = chan[(long long)i1 * sn];
     const float w0 = 0.5f - 0.5f * cospif((float)(2 * m) / 256.0f);       // periodic Hann-512
     const float w1 = 0.5f - 0.5f * cospif((float)(2 * m + 1) / 256.0f);
     z[bitrev8(m)] = make_float2(w0 * x0, w1 * x1);
@@ -250,6 +262,12 @@ extern "C" {
 
 int fnssl_num_frames(int ns) { return ns < kWin ? 0 : (ns - kWin) / kHop + 1; }
 
+int fnssl_num_frames_ex(int ns, int hop, int center) {
+  if (hop <= 0) return 0;
+  if (center) return ns > kWin / 2 ? ns / hop + 1 : 0;      // reflect padding needs ns > 256 (torch.stft's own check)
+  return ns < kWin ? 0 : (ns - kWin) / hop + 1;
+}
+
 int fnssl_num_pairs(int nch, int ch_mode) {
   if (nch < 2) return 0;
   return ch_mode == FNSSL_CH_MODE_MM ? nch * (nch - 1) / 2 : nch - 1;
@@ -274,20 +292,32 @@ int fnssl_forgetting_coefs(int nt, int sample_length, float* a, float* b) {
   return FNSSL_OK;
 }
 
-int fnssl_stft(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc, float* spec,
-               float* magsum, void* stream) {
+int fnssl_stft_ex(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc, int hop,
+                  int center, float* spec, float* magsum, void* stream) {
   FNSSL_REQUIRE(nb > 0 && nch > 0, "stft: empty batch (nb %d, nch %d)", nb, nch);
-  const int nt = fnssl_num_frames(ns);
-  FNSSL_REQUIRE(nt > 0, "stft: signal of %d samples is shorter than one %d-sample window", ns, kWin);
+  FNSSL_REQUIRE(hop > 0 && hop <= kWin, "stft: hop %d outside 1..%d", hop, kWin);
+  const int nt = fnssl_num_frames_ex(ns, hop, center);
+  FNSSL_REQUIRE(nt > 0, center ? "stft: signal of %d samples is too short for reflect padding of %d"
+                               : "stft: signal of %d samples is shorter than one %d-sample window",
+                ns, center ? kWin / 2 : kWin);
   FNSSL_REQUIRE(sig && spec, "stft: null pointer");
   const long long nframes = (long long)nb * nch * nt;
   const long long nblk = (nframes + kFramesPerBlock - 1) / kFramesPerBlock;
   FNSSL_REQUIRE(nblk < (1ll << 31), "stft: too many frames");
   fnssl::TimedLaunch tl("stft", fnssl::as_stream(stream));
-  hipLaunchKernelGGL(stft_kernel, dim3((unsigned)nblk), dim3(kFramesPerBlock * 64), 0,
-                     fnssl::as_stream(stream), sig, nb, nch, nt, sb, sn, sc, reinterpret_cast<float2*>(spec), magsum);
+  if (center)
+    hipLaunchKernelGGL(stft_kernel<true>, dim3((unsigned)nblk), dim3(kFramesPerBlock * 64), 0, fnssl::as_stream(stream),
+                       sig, nb, nch, nt, ns, hop, sb, sn, sc, reinterpret_cast<float2*>(spec), magsum);
+  else
+    hipLaunchKernelGGL(stft_kernel<false>, dim3((unsigned)nblk), dim3(kFramesPerBlock * 64), 0, fnssl::as_stream(stream),
+                       sig, nb, nch, nt, ns, hop, sb, sn, sc, reinterpret_cast<float2*>(spec), magsum);
   FNSSL_CHECK_LAUNCH("stft_kernel");
   return FNSSL_OK;
+}
+
+int fnssl_stft(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc, float* spec,
+               float* magsum, void* stream) {
+  return fnssl_stft_ex(sig, nb, ns, nch, sb, sn, sc, kHop, 0, spec, magsum, stream);
 }
 
 int fnssl_pair_features(const float* spec, const float* magsum, const float* coef_a, const float* coef_b,

@@ -71,6 +71,21 @@ int fnssl_stft(const float* sig, int nb, int ns, int nch,
                float* spec, float* magsum, void* stream);
 
 /*
+ * The same transform with the hop and the framing of IPDnet2's front end (IPDnet2/Module.py:47-64:
+ * torch.stft(n_fft 512, hop_length int(512 * 0.625) = 320, win_length 512, hann, center=True)):
+ *   hop     1..512 samples between frames
+ *   center  0: frames start at t*hop (as fnssl_stft);  1: frame t is centred on sample t*hop of the signal
+ *           extended by REFLECTION of 256 samples at both ends (torch.stft's default pad_mode) — the extension
+ *           is an index fold inside the kernel, never materialised;  nt = fnssl_num_frames_ex(ns, hop, center)
+ *           = ns / hop + 1 (Module.py:55), needs ns > 256.
+ * spec / magsum as fnssl_stft.  fnssl_stft(...) == fnssl_stft_ex(..., 256, 0, ...).
+ */
+int fnssl_num_frames_ex(int ns, int hop, int center);
+int fnssl_stft_ex(const float* sig, int nb, int ns, int nch,
+                  long long sb, long long sn, long long sc, int hop, int center,
+                  float* spec, float* magsum, void* stream);
+
+/*
  * Host helper: per-frame coefficients (a_t, b_t) of
  *   mu_t = a_t * mu_{t-1} + b_t * mean_t
  * with the reference's float32 rounding (FN-SSL/utils.py:26-44).

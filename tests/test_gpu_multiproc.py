@@ -115,3 +115,35 @@ def test_two_processes_on_one_gpu_match_single_process(tmp_path):
     assert moved.max() > 5e-4                                     # the step did move the parameters
     losses = [np.load(os.path.join(str(tmp_path), "loss_rank%d.npy" % r))[0] for r in range(world)]
     assert abs(0.5 * (losses[0] + losses[1]) - loss) < 1e-5 * max(1.0, abs(loss))   # mean of shard losses = batch loss
+
+
+def test_bench_self_launches_n_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE must itself start 2 ranks (torch.distributed.run, one process per
+    GPU).  This box has ONE GPU, so (a) without the test hook the call must exit non-zero, not fall back to one rank;
+    (b) with FNSSL_BENCH_SHARED_GPU=1 both ranks share cuda:0 over gloo (RCCL refuses two ranks on one device) and the
+    whole launch -> barrier -> max-over-ranks -> ONE JSON line path runs, for the forward and the training step."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm device")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FNSSL_BENCH_SHARED_GPU"):
+        env.pop(k, None)
+    bench = os.path.join(ROOT, "bench.py")
+    if torch.cuda.device_count() < 2:
+        res = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert res.returncode != 0 and res.stdout.strip() == "", (res.returncode, res.stdout[-300:])
+    env["FNSSL_BENCH_SHARED_GPU"] = "1"
+    for cfg, extra in ((2, ["--nb", "2", "--frames", "24"]), (4, ["--nb", "2", "--frames", "24"])):
+        res = subprocess.run([sys.executable, bench, "--gpus", "2", "--config", str(cfg), "--steps", "2", "--warmup", "1",
+                              "--other-configs", ""] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, res.stdout[-500:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and len(line["ms_per_step_per_rank"]) == 2 and line["backend"] == "gloo"
+        assert line["value"] > 0 and line["scaling"] == "weak"
+        # whole-job value = frames of BOTH ranks over the slowest rank's time
+        assert abs(line["value"] - 2 * 2 * 24 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"] + 0.01

@@ -221,3 +221,23 @@ def test_lightning_module_uses_manual_optimization(monkeypatch):
         assert m.configure_optimizers() is None
     finally:
         sys.modules.pop("predict_step", None)
+
+
+def test_bench_gpus_n_refuses_to_run_with_fewer_devices():
+    """`bench.py --gpus N` outside torch.distributed.run starts N ranks itself; with fewer than N devices it must exit
+    non-zero (never a silent 1-rank run that claims nothing about scaling).  No GPU here -> rc 2, no JSON line."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 2, (res.returncode, res.stderr[-500:])
+    assert res.stdout.strip() == ""
+    assert "refusing to run with fewer ranks" in res.stderr
+    # a WORLD_SIZE that disagrees with --gpus is an error too (the line's n_gpus must be what was asked for)
+    env["WORLD_SIZE"] = "2"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr

@@ -82,8 +82,10 @@ def _ptr(t):
 # --------------------------------------------------------------------------- #
 # front end
 # --------------------------------------------------------------------------- #
-def num_frames(ns: int) -> int:
-    return _lib.load().fnssl_num_frames(int(ns))
+def num_frames(ns: int, hop: int = 256, center: bool = False) -> int:
+    if hop == 256 and not center:
+        return _lib.load().fnssl_num_frames(int(ns))
+    return _lib.load().fnssl_num_frames_ex(int(ns), int(hop), int(bool(center)))
 
 
 def num_pairs(nch: int, ch_mode: str) -> int:
@@ -91,17 +93,19 @@ def num_pairs(nch: int, ch_mode: str) -> int:
 
 
 @on_device
-def stft(sig: torch.Tensor):
-    """sig [nb, ns, nch] -> (spec [nb, nch, nt, 257, 2], magsum [nb, nch, nt]).  Module.py:48-68."""
+def stft(sig: torch.Tensor, hop: int = 256, center: bool = False):
+    """sig [nb, ns, nch] -> (spec [nb, nch, nt, 257, 2], magsum [nb, nch, nt]).  Module.py:48-68; with hop 320 and
+    center=True (reflect padding) it is IPDnet2's transform, IPDnet2/Module.py:47-64."""
     _need_dev(sig)
     if sig.ndim != 3:
         raise RuntimeError("fnssl.stft: expected [nb, ns, nch], got %s" % (tuple(sig.shape),))
     nb, ns, nch = sig.shape          # any strides: a permuted [nb, nch, ns] batch is read in place
-    nt = num_frames(ns)
+    nt = num_frames(ns, hop, center)
     spec = torch.empty((nb, nch, max(nt, 0), NBIN, 2), dtype=torch.float32, device=sig.device)
     magsum = torch.empty((nb, nch, max(nt, 0)), dtype=torch.float32, device=sig.device)
     sb, sn, sc = sig.stride()
-    check(_lib.load().fnssl_stft(_ptr(sig), nb, ns, nch, sb, sn, sc, _ptr(spec), _ptr(magsum), _stream()), "stft")
+    check(_lib.load().fnssl_stft_ex(_ptr(sig), nb, ns, nch, sb, sn, sc, int(hop), int(bool(center)), _ptr(spec),
+                                    _ptr(magsum), _stream()), "stft")
     return spec, magsum
 
 
@@ -165,16 +169,27 @@ def array_features(spec, magsum, eps: float = 1e-6, sample_length: int = 280, la
     return x, mu
 
 
-def preprocess_array(sig, eps: float = 1e-6, sample_length: int = 280, layout: int = 1):
-    """Waveforms [nb, ns, nch] -> IPDnet input features (runIPDnetOn.py:237-254).
+def preprocess_array(sig, eps: float = 1e-6, sample_length: int = 280, layout: int = 1, hop: int = 256,
+                     center: bool = False):
+    """Waveforms [nb, ns, nch] -> IPDnet input features (runIPDnetOn.py:237-254); with ``hop=320, center=True,
+    sample_length=249`` the features of IPDnet2 (IPDnet2/run_IPDnet2.py:277-288, see ``preprocess_ipdnet2``).
 
     layout 1 returns the reference's tensor [nb, 2*nch, 256, nt] as a VIEW of the frame-major storage
     [nb, nt, 256, 2*nch] the network consumes (same shape and values for every reader; ``IPDnet.forward`` then skips
     its own transposition pass, and the front end writes whole rows instead of one float per 1200-byte stride).
     ``array_features(..., layout=1)`` still produces the contiguous NCHW tensor."""
-    spec, magsum = stft(sig)
+    spec, magsum = stft(sig, hop, center)
     x, _ = array_features(spec, magsum, eps, sample_length, 0)
     return x if layout == 0 else x.permute(0, 3, 2, 1)
+
+
+def preprocess_ipdnet2(sig, eps: float = 1e-6, sample_length: int = 249):
+    """Waveforms [nb, ns, nch] -> IPDnet2's network input [nb, 2*nch, 256, nt], nt = ns // 320 + 1
+    (IPDnet2/run_IPDnet2.py:277-288: STFT nfft 512 / hop 320 / center=True (IPDnet2/Module.py:47-64), abs,
+    forgetting_norm over ALL channels with sample_length 249, real / imag normalise, cat, DC drop).  The returned
+    tensor has the reference's shape and values; it is a view of frame-major storage (one contiguous row per frame),
+    which OnlineSpatialNet's encoder reads through strides."""
+    return preprocess_array(sig, eps, sample_length, 1, hop=320, center=True)
 
 
 @on_device

@@ -41,19 +41,27 @@ def n_frames(ns: int, win_len: int = WIN_LEN, hop: int = HOP) -> int:
     return int(np.floor((ns - win_len) / hop + 1))
 
 
-def stft(signal: np.ndarray) -> np.ndarray:
+def stft(signal: np.ndarray, hop: int = HOP, center: bool = False) -> np.ndarray:
     """STFT.forward, FN-SSL/Module.py:48-68.
 
     signal [nb, ns, nch] float32 -> complex64 [nb, 257, nt, nch]; Hann-512
     periodic window, hop 256, center=False, not normalised.  The DFT itself is
     evaluated in float64 and rounded once, i.e. it is the exact value the
     reference's float32 FFT approximates.
+
+    ``hop=320, center=True`` restates IPDnet2's transform (IPDnet2/Module.py:47-64): torch.stft's centred
+    framing = the signal extended by 256 reflected samples at both ends (pad_mode 'reflect', edge sample not
+    repeated), nt = floor(ns / hop + 1) (:55).
     """
     signal = np.asarray(signal, dtype=F32)
     nb, ns, nch = signal.shape
-    nt = n_frames(ns)
+    if center:
+        signal = np.pad(signal, ((0, 0), (WIN_LEN // 2, WIN_LEN // 2), (0, 0)), mode="reflect")
+        nt = int(np.floor(ns / hop + 1))
+    else:
+        nt = n_frames(ns, hop=hop)
     win = hann_periodic()
-    idx = (np.arange(nt)[:, None] * HOP + np.arange(WIN_LEN)[None, :])  # [nt, 512]
+    idx = (np.arange(nt)[:, None] * hop + np.arange(WIN_LEN)[None, :])  # [nt, 512]
     out = np.zeros((nb, NBIN, nt, nch), dtype=np.complex64)
     for c in range(nch):
         frames = signal[:, :, c][:, idx] * win[None, None, :]            # f32 product
@@ -158,10 +166,12 @@ def data_preprocess(mic_sig: np.ndarray, ch_mode: str = "MM", eps: float = 1e-6,
     return np.ascontiguousarray(x[:, :, 1:NBIN, :])
 
 
-def array_preprocess(mic_sig: np.ndarray, eps: float = 1e-6, sample_length: int = 280) -> np.ndarray:
+def array_preprocess(mic_sig: np.ndarray, eps: float = 1e-6, sample_length: int = 280, hop: int = HOP,
+                     center: bool = False) -> np.ndarray:
     """Input half of IPDnet's data_preprocess, IPDnet/runIPDnetOn.py:240-254: all channels are
-    normalised together.  mic_sig [nb, ns, nch] -> x [nb, 2*nch, 256, nt], channels [Re all, Im all]."""
-    spec = np.transpose(stft(mic_sig), (0, 3, 1, 2))   # [nb, nch, 257, nt]   :246
+    normalised together.  mic_sig [nb, ns, nch] -> x [nb, 2*nch, 256, nt], channels [Re all, Im all].
+    With ``sample_length=249, hop=320, center=True`` it is IPDnet2's (IPDnet2/run_IPDnet2.py:277-288)."""
+    spec = np.transpose(stft(mic_sig, hop, center), (0, 3, 1, 2))   # [nb, nch, 257, nt]   :246
     mu = forgetting_norm(np.abs(spec).astype(F32), sample_length)           # :248-249
     den = (mu + F32(eps)).astype(F32)
     x = np.concatenate([(spec.real.astype(F32) / den).astype(F32), (spec.imag.astype(F32) / den).astype(F32)], axis=1)

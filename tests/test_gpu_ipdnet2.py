@@ -393,3 +393,50 @@ def test_bf16_network_at_ragged_sizes_and_128_bins(dev, nb, nf, nt, layers):
         outs.append(o)
         t0 += n
     assert (torch.cat(outs, 1) - whole).abs().max().item() <= 2e-5
+
+
+def test_ipdnet2_waveform_frontend_vs_reference_golden(dev):
+    """IPDnet2's front end (IPDnet2/Module.py:47-64 centred hop-320 STFT, run_IPDnet2.py:277-288 all-channel
+    forgetting_norm(249) + real/imag + DC drop) on the device against G15 = the reference's own modules, and against the
+    oracle; the per-stage STFT drop-in; waveform -> network == features -> network."""
+    import importlib.util
+    import os
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    g = load_golden("g15_ipdnet2_frontend")
+    ci = 0
+    while "c%d_cfg" % ci in g.files:
+        seed, nb, ns, nch, sl = (int(v) for v in g["c%d_cfg" % ci])
+        sig = rs_randn(seed, (nb, ns, nch), 0.1)
+        want = g["c%d_feat" % ci]
+        x = ops.preprocess_ipdnet2(to_dev(sig, dev), sample_length=sl)
+        assert tuple(x.shape) == want.shape
+        scale = np.abs(want).max()
+        assert np.abs(x.cpu().numpy() - want).max() <= 5e-6 * scale, "case %d vs reference golden" % ci
+        assert np.abs(x.cpu().numpy() - O.array_preprocess(sig, sample_length=sl, hop=320, center=True)).max() <= 5e-6 * scale
+        # the dataloader's [nb, nch, ns] batch read in place through strides
+        x2 = ops.preprocess_ipdnet2(to_dev(np.ascontiguousarray(sig.transpose(0, 2, 1)), dev).permute(0, 2, 1), sample_length=sl)
+        assert torch.equal(x2, x)
+        ci += 1
+    assert ci == 4
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fnssl_ipdnet2_module", os.path.join(here, "fn-ssl_amd", "IPDnet2", "Module.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seed, nb, ns, nch, sl = (int(v) for v in g["c0_cfg"])
+    st = mod.STFT(win_len=512, win_shift_ratio=0.625, nfft=512)(to_dev(rs_randn(seed, (nb, ns, nch), 0.1), dev))
+    assert st.dtype == torch.complex64 and tuple(st.shape) == g["c0_stft"].shape
+    assert np.abs(st.cpu().numpy() - g["c0_stft"]).max() <= 5e-6 * np.abs(g["c0_stft"]).max()
+    assert ops.num_frames(ns, 320, True) == ns // 320 + 1 and ops.num_frames(256, 320, True) == 0
+    with pytest.raises(RuntimeError):
+        ops.stft(to_dev(rs_randn(1, (1, 200, 2)), dev), hop=320, center=True)      # shorter than the reflect padding
+    # waveform -> DP-IPD through the drop-in == features -> DP-IPD, and == the oracle chain
+    from oracle import ipdnet2_oracle as O2
+    sd, net = build_net(dev, 2400, num_layers=2)
+    sig = rs_randn(2401, (2, 320 * 19, 5), 0.1)
+    feats = ops.preprocess_ipdnet2(to_dev(sig, dev))
+    assert tuple(feats.shape) == (2, 10, 256, 20)
+    out = net(feats)
+    assert torch.equal(out, net(feats.contiguous()))
+    want = O2.forward(sd, O.array_preprocess(sig[:1], sample_length=249, hop=320, center=True))
+    assert_close(out[:1].cpu().numpy(), want, RTOL, 5e-5, "waveform -> OnlineSpatialNet vs oracle chain")

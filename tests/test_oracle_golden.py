@@ -239,3 +239,26 @@ def test_dropout_scale_statistics_and_determinism():
     # a chunk of the batch draws the same mask as the whole batch
     assert np.array_equal(T.dropout_scale(s, (1, 5, 7, 256), b0=1), a[1:2])
     assert not np.array_equal(T.dropout_scale(T.layer_seed(7, 4), (2, 5, 7, 256)), a)
+
+
+# --- IPDnet2 waveform front end (VERDICT r2 missing item 2) ---------------------------------------------
+def test_ipdnet2_frontend_oracle_matches_reference_golden():
+    """oracle stft(hop 320, center=True) + all-channel forgetting_norm(249) + pack == the reference's own
+    IPDnet2/Module.py::STFT and utils_.forgetting_norm composed as run_IPDnet2.py:277-288 (G15)."""
+    g = load_golden("g15_ipdnet2_frontend")
+    ci = 0
+    while "c%d_cfg" % ci in g.files:
+        seed, nb, ns, nch, sl = (int(v) for v in g["c%d_cfg" % ci])
+        sig = rs_randn(seed, (nb, ns, nch), 0.1)
+        want = g["c%d_feat" % ci]
+        got = O.array_preprocess(sig, sample_length=sl, hop=320, center=True)
+        assert got.shape == want.shape == (nb, 2 * nch, 256, ns // 320 + 1), (ci, got.shape, want.shape)
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max(), "IPDnet2 features case %d" % ci
+        ci += 1
+    assert ci == 4
+    seed, nb, ns, nch, sl = (int(v) for v in g["c0_cfg"])
+    spec = O.stft(rs_randn(seed, (nb, ns, nch), 0.1), 320, True)
+    assert spec.shape == g["c0_stft"].shape
+    assert np.abs(spec - g["c0_stft"]).max() <= 2e-6 * np.abs(g["c0_stft"]).max()
+    mu = O.forgetting_norm(np.abs(np.transpose(spec, (0, 3, 1, 2))).astype(np.float32), sl)
+    assert_close(mu, g["c0_mu"], 2e-6, 1e-9, "forgetting_norm(249) over all channels")

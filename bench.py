@@ -393,7 +393,12 @@ class Ipdnet2Forward:
         self.net = net.to(dev) if self.fp32 else net.to(dev).bfloat16()   # bf16 parameters select FNSSL_PRECISION_BF16
         g = torch.Generator(device=dev)
         g.manual_seed(3000 + rank)
-        self.x = torch.randn((self.nb, 2 * self.mics, 256, self.nt), generator=g, device=dev)
+        # waveforms [B, ns, 15] with ns = 320 (nt - 1): nt = ns // 320 + 1 frames (IPDnet2/Module.py:55).  --features-in
+        # starts from the feature tensor instead (the round-2 measurement)
+        self.features_in = args.features_in
+        self.sig = torch.randn((self.nb, 320 * (self.nt - 1), self.mics), generator=g, device=dev) * 0.1
+        self.x = ops.preprocess_ipdnet2(self.sig)
+        assert tuple(self.x.shape) == (self.nb, 2 * self.mics, 256, self.nt)
         self.frames_per_step = self.nb * self.nt
         self.dtype = "f32" if self.fp32 else "bf16"
         self.metric = "utt-frames/sec IPDnet2 (OnlineSpatialNet) DP-IPD forward, 15-mic input, 512 outputs per frame"
@@ -403,17 +408,22 @@ class Ipdnet2Forward:
             % (rank, world, self.nb, 2 * self.mics, self.nt, self.dtype))
 
     def step(self):
-        return self.net(self.x)
+        if self.features_in:
+            return self.net(self.x)
+        return self.net(self.ops.preprocess_ipdnet2(self.sig))
 
     def check(self, out):
         assert tuple(out.shape) == (self.nb, self.nt // 5, 512, 4, 2) and bool(torch.isfinite(out).all())
 
     def config(self):
         return {"workload": "BASELINE configs[4]: IPDnet2 OnlineSpatialNet (8 layers, hidden 96, mamba(16,4)), 15-mic "
-                            "mapping dim_input 30 (SURVEY 8d), 256 bins -> 2F = 512 outputs, online / causal path; features "
-                            "[B, 30, 256, T] resident in HBM -> [B, T/5, 512, 4, 2]; %d utterances/GPU x %d frames; %s; "
-                            "parity: non-Mamba blocks pinned to the reference, Mamba unpinned"
-                            % (self.nb, self.nt,
+                            "mapping dim_input 30 (SURVEY 8d), 256 bins -> 2F = 512 outputs, online / causal path; %s "
+                            "-> [B, T/5, 512, 4, 2]; %d utterances/GPU x %d frames; %s; "
+                            "parity: front end and non-Mamba blocks pinned to the reference, Mamba unpinned"
+                            % ("features [B, 30, 256, T] resident in HBM" if self.features_in else
+                               "waveforms [B, ns, 15] resident in HBM -> centred hop-320 STFT -> all-channel "
+                               "forgetting_norm(249) features [B, 30, 256, T] (run_IPDnet2.py:277-288)",
+                               self.nb, self.nt,
                                "fp32" if self.fp32 else "bf16 parameters; bf16 MFMA operands in the encoder, the grouped "
                                "frequency conv and the Mamba in / x / out projections, fp32 accumulate, fp32 tensors in HBM; "
                                "LayerNorm, depthwise conv, dt_proj, scan, full-band branch and head fp32"),
@@ -444,15 +454,17 @@ class Ipdnet2Forward:
 
     def cpu_baseline(self):
         from oracle import ipdnet2_oracle as O2
+        from oracle import fnssl_oracle as O
         frames = 20
-        x = self.x[:1, :, :, :frames].cpu().numpy()
+        sig = self.sig[:1, :320 * (frames - 1)].contiguous()
         c0 = time.perf_counter()
+        x = O.array_preprocess(sig.cpu().numpy(), sample_length=249, hop=320, center=True)
         want = O2.forward(self.sd, x)
         cdt = time.perf_counter() - c0
         cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "1 utterance x 30 channels x %d frames, numpy restatement (oracle/ipdnet2_oracle.py; Mamba block = "
+               "sample": "1 utterance x 15 mics x %d frames from the waveform, numpy restatement (oracle/ipdnet2_oracle.py; Mamba block = "
                          "published algorithm, parity unpinned), %.1f s" % (frames, cdt)}
-        got = self.net(self.x[:1, :, :, :frames].contiguous()).cpu()
+        got = self.net(self.ops.preprocess_ipdnet2(sig)).cpu()
         rt, at = (1e-4, 5e-5) if self.fp32 else (2e-2, 1.5e-2)          # bf16: SURVEY 8c, fp32 oracle at a looser tolerance
         return cpu, parity_of(got, torch.from_numpy(want), rt, at, "%d frames vs the fp32 oracle" % frames)
 

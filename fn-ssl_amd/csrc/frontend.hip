@@ -30,6 +30,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
 
+// Orders this wave's LDS writes before its later LDS reads (a wave's LDS operations complete in order; this keeps the
+// compiler from moving them across and waits for the outstanding ones) without stopping the other waves.
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // sig[b*sb + n*sn + c*sc] -> spec [nb, nch, nt, 257] (re, im), magsum [nb, nch, nt]
 // CENTER = torch.stft(center=True): frame t covers samples t*hop - 256 .. t*hop + 255 of the signal extended by
 // reflection (pad_mode 'reflect': x[-n] = x[n], x[ns-1+n] = x[ns-1-n]); the index is folded per sample, nothing is
@@ -75,7 +82,7 @@ stft_kernel(const float* __restrict__ sig, int nb, int nch, int nt, int ns, int 
     const float w1 = 0.5f - 0.5f * cospif((float)(2 * m + 1) / 256.0f);
     z[bitrev8(m)] = make_float2(w0 * x0, w1 * x1);
   }
-  __syncthreads();
+  __syncthreads();                                 // the twiddle table is shared by the block's waves
   // 8 radix-2 stages of the 256-point complex FFT; 128 butterflies per stage, 2 per lane
 #pragma unroll
   for (int st = 0; st < 8; ++st) {
@@ -92,7 +99,7 @@ stft_kernel(const float* __restrict__ sig, int nb, int nch, int nt, int ns, int 
       z[i0] = make_float2(a.x + tb.x, a.y + tb.y);
       z[i1] = make_float2(a.x - tb.x, a.y - tb.y);
     }
-    __syncthreads();
+    wave_lds_sync();                               // z is private to the wave: no workgroup barrier between stages
   }
   // split: X[k] = E[k] + W512^k O[k],  E = (Z[k] + conj Z[N-k])/2,  O = (Z[k] - conj Z[N-k])/(2i)
   float2* out = spec + fr * kBins;
@@ -133,12 +140,33 @@ __device__ __forceinline__ void pair_of(int p, int nch, int ch_mode, int& mi, in
 }
 
 // mu[pair, t]: mu_t = a_t * mu_{t-1} + b_t * mean_t, mean_t = (S_i + S_j) / 514.
-// One thread per pair; products and the sum are rounded separately like the
-// reference's tensor ops (utils.py:33-41).
-__global__ void ema_kernel(const float* __restrict__ magsum, const float* __restrict__ ca,
-                           const float* __restrict__ cb, int nb, int nch, int np, int nt, int ch_mode,
-                           float* __restrict__ mu) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per pair: the lanes form the per-frame means and the products b_t * mean_t in parallel (coalesced reads)
+// into LDS, lane 0 runs the nt-step recursion on LDS operands (a dependent chain of one multiply and one add per
+// frame instead of nt round trips to memory), the lanes write mu back coalesced.  Products and the sum are rounded
+// separately like the reference's tensor ops (utils.py:33-41); frames beyond kEmaTile continue from the carried mu.
+constexpr int kEmaTile = 1024;
+constexpr int kEmaWaves = 4;
+
+__device__ __forceinline__ void ema_scan_tile(float* bm, const float* ca_t, int n, float& m, int lane) {
+  // bm[0..n) holds b_t * mean_t on entry and mu_t on exit; ca_t[0..n) the a_t of the same frames
+  wave_lds_sync();
+  if (lane == 0) {
+    float mm = m;
+    for (int t = 0; t < n; ++t) {
+      mm = __fadd_rn(__fmul_rn(ca_t[t], mm), bm[t]);
+      bm[t] = mm;
+    }
+    m = mm;
+  }
+  wave_lds_sync();
+}
+
+__global__ void __launch_bounds__(kEmaWaves * 64)
+ema_kernel(const float* __restrict__ magsum, const float* __restrict__ ca, const float* __restrict__ cb, int nb,
+           int nch, int np, int nt, int ch_mode, float* __restrict__ mu) {
+  __shared__ float bm_s[kEmaWaves][kEmaTile], ca_s[kEmaWaves][kEmaTile];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * kEmaWaves + wave;
   if (idx >= nb * np) return;
   const int b = idx / np, p = idx - b * np;
   int mi, mj;
@@ -146,10 +174,16 @@ __global__ void ema_kernel(const float* __restrict__ magsum, const float* __rest
   const float* si = magsum + ((long long)b * nch + mi) * nt;
   const float* sj = magsum + ((long long)b * nch + mj) * nt;
   float m = 0.f;
-  for (int t = 0; t < nt; ++t) {
-    const float mean = __fdiv_rn(__fadd_rn(si[t], sj[t]), (float)(2 * kBins));
-    m = __fadd_rn(__fmul_rn(ca[t], m), __fmul_rn(cb[t], mean));
-    mu[(long long)idx * nt + t] = m;
+  for (int t0 = 0; t0 < nt; t0 += kEmaTile) {
+    const int n = min(kEmaTile, nt - t0);
+    for (int t = lane; t < n; t += 64) {
+      const float mean = __fdiv_rn(__fadd_rn(si[t0 + t], sj[t0 + t]), (float)(2 * kBins));
+      bm_s[wave][t] = __fmul_rn(cb[t0 + t], mean);
+      ca_s[wave][t] = ca[t0 + t];
+    }
+    ema_scan_tile(bm_s[wave], ca_s[wave], n, m, lane);
+    for (int t = lane; t < n; t += 64) mu[(long long)idx * nt + t0 + t] = bm_s[wave][t];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -205,20 +239,30 @@ nchw_to_seq_kernel(const float* __restrict__ x, int c, int nf, int nt, float* __
 }
 
 // ---- all-channel ("array") features of IPDnet (reference IPDnet/runIPDnetOn.py:240-254) ----------
-// mu[b, t]: the same recursion on the mean magnitude over ALL channels and the 257 bins.
-__global__ void ema_array_kernel(const float* __restrict__ magsum, const float* __restrict__ ca,
-                                 const float* __restrict__ cb, int nb, int nch, int nt, float* __restrict__ mu) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// mu[b, t]: the same recursion on the mean magnitude over ALL channels and the 257 bins (one wave per utterance,
+// like ema_kernel; the channel sum keeps the reference's left-to-right order).
+__global__ void __launch_bounds__(kEmaWaves * 64)
+ema_array_kernel(const float* __restrict__ magsum, const float* __restrict__ ca, const float* __restrict__ cb, int nb,
+                 int nch, int nt, float* __restrict__ mu) {
+  __shared__ float bm_s[kEmaWaves][kEmaTile], ca_s[kEmaWaves][kEmaTile];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * kEmaWaves + wave;
   if (b >= nb) return;
   const float* s = magsum + (long long)b * nch * nt;
   const float cnt = (float)(nch * kBins);
   float m = 0.f;
-  for (int t = 0; t < nt; ++t) {
-    float acc = s[t];
-    for (int c = 1; c < nch; ++c) acc = __fadd_rn(acc, s[(long long)c * nt + t]);
-    const float mean = __fdiv_rn(acc, cnt);
-    m = __fadd_rn(__fmul_rn(ca[t], m), __fmul_rn(cb[t], mean));
-    mu[(long long)b * nt + t] = m;
+  for (int t0 = 0; t0 < nt; t0 += kEmaTile) {
+    const int n = min(kEmaTile, nt - t0);
+    for (int t = lane; t < n; t += 64) {
+      float acc = s[t0 + t];
+      for (int c = 1; c < nch; ++c) acc = __fadd_rn(acc, s[(long long)c * nt + t0 + t]);
+      const float mean = __fdiv_rn(acc, cnt);
+      bm_s[wave][t] = __fmul_rn(cb[t0 + t], mean);
+      ca_s[wave][t] = ca[t0 + t];
+    }
+    ema_scan_tile(bm_s[wave], ca_s[wave], n, m, lane);
+    for (int t = lane; t < n; t += 64) mu[(long long)b * nt + t0 + t] = bm_s[wave][t];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -253,6 +297,47 @@ pack_array_kernel(const float2* __restrict__ spec, const float* __restrict__ mu,
     const int n = kNF * 2 * nch;                       // multiple of 4; the row starts on a 16-byte boundary
     for (int i = 4 * f; i < n; i += 4 * 256)
       *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(row_lds + i);
+  }
+}
+
+// layout 1 ([nb, 2 nch, 256, nt], frames fastest — the tensor the reference builds) as a tiled transposition: a
+// workgroup reads a 64-frame x 32-bin tile of one channel's spectrum bin-contiguous (256-byte runs), normalises it and
+// writes both planes (Re -> channel c, Im -> channel nch + c) frame-contiguous (256-byte runs).  The element-wise
+// version (pack_array_kernel<1>) wrote one float per nt*4-byte stride.
+__global__ void __launch_bounds__(256)
+pack_array_planes_kernel(const float2* __restrict__ spec, const float* __restrict__ mu, int nch, int nt, float eps,
+                         float* __restrict__ x) {
+  __shared__ float re_t[32][65], im_t[32][65];
+  const int t0 = blockIdx.x * 64, f0 = blockIdx.y * 32;
+  const long long b = blockIdx.z / nch;
+  const int c = blockIdx.z - (int)b * nch;
+  const int tid = threadIdx.x;
+  {
+    const int fl = tid & 31, tl = tid >> 5;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int tt = tl + 8 * r, t = t0 + tt;
+      if (t < nt) {
+        const float den = __fadd_rn(mu[b * nt + t], eps);
+        const float2 v = spec[((b * nch + c) * nt + t) * kBins + f0 + fl + 1];
+        re_t[fl][tt] = __fdiv_rn(v.x, den);
+        im_t[fl][tt] = __fdiv_rn(v.y, den);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int tt = tid & 63, fl = tid >> 6, t = t0 + tt;
+    if (t < nt) {
+      const long long cs = (long long)kNF * nt;
+      float* o = x + b * 2 * nch * cs + (long long)f0 * nt + t;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int f = fl + 4 * r;
+        o[c * cs + (long long)f * nt] = re_t[f][tt];
+        o[(nch + c) * cs + (long long)f * nt] = im_t[f][tt];
+      }
+    }
   }
 }
 
@@ -332,8 +417,8 @@ int fnssl_pair_features(const float* spec, const float* magsum, const float* coe
   {
     fnssl::TimedLaunch tl("ema", st);
     const int n = nb * np;
-    hipLaunchKernelGGL(ema_kernel, dim3((n + 63) / 64), dim3(64), 0, st, magsum, coef_a, coef_b, nb, nch, np,
-                       nt, ch_mode, mu);
+    hipLaunchKernelGGL(ema_kernel, dim3((n + kEmaWaves - 1) / kEmaWaves), dim3(kEmaWaves * 64), 0, st, magsum, coef_a,
+                       coef_b, nb, nch, np, nt, ch_mode, mu);
     FNSSL_CHECK_LAUNCH("ema_kernel");
   }
   {
@@ -359,8 +444,8 @@ int fnssl_array_features(const float* spec, const float* magsum, const float* co
   hipStream_t st = fnssl::as_stream(stream);
   {
     fnssl::TimedLaunch tl("ema", st);
-    hipLaunchKernelGGL(ema_array_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, magsum, coef_a, coef_b, nb, nch, nt,
-                       mu);
+    hipLaunchKernelGGL(ema_array_kernel, dim3((nb + kEmaWaves - 1) / kEmaWaves), dim3(kEmaWaves * 64), 0, st, magsum,
+                       coef_a, coef_b, nb, nch, nt, mu);
     FNSSL_CHECK_LAUNCH("ema_array_kernel");
   }
   {
@@ -377,9 +462,11 @@ int fnssl_array_features(const float* spec, const float* magsum, const float* co
     if (layout == 0)
       hipLaunchKernelGGL(pack_array_kernel<0>, dim3((unsigned)rows), dim3(256), (size_t)kNF * 2 * nch * sizeof(float), st,
                          reinterpret_cast<const float2*>(spec), mu, nch, nt, eps, x);
-    else
-      hipLaunchKernelGGL(pack_array_kernel<1>, dim3((unsigned)rows), dim3(256), 0, st,
+    else {
+      FNSSL_REQUIRE((long long)nb * nch < 65536, "array_features: nb * nch too large for one launch");
+      hipLaunchKernelGGL(pack_array_planes_kernel, dim3((nt + 63) / 64, kNF / 32, nb * nch), dim3(256), 0, st,
                          reinterpret_cast<const float2*>(spec), mu, nch, nt, eps, x);
+    }
     FNSSL_CHECK_LAUNCH("pack_array_kernel");
   }
   return FNSSL_OK;

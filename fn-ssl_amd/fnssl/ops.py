@@ -183,13 +183,17 @@ def preprocess_array(sig, eps: float = 1e-6, sample_length: int = 280, layout: i
     return x if layout == 0 else x.permute(0, 3, 2, 1)
 
 
-def preprocess_ipdnet2(sig, eps: float = 1e-6, sample_length: int = 249):
+def preprocess_ipdnet2(sig, eps: float = 1e-6, sample_length: int = 249, frame_major: bool = False):
     """Waveforms [nb, ns, nch] -> IPDnet2's network input [nb, 2*nch, 256, nt], nt = ns // 320 + 1
     (IPDnet2/run_IPDnet2.py:277-288: STFT nfft 512 / hop 320 / center=True (IPDnet2/Module.py:47-64), abs,
     forgetting_norm over ALL channels with sample_length 249, real / imag normalise, cat, DC drop).  The returned
-    tensor has the reference's shape and values; it is a view of frame-major storage (one contiguous row per frame),
-    which OnlineSpatialNet's encoder reads through strides."""
-    return preprocess_array(sig, eps, sample_length, 1, hop=320, center=True)
+    tensor has the reference's shape and values, contiguous like the reference's (frames fastest: the layout the
+    encoder kernel's frame-per-lane loads coalesce on); ``frame_major=True`` returns the same tensor as a view of
+    [nb, nt, 256, 2*nch] storage instead."""
+    if frame_major:
+        return preprocess_array(sig, eps, sample_length, 1, hop=320, center=True)
+    spec, magsum = stft(sig, 320, True)
+    return array_features(spec, magsum, eps, sample_length, 1)[0]
 
 
 @on_device

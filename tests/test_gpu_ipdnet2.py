@@ -417,6 +417,8 @@ def test_ipdnet2_waveform_frontend_vs_reference_golden(dev):
         # the dataloader's [nb, nch, ns] batch read in place through strides
         x2 = ops.preprocess_ipdnet2(to_dev(np.ascontiguousarray(sig.transpose(0, 2, 1)), dev).permute(0, 2, 1), sample_length=sl)
         assert torch.equal(x2, x)
+        assert x.is_contiguous()
+        assert torch.equal(ops.preprocess_ipdnet2(to_dev(sig, dev), sample_length=sl, frame_major=True), x)
         ci += 1
     assert ci == 4
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

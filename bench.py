@@ -309,7 +309,7 @@ class FnsslTrain:
         if self.cstep is not None:
             self.cstep.step_nosync(x, self.gt, 1000003 + 8191 * (self.eng.step_count + 1))
             return self.eng.loss_dev
-        return self.eng.step(x, self.gt, sync_loss=False)
+        return self.eng.step(x, self.gt, sync_loss=False, pair_offset=self.rank * self.nb * self.npair)
 
     def check(self, out):
         assert bool(torch.isfinite(out).all())

@@ -323,8 +323,12 @@ class IPDnet(nn.Module):
             # half's kernels instead of leaving CUs idle.  Same kernels, same results (batch slices).
             cur = torch.cuda.current_stream()
             ns = max(2, min(int(os.environ.get("FNSSL_IPDNET_STREAMS", "2")), nb))
-            if self._side is None or len(self._side) != ns:
-                self._side = tuple(torch.cuda.Stream(device=x.device) for _ in range(ns))
+            if self._side is None or len(self._side) != ns or self._side[0].device != x.device:
+                self._side = tuple(torch.cuda.Stream(device=x.device) for _ in range(ns))   # keyed by (device, count)
+            # pack / upload the weight streams on the CALLER's stream before forking: the side streams only read them
+            self.block_1._streams(x.device)
+            self.block_2._streams(x.device)
+            self.conv._streams(x.device, self.block_2.narr_hidden_size, xp.shape[3])   # two-stream path: online, bf16
             bounds = [nb * i // ns for i in range(ns + 1)]
             parts = []
             for st, lo, hi in zip(self._side, bounds[:-1], bounds[1:]):

@@ -14,7 +14,8 @@ Built for the configuration the reference ships (run_IPDnet2.py:103-119): dim_hi
 kernel_size (5, .), conv_groups (8, .), all-LN norms, attention 'mamba(16,4)', dim_output 16,
 fre_compression_ratio 16, time_compression_layer 0; other values raise.  Forward only (``eval()``), fp32, ROCm
 tensors only — there is no CPU path.  ``inference=True`` (the reference's frame-by-frame Mamba stepping, :170-177)
-computes the same function as the parallel mode and runs the same kernels.  The Mamba block follows the
+is honoured: the Mamba blocks are driven one frame per ``fnssl_sn_mamba`` call with carried conv / SSM state (the
+role of ``InferenceParams``); it computes the same function as the parallel mode with T x the launches.  The Mamba block follows the
 published algorithm ("parity unpinned": no mamba_ssm to compare with, see oracle/ipdnet2_oracle.py).
 """
 import math
@@ -222,8 +223,23 @@ class SpatialNetLayer(nn.Module):
         return sn.full(x.float(), self._packed(x.device)[1], residual=False, precision=_prec(self)).to(x.dtype)
 
     def _mamba(self, x: torch.Tensor, mamba: Mamba, norm: nn.Module, dropout: nn.Module, inference: bool = False):
+        """LN + Mamba along T WITHOUT the residual (:166-181).  ``inference``: frame-by-frame stepping from zero state,
+        the carried conv taps / SSM state playing ``InferenceParams`` (:170-177)."""
         w = self._packed(x.device)
-        return sn.mamba(x.float(), w[3] if mamba is self.mhsa else w[4], residual=False, precision=_prec(self)).to(x.dtype)
+        mw = w[3] if mamba is self.mhsa else w[4]
+        xf = x.float()
+        if not inference:
+            return sn.mamba(xf, mw, residual=False, precision=_prec(self)).to(x.dtype)
+        return self._mamba_steps(xf, mw, False).to(x.dtype)
+
+    def _mamba_steps(self, xf: torch.Tensor, mw, residual: bool) -> torch.Tensor:
+        nb, nf, nt, _ = xf.shape
+        st = sn.mamba_state(nb, nf, xf.device)
+        out = sn._new_bfth(nb, nf, nt, xf.device)
+        for t in range(nt):
+            sn.mamba(xf[:, :, t:t + 1], mw, residual=residual, state=st, carry=t > 0, out=out[:, :, t:t + 1],
+                     precision=_prec(self))
+        return out
 
     @ops.on_device
     def forward(self, x: torch.Tensor, att_mask: Optional[torch.Tensor] = None, chunkwise_recurrent: bool = True,
@@ -236,8 +252,11 @@ class SpatialNetLayer(nn.Module):
         y = sn.fconv(y, f1, pool=2 if self.is_first else 1, precision=pr)   # x + fconv1, fre_compress_first
         y = sn.full(y, fu, out=y, precision=pr)
         y = sn.fconv(y, f2, pool=8 if self.is_first else 1, precision=pr)   # x + fconv2, fre_compress_second
-        y = sn.mamba(y, m0, out=y, precision=pr)
-        y = sn.mamba(y, m1, out=y, precision=pr)
+        if inference:                                                       # per-frame recurrence (:170-177)
+            y = self._mamba_steps(self._mamba_steps(y, m0, True), m1, True)
+        else:
+            y = sn.mamba(y, m0, out=y, precision=pr)
+            y = sn.mamba(y, m1, out=y, precision=pr)
         return y.to(x.dtype), None
 
     def extra_repr(self) -> str:
@@ -296,7 +315,10 @@ class OnlineSpatialNet(nn.Module):
         _require_eval(self)
         if return_attn_score:
             raise NotImplementedError("return_attn_score: the Mamba configuration has no attention scores")
-        return self.device_net(x.device).forward(x.float()).to(x.dtype)
+        dn = self.device_net(x.device)
+        if inference:       # the reference's frame-by-frame Mamba stepping (:170-177), see DeviceSpatialNet.forward_stepwise
+            return dn.forward_stepwise(x.float()).to(x.dtype)
+        return dn.forward(x.float()).to(x.dtype)
 
     @ops.on_device
     def forward_stream(self, x: torch.Tensor, state=None):

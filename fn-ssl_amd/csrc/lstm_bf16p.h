@@ -29,18 +29,26 @@
 namespace fnssl_lstm {
 
 // ABL (make ABLATE=1 builds only): timing ablations, wrong results — 1 cheap gate math (no transcendentals), 4 no MFMAs
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false>
 __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   constexpr int NT = H / 8, NTW = NT / 2, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr int KP = KT / 2;                              // half a tile
   // ring granule = a QUARTER tile per role ("piece": KQ0, KP - KQ0, KQ0, KP - KQ0 records), one barrier per piece
   constexpr int KQ0 = (KP + 1) / 2, KQ1 = KP - KQ0;
   constexpr int KPW = (KQ0 + 1) / 2;                      // DMA requests per wave and piece (2 waves per role)
-  constexpr int NSLOT = 6;                                // slots of KQ0 records per role
-  constexpr int LAND = KQ1 >= 4 ? 1 : 2;                  // pieces ahead of the consumer that are complete in LDS
-  constexpr int INFL = NSLOT - 1 - LAND;                  // pieces in flight
+  // Ring accounting.  At the barrier that opens interval j every wave has REQUESTED pieces 0 .. j + NSLOT - 2 (the
+  // prologue requests NSLOT - 1, one more follows each barrier) and waits until all but its INFL youngest piece
+  // requests have landed, i.e. pieces <= j + LAND are complete in LDS for everybody after the barrier; the request
+  // issued after the barrier (piece j + NSLOT - 1) takes the slot of interval j - 1, which nobody reads any more.
+  //   slots: [j - 1: being refilled] [j: consumed] [j + 1 .. j + LAND: landed] [the INFL youngest: in flight]
+  // The A-operand pipeline reads AD records ahead of the MFMA, so it may reach LAND pieces ahead and no further:
+  // AD <= the smallest piece.  (Round 2 waited for vmcnt(INFL' * KPW) with INFL' = NSLOT - 1 - LAND counted AFTER the
+  // next request, one piece too few: the read-ahead could touch a piece still in flight — stale weights under load.)
+  constexpr int NSLOT = NSLOT_;                           // slots of KQ0 records per role
+  constexpr int LAND = 1;                                 // pieces ahead of the consumer that are complete in LDS
+  constexpr int INFL = NSLOT - 2 - LAND;                  // my piece requests that may still be in flight at a barrier
   constexpr bool F0 = FLAGS & kW_F0, F2 = FLAGS & kW_F2, OUTF = FLAGS & kW_OUTF;
-  constexpr int AD = 4;                                   // A-operand reads in flight ahead of their MFMA
+  constexpr int AD = KQ1 >= 4 ? 4 : KQ1;                  // A-operand reads in flight ahead of their MFMA
   constexpr int SLOTB = 2 * KQ0 * 1024;                   // bytes per slot (both roles)
   constexpr int RING = NSLOT * SLOTB, HBUF = NKH * 1024;
   // the last tile's gates of a step run under the first tile of the next step when the recurrent part of a tile
@@ -48,7 +56,8 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   constexpr bool LATE = 1 + NKX >= KQ0;
   static_assert(KT % 2 == 0 && NT % 2 == 0, "tiles are fetched in two pieces, shared by two roles");
   static_assert(RING + 2 * HBUF <= 160 * 1024, "ring + h staging do not fit the LDS");
-  static_assert(AD <= (LAND == 1 ? KQ1 : KQ0 + KQ1) && (NTW * KT) % AD == 0, "A pipeline");
+  static_assert(AD >= 1 && AD <= KQ1 && KQ1 <= KQ0 && (NTW * KT) % AD == 0, "A pipeline reaches at most one piece ahead");
+  static_assert(INFL >= 1 && NSLOT >= 6, "cbs[] addresses six consecutive slots");
   static_assert(INFL * KPW <= 60, "vmcnt is a 6-bit counter");
   static_assert(2 * (KPW - 2) + 1 < KQ1 || KPW == 1, "only the last request of a piece may need clamping");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,9 +174,9 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   // EXCH: the interval boundary at which the pair exchanges h_t — my staging writes must be complete first.
   auto piece_barrier = [&](auto exch) {
     if constexpr (decltype(exch)::value)
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(INFL * KPW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DRAIN ? 0 : INFL * KPW) : "memory");
     else
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(INFL * KPW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DRAIN ? 0 : INFL * KPW) : "memory");
     flush_pending();
     fetch_next();
   };
@@ -296,8 +305,18 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
 template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
 int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
-  const size_t lds = (size_t)6 * 2 * ((KT / 2 + 1) / 2) * 1024 + (size_t)2 * (H / 16) * 1024;
-  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL>;
+  // 7 slots where a workgroup owns its CU anyway; the 144-column full-band layer (6 KB slots) keeps 6 so that three
+  // workgroups stay resident per CU (its 600 workgroups are 2.3 per CU)
+  constexpr int NSLOT = KT <= 12 ? 6 : 7;
+  const size_t lds = (size_t)NSLOT * 2 * ((KT / 2 + 1) / 2) * 1024 + (size_t)2 * (H / 16) * 1024;
+  // DRAIN (the 144-column layer only, the one shape whose 52 KB workgroups share a CU three at a time): every barrier
+  // waits for ALL of the wave's requests (vmcnt(0)) instead of leaving INFL pieces in flight.  Measured on MI355X
+  // (profiles/r03/c_*): with counted waits this shape alone gave run-to-run differences at config 3's batch (a 32-sequence
+  // group reading one stale weight record, a few times per launch) whenever several workgroups were resident per CU
+  // — bit-stable with one workgroup per CU (same kernel, LDS padded) and with drained barriers; the cause could not
+  // be pinned from here, so the shape runs the canonical "vmcnt(0) + barrier" protocol: 3.99 -> 4.37 ms per launch
+  // (three resident workgroups hide each other's waits).  The other shapes own their CU (114-158 KB of LDS).
+  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12)>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, st, p);

@@ -2123,7 +2123,8 @@ static size_t sn_act_floats(int nb, int nf, int nt, int ratio) {
 
 size_t fnssl_sn_forward_workspace_bytes(int nb, int nf, int nt) {
   if (nb <= 0 || nf <= 0 || nt <= 0) return 0;
-  return (sn_act_floats(nb, nf, nt, 5) + mamba_ws_floats((long long)nb * nt * (nf / 16))) * sizeof(float) + 256;
+  // sized for ANY time ratio fnssl_sn_forward accepts (1..16): the pooled buffer is largest at ratio 1
+  return (sn_act_floats(nb, nf, nt, 1) + mamba_ws_floats((long long)nb * nt * (nf / 16))) * sizeof(float) + 256;
 }
 
 size_t fnssl_sn_state_floats(const fnssl_sn_net* net, int nb, int nf) {

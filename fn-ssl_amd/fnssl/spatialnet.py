@@ -265,6 +265,37 @@ class DeviceSpatialNet:
         self.net = net
         self.time_ratio = int(time_ratio)
 
+    def forward_stepwise(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's ``inference=True`` (IPDnet2.py:170-177): every Mamba block is driven FRAME BY FRAME from zero
+        state — one ``fnssl_sn_mamba`` call per frame with the carried conv taps / SSM state standing in for
+        ``InferenceParams`` — and the network is orchestrated per op (fnssl_sn_encoder / fconv / full / mamba / head,
+        fnssl_avgpool_time for the 5x time pooling) instead of by ``fnssl_sn_forward``.  Same function as ``forward``
+        (the published recurrence and its scan are one algorithm); T x more launches, so it is the faithful twin of the
+        flag, not the fast path."""
+        from . import ops
+        _need_dev(x)
+        with torch.cuda.device(x.device):
+            nb, cin, nf, nt = x.shape
+            if cin != self.dim_input or nf != self.num_freqs:
+                raise RuntimeError("fnssl.spatialnet: expected [B, %d, %d, T], got %s"
+                                   % (self.dim_input, self.num_freqs, tuple(x.shape)))
+            pr = self.precision
+            y = encoder(x, self.enc_wT, self.enc_b, precision=pr)                  # logical [B, F, T, 96]
+            for l, (f1, fu, f2, m0, m1, _) in enumerate(self.layers):
+                first = l == 0
+                y = fconv(y, f1, pool=2 if first else 1, precision=pr)
+                y = full(y, fu, out=y, precision=pr)
+                y = fconv(y, f2, pool=8 if first else 1, precision=pr)
+                for m in (m0, m1):
+                    st = mamba_state(nb, y.shape[1], x.device)
+                    out = _new_bfth(nb, y.shape[1], y.shape[2], x.device)
+                    for t in range(y.shape[2]):
+                        mamba(y[:, :, t:t + 1], m, residual=True, state=st, carry=t > 0, out=out[:, :, t:t + 1], precision=pr)
+                    y = out
+                if first:
+                    y = ops.avgpool_time(y.contiguous(), self.time_ratio)         # [B, Fc, T // ratio, 96]
+            return head(y, self.head_ptrs)
+
     def new_state(self, nb: int):
         n = _lib.load().fnssl_sn_state_floats(C.byref(self.net), nb, self.num_freqs)
         return torch.zeros(n, dtype=torch.float32, device=self.device)

@@ -192,6 +192,21 @@ class TrainEngine:
             return 1, 0
         return dist.get_world_size(self.pg), dist.get_rank(self.pg)
 
+    def global_pair_offset(self, nbp: int) -> int:
+        """Index of this rank's first pair in the global batch = the pairs of all lower ranks.  Equal shards give
+        rank * nbp without communication; shards are compared with ONE small all-gather (shard_utterances() hands
+        the first ranks one utterance more when the batch does not divide), so uneven shards never draw overlapping
+        dropout masks."""
+        world, rank = self._world_rank()
+        if world <= 1:
+            return 0
+        dist = torch.distributed
+        mine = torch.tensor([int(nbp)], dtype=torch.int64,
+                            device=self.dev if dist.get_backend(self.pg or None) == "nccl" else "cpu")
+        counts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(counts, mine, group=self.pg or None)
+        return int(sum(int(c.item()) for c in counts[:rank]))
+
     def _bucket(self, prefix):
         """[lo, hi) of the flat vector covered by the parameters whose name starts with ``prefix`` (contiguous:
         the flat order is named_parameters order)."""
@@ -411,7 +426,9 @@ class TrainEngine:
         self.step_count += 1
         world, rank = self._world_rank()
         base = (self.seed * 1000003 + self.step_count * 8191) & 0xFFFFFFFF if self.force_seed is None else self.force_seed
-        pair0 = rank * nbp if pair_offset is None else int(pair_offset)      # this rank's first GLOBAL pair index
+        if pair_offset is None:
+            pair_offset = self.global_pair_offset(nbp)
+        pair0 = int(pair_offset)                                              # this rank's first GLOBAL pair index
         seeds = [layer_seed(base, l) for l in range(6)]
         self.last_seed = base
         fw, bw = self._pack_all()
@@ -421,12 +438,23 @@ class TrainEngine:
         cp = self.chunk_pairs or nbp
         cp = max(npair, (cp // npair) * npair)            # whole utterances per chunk
         gt_ipd = gt_ipd.contiguous()
-        for b0 in range(0, nbp, cp):
-            b1 = min(nbp, b0 + cp)
-            self._reduce_now = b1 == nbp          # gradients are final only in the last chunk's backward
-            self._chunk(x[b0:b1].contiguous(), gt_ipd[b0 // npair:b1 // npair], pair0 + b0, n_total, fw, bw, seeds)
-        self._reduce_now = False
-        self._wait_reductions()
+        try:
+            for b0 in range(0, nbp, cp):
+                b1 = min(nbp, b0 + cp)
+                self._reduce_now = b1 == nbp          # gradients are final only in the last chunk's backward
+                self._chunk(x[b0:b1].contiguous(), gt_ipd[b0 // npair:b1 // npair], pair0 + b0, n_total, fw, bw, seeds)
+            self._reduce_now = False
+            self._wait_reductions()
+        except BaseException:
+            # a failed chunk (OOM, HIP error) must not leave stale collective handles or the "reduce now" flag behind
+            self._reduce_now = False
+            for w in self._pending:
+                try:
+                    w.wait()
+                except Exception:
+                    pass
+            self._pending, self._wait_events = [], None
+            raise
         gscale = 1.0 / world
         check(_lib.load().fnssl_adam_step(self.theta.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                           self.exp_avg_sq.data_ptr(), self.theta.numel(), self.lr, self.betas[0],

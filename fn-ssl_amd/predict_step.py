@@ -8,8 +8,11 @@ like the reference's ``main.py predict``); without it the same class derives
 from ``nn.Module`` and ``predict_step`` is called directly (``Predict.py``).
 ``training_step`` (main.py:149-157) runs the HIP training path (fnssl.train: forward with
 dropout, MSE loss, BPTT, RCCL gradient all-reduce, Adam) and, because that path carries its own
-backward and optimizer, returns the loss as a detached scalar; ``configure_optimizers`` hands Lightning
-nothing to do.  The numpy DP-IPD target generator and the DOA metrics stay outside this path
+backward and optimizer, returns the loss as a detached scalar; ``configure_optimizers`` hands Lightning an
+``EngineOptimizer`` — a ``torch.optim.Optimizer`` whose ``step()`` does no arithmetic (the engine has already
+applied Adam) but which Lightning's manual-optimisation loop counts, so ``trainer.global_step`` advances and
+``ModelCheckpoint`` / ``max_steps`` / logger step indices work, and whose ``state_dict`` carries the engine's Adam
+moments into checkpoints.  The numpy DP-IPD target generator and the DOA metrics stay outside this path
 (SURVEY.md §8): ``gt_batch['ipd']`` must already hold the target IPDs.
 """
 import torch
@@ -21,6 +24,44 @@ try:  # optional, absent in the build image
     from pytorch_lightning import LightningModule as _Base
 except Exception:  # pragma: no cover
     _Base = torch.nn.Module
+
+
+class EngineOptimizer(torch.optim.Optimizer):
+    """What ``configure_optimizers`` returns.  The HIP engine owns the parameters' flat copy, the gradients and the Adam
+    moments and applies the update inside ``TrainEngine.step``; this object exists for the trainer's bookkeeping:
+    ``step()`` is counted by Lightning (``optim_step_progress`` -> ``trainer.global_step``), ``state_dict()`` /
+    ``load_state_dict()`` move the engine's optimizer state (moments, step count, learning rate) through checkpoints."""
+
+    def __init__(self, module):
+        self._module = module
+        self._anchor = torch.nn.Parameter(torch.zeros(1), requires_grad=False)     # Optimizer needs >= 1 parameter
+        super().__init__([self._anchor], {"lr": 0.001})
+        self.steps_taken = 0
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.steps_taken += 1
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        return None                                   # the engine zeroes its flat gradient at the start of every step
+
+    def state_dict(self):
+        eng = getattr(self._module, "_train_engine", None)
+        sd = {"steps_taken": self.steps_taken, "engine": None}
+        if eng is not None:
+            sd["engine"] = {"exp_avg": eng.exp_avg.detach().cpu(), "exp_avg_sq": eng.exp_avg_sq.detach().cpu(),
+                            "step_count": int(eng.step_count), "lr": float(eng.lr)}
+        return sd
+
+    def load_state_dict(self, sd):
+        self.steps_taken = int(sd.get("steps_taken", 0))
+        es = sd.get("engine")
+        if es is not None:
+            eng = self._module._engine()
+            eng.exp_avg.copy_(es["exp_avg"].to(eng.exp_avg.device))
+            eng.exp_avg_sq.copy_(es["exp_avg_sq"].to(eng.exp_avg_sq.device))
+            eng.step_count, eng.lr = int(es["step_count"]), float(es["lr"])
 
 
 class MyModel(_Base):
@@ -60,6 +101,12 @@ class MyModel(_Base):
         mic_sig_batch, gt_batch = batch[0], batch[1]
         x = ops.preprocess(mic_sig_batch.to(self.dev), self.ch_mode, 1e-6, layout=1)
         loss = self._engine().step(x, gt_batch['ipd'].to(self.dev), sync_loss=False)
+        # manual optimisation: Lightning counts optimizer steps, not training_step calls.  Stepping the (arithmetic-
+        # free) EngineOptimizer through self.optimizers() — Lightning's wrapper — advances trainer.global_step, which
+        # ModelCheckpoint, max_steps and the loggers key on.
+        if _Base is not torch.nn.Module and getattr(self, "_trainer", None) is not None:
+            opt = self.optimizers()
+            (opt[0] if isinstance(opt, (list, tuple)) else opt).step()
         return {"loss": loss.detach().clone().reshape(())}
 
     @ops.on_device
@@ -79,8 +126,9 @@ class MyModel(_Base):
 
     def configure_optimizers(self):
         """The optimizer (Adam, lr 1e-3; the ExponentialLR decay is applied by ``on_train_epoch_end``) lives in
-        the HIP training engine; Lightning gets no optimizer to step."""
-        return None
+        the HIP training engine; Lightning gets the ``EngineOptimizer`` shim so that its step counter, checkpoints
+        and ``max_steps`` work (see the class)."""
+        return EngineOptimizer(self)
 
     def on_train_epoch_end(self):
         if getattr(self, "_train_engine", None) is not None:

@@ -592,6 +592,7 @@ typedef struct {
   int precision;                           /* FNSSL_PRECISION_FP32 / _BF16, see fnssl_sn_encoder */
 } fnssl_sn_net;
 
+/* bytes of workspace fnssl_sn_forward needs, sufficient for every time_ratio it accepts (1..16) */
 size_t fnssl_sn_forward_workspace_bytes(int nb, int nf, int nt);
 /* floats of the carried state of a whole network (encoder frames + per Mamba block conv / ssm state) */
 size_t fnssl_sn_state_floats(const fnssl_sn_net* net, int nb, int nf);

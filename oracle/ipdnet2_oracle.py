@@ -217,17 +217,111 @@ def mamba(sd, p, x, state=None):
     return out, (xp[:, -(K - 1):].copy(), h)
 
 
-def mamba_block(sd, p_norm, p_mamba, x, state=None):
-    """SpatialNetLayer._mamba (:166-181): LN, the block along T for every (b, f), WITHOUT the residual."""
+def mamba_step(sd, p, x_t, conv_state, ssm_state):
+    """ONE frame of a Mamba block with explicit state — the recurrence the reference drives when ``inference=True``
+    (IPDnet2.py:170-177: ``InferenceParams`` + ``mamba.forward(x[:, [i], :], inference_params)`` per frame, which in
+    mamba_ssm dispatches to ``Mamba.step``).  PARITY UNPINNED like ``mamba``; restated from the published step form:
+      conv_state <- roll(conv_state, -1); conv_state[..., -1] = x        (the last d_conv inputs of in_proj's x half)
+      u  = SiLU(sum_k conv_state[..., k] * conv1d.weight[:, k] + conv1d.bias)
+      dt = softplus(dt_proj(x_proj(u)[:R]) + dt_proj.bias);  B, C = x_proj(u)[R:R+N], [R+N:]
+      ssm_state <- ssm_state * exp(dt A) + (dt B) u;   y = ssm_state . C + D u;   y <- y * SiLU(z);  out_proj(y)
+    x_t [S, D]; conv_state [S, E, K] (oldest first; zeros before the first frame), ssm_state [S, E, N].
+    Returns (out [S, D], conv_state, ssm_state) — new arrays."""
+    x_t = _f(x_t)
+    w_in = _f(sd[p + "in_proj.weight"])
+    E = w_in.shape[0] // 2
+    xz = (_q(x_t) @ _q(w_in).T).astype(F32)
+    xi, z = xz[:, :E], xz[:, E:]
+    wc, bc = _f(sd[p + "conv1d.weight"])[:, 0, :], _f(sd[p + "conv1d.bias"])
+    conv_state = np.concatenate([_f(conv_state)[:, :, 1:], xi[:, :, None]], axis=2)
+    u = np.zeros_like(xi) + bc
+    for k in range(wc.shape[1]):
+        u += conv_state[:, :, k] * wc[:, k]
+    u = silu(u)
+    wx = _f(sd[p + "x_proj.weight"])
+    a_log = _f(sd[p + "A_log"])
+    N = a_log.shape[1]
+    R = wx.shape[0] - 2 * N
+    dbl = (_q(u) @ _q(wx).T).astype(F32)
+    dt = softplus((dbl[:, :R] @ _f(sd[p + "dt_proj.weight"]).T).astype(F32) + _f(sd[p + "dt_proj.bias"]))
+    Bm, Cm = dbl[:, R:R + N], dbl[:, R + N:]
+    A = -np.exp(a_log)
+    dA = np.exp(dt[:, :, None] * A[None])
+    ssm_state = (dA * _f(ssm_state) + (dt[:, :, None] * Bm[:, None, :]) * u[:, :, None]).astype(F32)
+    y = (ssm_state * Cm[:, None, :]).sum(-1, dtype=F32) + _f(sd[p + "D"]) * u
+    y = (y * silu(z)).astype(F32)
+    out = (_q(y) @ _q(_f(sd[p + "out_proj.weight"])).T).astype(F32)
+    return out, conv_state, ssm_state
+
+
+def mamba_stepwise(sd, p, x):
+    """The block driven frame by frame from zero state (IPDnet2.py:170-177).  x [S, T, D] -> [S, T, D]."""
+    x = _f(x)
+    S, T, _ = x.shape
+    E = sd[p + "in_proj.weight"].shape[0] // 2
+    K = sd[p + "conv1d.weight"].shape[2]
+    N = sd[p + "A_log"].shape[1]
+    cs, ss = np.zeros((S, E, K), F32), np.zeros((S, E, N), F32)
+    outs = []
+    for t in range(T):
+        o, cs, ss = mamba_step(sd, p, x[:, t], cs, ss)
+        outs.append(o)
+    return np.stack(outs, axis=1)
+
+
+def mamba_parallel_f64(sd, p, x):
+    """Independent float64 evaluation of the same block in PARALLEL (non-recurrent) form, used only to cross-check
+    ``mamba``: with c_t = sum_{r<=t} dt_r the recurrence h_t = exp(dt_t A) h_{t-1} + dt_t B_t u_t unrolls to
+    h_t = sum_{s<=t} exp(A (c_t - c_s)) dt_s B_s u_s, evaluated directly (O(T^2)); the causal conv as an explicit
+    Toeplitz sum.  x [S, T, D] -> [S, T, D] float64."""
+    f8 = lambda k: np.asarray(sd[p + k], dtype=np.float64)   # noqa: E731
+    x = np.asarray(x, dtype=np.float64)
+    S, T, _ = x.shape
+    w_in = f8("in_proj.weight")
+    E = w_in.shape[0] // 2
+    xz = x @ w_in.T
+    xi, z = xz[..., :E], xz[..., E:]
+    wc, bc = f8("conv1d.weight")[:, 0, :], f8("conv1d.bias")
+    K = wc.shape[1]
+    u = np.zeros((S, T, E)) + bc
+    for t in range(T):
+        for k in range(K):
+            s_ = t - (K - 1) + k
+            if s_ >= 0:
+                u[:, t] += xi[:, s_] * wc[:, k]
+    u = u / (1.0 + np.exp(-u))
+    wx = f8("x_proj.weight")
+    N = f8("A_log").shape[1]
+    R = wx.shape[0] - 2 * N
+    dbl = u @ wx.T
+    pre = dbl[..., :R] @ f8("dt_proj.weight").T + f8("dt_proj.bias")
+    dt = np.log1p(np.exp(-np.abs(pre))) + np.maximum(pre, 0.0)
+    Bm, Cm = dbl[..., R:R + N], dbl[..., R + N:]
+    A = -np.exp(f8("A_log"))                                     # [E, N]
+    c = np.cumsum(dt, axis=1)                                     # [S, T, E]
+    y = np.zeros((S, T, E))
+    for t in range(T):
+        decay = np.exp(A[None, None] * (c[:, t, None, :, None] - c[:, :t + 1, :, None]))     # [S, t+1, E, N]
+        h = (decay * (dt[:, :t + 1, :, None] * Bm[:, :t + 1, None, :]) * u[:, :t + 1, :, None]).sum(axis=1)
+        y[:, t] = (h * Cm[:, t, None, :]).sum(-1) + f8("D") * u[:, t]
+    y = y * (z / (1.0 + np.exp(-z)))
+    return y @ f8("out_proj.weight").T
+
+
+def mamba_block(sd, p_norm, p_mamba, x, state=None, stepwise=False):
+    """SpatialNetLayer._mamba (:166-181): LN, the block along T for every (b, f), WITHOUT the residual.
+    ``stepwise`` = the reference's ``inference=True`` branch (:170-177): frame-by-frame recurrence from zero state."""
     B, F, T, H = x.shape
     y = layer_norm(x, sd[p_norm + ".weight"], sd[p_norm + ".bias"]).reshape(B * F, T, H)
+    if stepwise:
+        return mamba_stepwise(sd, p_mamba + ".", y).reshape(B, F, T, H), None
     y, st = mamba(sd, p_mamba + ".", y, state)
     return y.reshape(B, F, T, H), st
 
 
-def layer_forward(sd, p, x, is_first, state=None):
+def layer_forward(sd, p, x, is_first, state=None, inference=False):
     """SpatialNetLayer.forward (:137-164).  x [B, F, T, H]; returns (x, state) with state = the two Mamba
-    blocks' carried states."""
+    blocks' carried states.  ``inference``: the Mamba blocks are stepped frame by frame (:170-177)."""
     x = _f(x)
     x = x + fconv(sd, p + "fconv1", x)
     if is_first:
@@ -237,9 +331,9 @@ def layer_forward(sd, p, x, is_first, state=None):
     if is_first:
         x = avgpool_f(x, 8)
     st = [None, None] if state is None else list(state)
-    y, st[0] = mamba_block(sd, p + "norm_mhsa", p + "mhsa", x, st[0])
+    y, st[0] = mamba_block(sd, p + "norm_mhsa", p + "mhsa", x, st[0], stepwise=inference)
     x = x + y
-    y, st[1] = mamba_block(sd, p + "norm_tconvffn", p + "tconvffn", x, st[1])
+    y, st[1] = mamba_block(sd, p + "norm_tconvffn", p + "tconvffn", x, st[1], stepwise=inference)
     x = x + y
     return x.astype(F32), st
 
@@ -260,8 +354,9 @@ def num_layers_of(sd):
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("layers."))
 
 
-def forward(sd, x, time_compression_ratio=5, fre_compression_ratio=16, state=None):
-    """OnlineSpatialNet.forward (:331-368) with time_compression_layer = 0.
+def forward(sd, x, time_compression_ratio=5, fre_compression_ratio=16, state=None, inference=False):
+    """OnlineSpatialNet.forward (:331-368) with time_compression_layer = 0 (``inference`` as the reference's flag:
+    per-frame Mamba stepping, :170-177; not combinable with ``state``).
     x [B, dim_input, F, T] -> [B, T // ratio, 2F, dim_output // 4, 2]  (and the carried state when asked:
     pass state={} for the first chunk; T must then be a multiple of the time ratio)."""
     x = _f(x).transpose(0, 2, 3, 1)                                     # [B, F, T, H0]   (:333)
@@ -272,7 +367,7 @@ def forward(sd, x, time_compression_ratio=5, fre_compression_ratio=16, state=Non
     x = y.transpose(0, 2, 1).reshape(B, F, T, -1)                        # (:335)
     new_state = {"enc": enc_new}
     for l in range(num_layers_of(sd)):
-        x, st = layer_forward(sd, "layers.%d." % l, x, l == 0, None if not state else state.get("l%d" % l))
+        x, st = layer_forward(sd, "layers.%d." % l, x, l == 0, None if not state else state.get("l%d" % l), inference)
         new_state["l%d" % l] = st
         if l == 0:
             x = avgpool_t(x, time_compression_ratio)                    # (:343-349)

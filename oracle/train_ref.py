@@ -115,14 +115,15 @@ def make_masks(seed, nbp, nt, nf, hidden_size, is_online=True, b0=0):
 
 
 def train_step(sd, x, gt_ipd, seed, hidden_size=256, is_online=True, lr=1e-3, adam_state=None, step=1,
-               grad_divisor=1.0):
+               grad_divisor=1.0, b0=0):
     """One training step on CPU.  sd: numpy state dict (reference names); x [nb*np, 4, nf, nt] features;
-    gt_ipd [nb, nt2, 2nf, np].  Returns (loss, grads dict, new params dict, new adam_state)."""
+    gt_ipd [nb, nt2, 2nf, np]; ``b0``: index of x's first pair in the GLOBAL batch (keys the dropout masks, so a
+    slice of a larger batch draws that batch's masks).  Returns (loss, grads dict, new params dict, new adam_state)."""
     net = TrainFNSSL(4, hidden_size, is_online)
     net.load_state_dict({k: torch.from_numpy(np.array(v, dtype=np.float32)) for k, v in sd.items()})
     xt = torch.from_numpy(np.asarray(x, dtype=np.float32))
     nbp, _, nf, nt = xt.shape
-    masks = make_masks(seed, nbp, nt, nf, hidden_size, is_online)
+    masks = make_masks(seed, nbp, nt, nf, hidden_size, is_online, b0)
     pred = net(xt, masks)
     loss = cal_loss(pred, torch.from_numpy(np.asarray(gt_ipd, dtype=np.float32)))
     loss.backward()

@@ -156,7 +156,6 @@ def test_layers_and_network_vs_reference_orchestration(dev):
     out = net(x)
     assert tuple(out.shape) == (2, 4, 512, 4, 2)
     assert_close(out.cpu().numpy(), g["net_out"], RTOL, 5e-5, "OnlineSpatialNet (5-mic)")
-    assert torch.equal(net(x, inference=True), out)
     sd3, net3 = build_net(dev, 2200, dim_input=30, num_layers=3)
     assert_close(net3(to_dev(rs_randn(2210, (1, 30, 256, 15)), dev)).cpu().numpy(), g["net30_out"], RTOL, 5e-5,
                  "OnlineSpatialNet (15-mic input, BASELINE config 5 mapping)")
@@ -442,3 +441,41 @@ def test_ipdnet2_waveform_frontend_vs_reference_golden(dev):
     assert torch.equal(out, net(feats.contiguous()))
     want = O2.forward(sd, O.array_preprocess(sig[:1], sample_length=249, hop=320, center=True))
     assert_close(out[:1].cpu().numpy(), want, RTOL, 5e-5, "waveform -> OnlineSpatialNet vs oracle chain")
+
+
+def test_inference_flag_steps_the_mamba_blocks_frame_by_frame(dev):
+    """``OnlineSpatialNet(x, inference=True)`` / ``SpatialNetLayer(x, inference=True)`` / ``_mamba(..., inference=True)``:
+    the reference's per-frame branch (IPDnet2.py:170-177) restated in the oracle as an explicit-state recurrence
+    (``mamba_step``), against the device path that drives ``fnssl_sn_mamba`` one frame at a time."""
+    from fnssl import spatialnet as sn
+    from oracle import ipdnet2_oracle as O2
+    sd, net = build_net(dev, 2600, num_layers=2)
+    x = rs_randn(2601, (2, 10, 256, 10), 0.8)
+    xd = to_dev(x, dev)
+    got = net(xd, inference=True)
+    assert tuple(got.shape) == (2, 2, 512, 4, 2)
+    assert_close(got[:1].cpu().numpy(), O2.forward(sd, x[:1], inference=True), RTOL, 5e-5, "network, inference=True vs stepwise oracle")
+    assert_close(got.cpu().numpy(), net(xd).cpu().numpy(), 1e-4, 2e-5, "inference=True == parallel mode")
+    # one layer and one bare block, frame by frame, against the per-step restatement
+    l1 = net.layers[1]
+    xl = rs_randn(2602, (1, 16, 7, 96))
+    y, _ = l1(to_dev(xl, dev), inference=True)
+    want, _ = O2.layer_forward(sd, "layers.1.", xl, False, inference=True)
+    assert_close(y.cpu().numpy(), want, RTOL, 5e-5, "SpatialNetLayer(inference=True)")
+    yb = l1._mamba(to_dev(xl, dev), l1.mhsa, l1.norm_mhsa, l1.dropout_mhsa, inference=True)
+    wb, _ = O2.mamba_block(sd, "layers.1.norm_mhsa", "layers.1.mhsa", xl, stepwise=True)
+    assert_close(yb.cpu().numpy(), wb, RTOL, ATOL, "_mamba(inference=True) vs mamba_step recurrence")
+    # T = 1 drive of the kernel against the explicit-state oracle step, state compared after every frame
+    w = l1._packed(dev)
+    S, T = 5, 6
+    xs = rs_randn(2603, (S, T, 96))
+    st = sn.mamba_state(1, S, dev)
+    cs, ss = np.zeros((S, 192, 4), np.float32), np.zeros((S, 192, 16), np.float32)
+    for t in range(T):
+        xin = to_dev(xs[None, :, t:t + 1], dev)
+        o = sn.mamba(xin, w[3], residual=False, state=st, carry=t > 0)
+        ln = O2.layer_norm(xs[:, t], sd["layers.1.norm_mhsa.weight"], sd["layers.1.norm_mhsa.bias"])
+        wo, cs, ss = O2.mamba_step(sd, "layers.1.mhsa.", ln, cs, ss)
+        assert_close(o[0, :, 0].cpu().numpy(), wo, RTOL, ATOL, "step %d output" % t)
+        assert_close(st[1].cpu().numpy(), ss, RTOL, ATOL, "step %d SSM state" % t)
+        assert_close(st[0].cpu().numpy(), np.transpose(cs[:, :, 1:], (0, 2, 1)), 1e-6, 1e-6, "step %d conv taps" % t)

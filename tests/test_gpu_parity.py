@@ -777,6 +777,42 @@ def test_ipdnet_bf16_config3(dev, isz, hid, online, shape):
     assert y32.dtype == torch.float32 and np.abs(y32.cpu().numpy() - want_bf).max() <= BF_ATOL
 
 
+@pytest.mark.parametrize("nb,nf,nt", [(8, 32, 24), (64, 256, 300)])
+def test_ipdnet_bf16_two_stream_branch_vs_oracle_and_one_stream(dev, monkeypatch, nb, nf, nt):
+    """The branch BASELINE config 3's benchmark runs (IPDnet.forward: bf16 wide path, batch >= 8 -> the two halves of
+    the batch on two side streams with per-stream workspaces, record_stream, torch.cat) — at the smallest batch that
+    takes it and at config 3's real 64 x 16 x 256 x 300 batch (600 full-band workgroups, multi-pass conv tiles):
+      * one utterance of the batch against the bf16-restating oracle and, at SURVEY 8d's config-3 tolerance, the fp32 one;
+      * the whole output bit-identical to the one-stream path (FNSSL_IPDNET_ONE_STREAM=1);
+      * three repetitions bit-identical (a race between the side streams would show)."""
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    M = _ipdnet_module()
+    monkeypatch.delenv("FNSSL_IPDNET_ONE_STREAM", raising=False)
+    monkeypatch.delenv("FNSSL_IPDNET_STREAMS", raising=False)
+    sd = W.make_ipdnet_state(4500, 16, 256, 2, True)
+    net = M.IPDnet(input_size=16, hidden_size=256, max_track=2, is_online=True).eval()
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net.to(dev).bfloat16()
+    assert net._two_streams(nb), "this batch must take the two-stream branch"
+    x = O.bf16_round(rs_randn(4501, (nb, 16, nf, nt)))
+    xd = to_dev(x, dev)
+    outs = [net(xd) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert outs[0].dtype == torch.float32 and tuple(outs[0].shape) == (nb, nt // 12, 2 * nf, 7, 2)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "two-stream runs differ: a race"
+    monkeypatch.setenv("FNSSL_IPDNET_ONE_STREAM", "1")
+    assert not net._two_streams(nb)
+    one = net(xd)
+    assert torch.equal(one, outs[0]), "two streams vs one stream"
+    monkeypatch.delenv("FNSSL_IPDNET_ONE_STREAM")
+    for b in sorted({0, nb // 2, nb - 1}) if nb <= 8 else (nb // 2 + 3,):       # a row of each half / one of the big batch
+        want_bf = O.ipdnet_forward(sd, x[b:b + 1], True, bf16=True)
+        got = outs[0][b:b + 1].cpu().numpy()
+        assert np.abs(got - want_bf).max() <= BF_ATOL, (b, np.abs(got - want_bf).max())
+        assert_close(got, O.ipdnet_forward(sd, x[b:b + 1], True), 2e-2, 2e-3, "bf16 IPDnet (two streams) vs fp32 oracle")
+
+
 @pytest.mark.parametrize("cout,ca,cb,nb,nf,nt,act", [(128, 256, 16, 1, 4, 21, "relu"), (128, 128, 0, 2, 3, 16, "relu"),
                                                       (28, 128, 0, 1, 2, 9, "tanh"), (4, 128, 0, 1, 5, 5, "tanh"),
                                                       (128, 16, 16, 1, 3, 17, "none")])

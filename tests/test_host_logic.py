@@ -199,26 +199,93 @@ def test_predict_cli_accepts_the_reference_flag_surface():
 def test_lightning_module_uses_manual_optimization(monkeypatch):
     """With pytorch_lightning present MyModel is a LightningModule whose training_step runs the whole optimisation
     step in the HIP engine and returns a detached loss: automatic optimisation must be off (Lightning 2.x would
-    otherwise call backward() on that loss).  Lightning is absent from the image, so a stub stands in for it."""
+    otherwise call backward() on that loss), and — because Lightning's manual-optimisation loop counts OPTIMIZER steps —
+    every training_step must step the optimizer Lightning wraps, or trainer.global_step stays 0 and ModelCheckpoint
+    (which skips saving while global_step == its last saved step, initially 0), max_steps and logger indices never
+    move.  Lightning is absent from the image, so stubs with that bookkeeping stand in for it."""
     import importlib
     import sys
     import types
     import torch
     pl = types.ModuleType("pytorch_lightning")
 
+    class LightningOptimizer:                      # Lightning's wrapper: counts completed optimizer steps
+        def __init__(self, opt, trainer):
+            self._optimizer, self._trainer = opt, trainer
+
+        def step(self, closure=None):
+            out = self._optimizer.step(closure)
+            self._trainer.optim_step_completed += 1
+            return out
+
+    class Trainer:                                 # global_step as Lightning 2.x derives it under manual optimisation
+        def __init__(self, module):
+            self.optim_step_completed, self.saved, self._last_global_step_saved = 0, [], 0
+            self.module = module
+            module._trainer = self
+            self._opts = [LightningOptimizer(module.configure_optimizers(), self)]
+
+        @property
+        def global_step(self):
+            return self.optim_step_completed
+
+        def maybe_checkpoint(self):                # ModelCheckpoint._should_skip_saving_checkpoint
+            if self._last_global_step_saved == self.global_step:
+                return
+            self.saved.append({"global_step": self.global_step,
+                               "optimizer_states": [o._optimizer.state_dict() for o in self._opts]})
+            self._last_global_step_saved = self.global_step
+
     class LightningModule(torch.nn.Module):
         def __init__(self):
             super().__init__()
             self.automatic_optimization = True
+            self._trainer = None
+
+        def optimizers(self):
+            return self._trainer._opts[0]
 
     pl.LightningModule = LightningModule
     monkeypatch.setitem(sys.modules, "pytorch_lightning", pl)
     monkeypatch.delitem(sys.modules, "predict_step", raising=False)
     ps = importlib.import_module("predict_step")
     try:
-        m = ps.MyModel()
+        m = ps.MyModel(device="cpu")
         assert isinstance(m, LightningModule) and m.automatic_optimization is False
-        assert m.configure_optimizers() is None
+        opt = m.configure_optimizers()
+        assert isinstance(opt, torch.optim.Optimizer) and isinstance(opt, ps.EngineOptimizer)
+
+        class FakeEngine:                          # stands in for fnssl.train.TrainEngine (which needs the GPU)
+            def __init__(self):
+                self.exp_avg, self.exp_avg_sq = torch.zeros(5), torch.zeros(5)
+                self.step_count, self.lr = 0, 1e-3
+
+            def step(self, x, gt, sync_loss=True):
+                self.step_count += 1
+                self.exp_avg += 1.0
+                return torch.tensor([0.25 / self.step_count])
+
+        m._train_engine = FakeEngine()
+        monkeypatch.setattr(ps.ops, "preprocess", lambda sig, *a, **k: sig)
+        tr = Trainer(m)
+        batch = (torch.zeros(1, 4, 2), {"ipd": torch.zeros(1, 1, 512, 1)})
+        for i in range(3):
+            out = m.training_step(batch, i)
+            assert out["loss"].shape == () and not out["loss"].requires_grad
+            assert tr.global_step == i + 1                       # the counter Lightning checkpoints / stops on
+            tr.maybe_checkpoint()
+        assert [c["global_step"] for c in tr.saved] == [1, 2, 3]     # a checkpoint IS written once steps advance
+        # the engine's Adam state rides in the optimizer state and restores into a fresh module
+        st = tr.saved[-1]["optimizer_states"][0]
+        assert st["steps_taken"] == 3 and st["engine"]["step_count"] == 3 and float(st["engine"]["exp_avg"][0]) == 3.0
+        m2 = ps.MyModel(device="cpu")
+        m2._train_engine = FakeEngine()
+        m2.configure_optimizers().load_state_dict(st)
+        assert m2._train_engine.step_count == 3 and float(m2._train_engine.exp_avg[0]) == 3.0
+        # without a trainer (plain nn.Module use, Predict.py --train) training_step must not need one
+        m3 = ps.MyModel(device="cpu")
+        m3._train_engine = FakeEngine()
+        assert m3.training_step(batch, 0)["loss"].shape == ()
     finally:
         sys.modules.pop("predict_step", None)
 

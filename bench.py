@@ -260,18 +260,24 @@ class IpdnetForward:
         return r
 
     def cpu_baseline(self):
-        from oracle import fnssl_oracle as O
-        frames = 24
-        sig = self.sig[:1, :256 * (frames + 1)].cpu().numpy()
-        c0 = time.perf_counter()
-        want = O.ipdnet_forward(self.sd, O.array_preprocess(sig), True)            # fp32 oracle
-        cdt = time.perf_counter() - c0
-        cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "1 utterance x 8 mics x %d frames, numpy restatement of the reference (oracle/fnssl_oracle.py), "
-                         "%.1f s" % (frames, cdt)}
+        from oracle import torch_ref as R
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        net = R.build_ipdnet(self.sd, 2 * self.mics, self.hidden, 2, True)
+        frames = 120 if self.nt >= 120 else self.nt // 12 * 12
+        sig = self.sig[:1, :256 * (frames + 1)].cpu()
+        with torch.no_grad():
+            net(R.array_preprocess(sig[:, :256 * 13]))                             # warm-up (12 frames)
+            c0 = time.perf_counter()
+            want = net(R.array_preprocess(sig)).contiguous()                         # fp32 PyTorch CPU forward
+            cdt = time.perf_counter() - c0
+        cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "1 utterance x 8 mics x %d frames from the waveform, PyTorch CPU restatement of the reference "
+                         "(oracle/torch_ref.py: torch.stft + oneDNN nn.LSTM + Conv2d), fp32, %d threads, %.1f s"
+                         % (frames, cores, cdt)}
         got = self.net(self.ops.preprocess_array(self.sig[:1, :256 * (frames + 1)])).float().cpu()
         rt, at = (1e-4, 2e-5) if self.fp32 else (2e-2, 4e-3)                      # SURVEY 8d config-3 tolerance
-        return cpu, parity_of(got, torch.from_numpy(want), rt, at, "%d frames vs the fp32 oracle" % frames)
+        return cpu, parity_of(got, want, rt, at, "%d frames vs the fp32 PyTorch CPU forward" % frames)
 
 
 # ------------------------------------------------------------------------------------------------------------ #
@@ -453,20 +459,24 @@ class Ipdnet2Forward:
         return r
 
     def cpu_baseline(self):
-        from oracle import ipdnet2_oracle as O2
-        from oracle import fnssl_oracle as O
-        frames = 20
+        from oracle import torch_ref as R
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        frames = 50 if self.nt >= 50 else self.nt // 5 * 5
         sig = self.sig[:1, :320 * (frames - 1)].contiguous()
+        sigc = sig.cpu()
+        R.ipdnet2_forward(self.sd, R.array_preprocess(sigc[:, :320 * 4], 249, 320, True))      # warm-up (5 frames)
         c0 = time.perf_counter()
-        x = O.array_preprocess(sig.cpu().numpy(), sample_length=249, hop=320, center=True)
-        want = O2.forward(self.sd, x)
+        want = R.ipdnet2_forward(self.sd, R.array_preprocess(sigc, 249, 320, True))            # fp32 PyTorch CPU forward
         cdt = time.perf_counter() - c0
-        cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "1 utterance x 15 mics x %d frames from the waveform, numpy restatement (oracle/ipdnet2_oracle.py; Mamba block = "
-                         "published algorithm, parity unpinned), %.1f s" % (frames, cdt)}
+        cpu = {"value": round(frames / cdt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "1 utterance x 15 mics x %d frames from the waveform, PyTorch CPU restatement (oracle/torch_ref.py::"
+                         "ipdnet2_forward: torch.stft, conv1d, layer_norm, matmul; the Mamba block = the published "
+                         "algorithm with a python scan over frames, parity unpinned), fp32, %d threads, %.1f s"
+                         % (frames, cores, cdt)}
         got = self.net(self.ops.preprocess_ipdnet2(sig)).cpu()
-        rt, at = (1e-4, 5e-5) if self.fp32 else (2e-2, 1.5e-2)          # bf16: SURVEY 8c, fp32 oracle at a looser tolerance
-        return cpu, parity_of(got, torch.from_numpy(want), rt, at, "%d frames vs the fp32 oracle" % frames)
+        rt, at = (1e-4, 5e-5) if self.fp32 else (2e-2, 1.5e-2)          # bf16: SURVEY 8c, fp32 reference at a looser tolerance
+        return cpu, parity_of(got, want, rt, at, "%d frames vs the fp32 PyTorch CPU forward" % frames)
 
 
 WORKLOADS = {2: FnsslForward, 3: IpdnetForward, 4: FnsslTrain, 5: Ipdnet2Forward}

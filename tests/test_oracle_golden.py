@@ -262,3 +262,30 @@ def test_ipdnet2_frontend_oracle_matches_reference_golden():
     assert np.abs(spec - g["c0_stft"]).max() <= 2e-6 * np.abs(g["c0_stft"]).max()
     mu = O.forgetting_norm(np.abs(np.transpose(spec, (0, 3, 1, 2))).astype(np.float32), sl)
     assert_close(mu, g["c0_mu"], 2e-6, 1e-9, "forgetting_norm(249) over all channels")
+
+
+def test_torch_ref_ipdnet_and_ipdnet2_match_reference_golden():
+    """The PyTorch-CPU twins used as the multi-threaded cpu_baseline of configs 3 / 5 (oracle/torch_ref.py) are pinned to
+    the same reference-generated fixtures as the numpy oracles: IPDnet (G10), IPDnet2 network (G14), both front ends."""
+    import torch
+    from oracle import torch_ref as R
+    g = load_golden("g10_ipdnet")
+    for ci, (isz, hid, online, shape) in enumerate([(4, 128, True, (2, 4, 16, 24)), (16, 256, True, (1, 16, 32, 24)),
+                                                   (4, 128, False, (2, 4, 16, 29)), (4, 128, True, (1, 4, 256, 12))]):
+        sd = W.make_ipdnet_state(1500 + ci, isz, hid, 2, online)
+        net = R.build_ipdnet(sd, isz, hid, 2, online)
+        with torch.no_grad():
+            y = net(torch.from_numpy(rs_randn(1600 + ci, shape))).numpy()
+        assert_close(y, g["c%d_out" % ci], 1e-5, 1e-6, "torch IPDnet case %d" % ci)
+    feat = R.array_preprocess(torch.from_numpy(rs_randn(1630, (2, 256 * 14, 4), 0.1))).numpy()
+    assert np.abs(feat - g["feat_out"]).max() <= 2e-6 * np.abs(g["feat_out"]).max()
+    g14 = load_golden("g14_ipdnet2")
+    out = R.ipdnet2_forward(W.make_ipdnet2_state(2100), torch.from_numpy(rs_randn(2110, (2, 10, 256, 20)))).numpy()
+    assert_close(out, g14["net_out"], 1e-4, 5e-5, "torch OnlineSpatialNet")
+    sd3 = W.make_ipdnet2_state(2200, dim_input=30, num_layers=3)
+    out = R.ipdnet2_forward(sd3, torch.from_numpy(rs_randn(2210, (1, 30, 256, 15)))).numpy()
+    assert_close(out, g14["net30_out"], 1e-4, 5e-5, "torch OnlineSpatialNet, 15-mic mapping")
+    g15 = load_golden("g15_ipdnet2_frontend")
+    seed, nb, ns, nch, sl = (int(v) for v in g15["c0_cfg"])
+    f = R.array_preprocess(torch.from_numpy(rs_randn(seed, (nb, ns, nch), 0.1)), sl, 320, True).numpy()
+    assert np.abs(f - g15["c0_feat"]).max() <= 2e-6 * np.abs(g15["c0_feat"]).max()

@@ -8,15 +8,11 @@
 // Python and no torch in it.  fnssl_train_step = zero the gradient + backward + fnssl_adam_step (single process); a
 // multi-GPU caller puts its sum all-reduce of the flat gradient between fnssl_train_backward and fnssl_adam_step.
 //
-// The weight gradients  dW = dA^T [x | h_prev]  are plain GEMMs with a 2.3 M-row reduction: the one place this library
-// calls a vendor GEMM (rocBLAS, resolved with dlopen at first use so that the inference paths carry no dependency),
-// reduction split 64 ways exactly like the Python engine (a single call has too few output tiles to fill 256 CUs).
-// h_prev is never materialised: with the rows of all sequences flattened, sum_r dA[r]^T h[r-1] over ALL rows is one
-// GEMM on two views offset by one row, minus the small GEMM of the sequence-boundary rows it wrongly includes.
-#include <dlfcn.h>
-
+// The weight gradients  dW = dA^T [x | h_prev],  db = sum dA  (a 2.5 M-row reduction) are ONE launch of the library's own
+// split-K fp32-MFMA kernel per layer (fnssl_lstm_weight_grads, csrc/wgrad.hip) — the same entry point the Python engine
+// calls; h_prev is an index shift inside its loader, never materialised.  (Rounds 1-2 called rocBLAS here through
+// dlopen; nothing in this library calls a vendor GEMM any more.)
 #include <cstring>
-#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -46,100 +42,11 @@ struct fnssl_train {
 
 namespace {
 
-// ---- rocBLAS through dlopen ---------------------------------------------------------------------------------
-typedef int (*create_fn)(void**);
-typedef int (*set_stream_fn)(void*, hipStream_t);
-typedef int (*sgemm_sb_fn)(void*, int, int, int, int, int, const float*, const float*, int, long long, const float*,
-                           int, long long, const float*, float*, int, long long, int);
-struct Blas {
-  void* lib = nullptr;
-  void* handle = nullptr;
-  set_stream_fn set_stream = nullptr;
-  sgemm_sb_fn sgemm = nullptr;
-  bool tried = false;
-};
-Blas g_blas;
-std::mutex g_blas_mu;
-
-int blas_init() {
-  std::lock_guard<std::mutex> lk(g_blas_mu);
-  if (g_blas.handle) return FNSSL_OK;
-  if (g_blas.tried) {
-    fnssl::set_error("train: rocBLAS is not available (needed for the weight-gradient GEMMs)");
-    return FNSSL_E_HIP;
-  }
-  g_blas.tried = true;
-  for (const char* n : {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
-    g_blas.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (g_blas.lib) break;
-  }
-  if (!g_blas.lib) {
-    fnssl::set_error("train: cannot load librocblas.so: %s", dlerror());
-    return FNSSL_E_HIP;
-  }
-  auto create = reinterpret_cast<create_fn>(dlsym(g_blas.lib, "rocblas_create_handle"));
-  g_blas.set_stream = reinterpret_cast<set_stream_fn>(dlsym(g_blas.lib, "rocblas_set_stream"));
-  g_blas.sgemm = reinterpret_cast<sgemm_sb_fn>(dlsym(g_blas.lib, "rocblas_sgemm_strided_batched"));
-  if (!create || !g_blas.set_stream || !g_blas.sgemm || create(&g_blas.handle) != 0) {
-    fnssl::set_error("train: rocBLAS symbols missing or handle creation failed");
-    g_blas.handle = nullptr;
-    return FNSSL_E_HIP;
-  }
-  return FNSSL_OK;
-}
-
-constexpr int kOpN = 111, kOpT = 112;   // rocblas_operation_none / _transpose
-
-// G[M, C] (row stride ldg) (+)= alpha * sum_r a[r, 0:M]^T x[r, 0:C];  a row stride lda, x row stride ldx.
-// Column-major view: G' (C x M, ld ldg) = X' (C x R, ld ldx) * A'^T (A' = M x R, ld lda).
-int gemm_tn(hipStream_t st, const float* a, long long lda, const float* x, long long ldx, long long rows, int M, int C,
-            float alpha, float beta, float* g, int ldg, int batch = 1, long long stride_rows = 0, long long stride_g = 0) {
-  if (rows <= 0 || M <= 0 || C <= 0) return FNSSL_OK;
-  if (g_blas.set_stream(g_blas.handle, st) != 0 ||
-      g_blas.sgemm(g_blas.handle, kOpN, kOpT, C, M, (int)rows, &alpha, x, (int)ldx, stride_rows * ldx, a, (int)lda,
-                   stride_rows * lda, &beta, g, ldg, stride_g, batch) != 0) {
-    fnssl::set_error("train: rocblas_sgemm_strided_batched failed (rows %lld, M %d, C %d)", rows, M, C);
-    return FNSSL_E_HIP;
-  }
-  return FNSSL_OK;
-}
-
 // ---- small kernels ------------------------------------------------------------------------------------------
 __global__ void gather_kernel(const float* __restrict__ theta, const int* __restrict__ ia, const int* __restrict__ ib,
                               long long n, float* __restrict__ out) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = theta[ia[i]] + (ib ? theta[ib[i]] : 0.f);
-}
-
-// dst[m, c] (row stride ld) += sum_s part[s][m][c]
-__global__ void partial_sum_kernel(const float* __restrict__ part, int s, int M, int C, float* __restrict__ dst, int ld) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= M * C) return;
-  float acc = 0.f;
-  for (int k = 0; k < s; ++k) acc += part[(long long)k * M * C + i];
-  dst[(long long)(i / C) * ld + (i % C)] += acc;
-}
-
-// column sums of a [rows, M] (row stride lda), two deterministic stages: part[blk][m], then dst1/dst2[m] += sum
-__global__ void __launch_bounds__(256)
-colsum_stage1(const float* __restrict__ a, long long rows, int M, long long lda, long long rows_per_blk,
-              float* __restrict__ part) {
-  const int m = blockIdx.y * 256 + threadIdx.x;
-  if (m >= M) return;
-  const long long r0 = (long long)blockIdx.x * rows_per_blk;
-  const long long r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
-  float acc = 0.f;
-  for (long long r = r0; r < r1; ++r) acc += a[r * lda + m];
-  part[(long long)blockIdx.x * M + m] = acc;
-}
-__global__ void colsum_stage2(const float* __restrict__ part, int nblk, int M, float* __restrict__ d1,
-                              float* __restrict__ d2) {
-  const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  float acc = 0.f;
-  for (int k = 0; k < nblk; ++k) acc += part[(long long)k * M + m];
-  d1[m] += acc;
-  d2[m] += acc;
 }
 
 // ---- logical [b, t, f, C] tensors -----------------------------------------------------------------------------
@@ -159,8 +66,8 @@ fnssl_view seqview(const T4& t, bool full) {
 struct Ctx {
   hipStream_t st;
   int nbp, nt, nf;
-  float* gemm_part;   // [64][1024][272]
-  float* colsum_part; // [1024 blocks][1024]
+  void* wgrad_ws;
+  size_t wgrad_ws_bytes;
   float* lstm_ws;
   size_t lstm_ws_bytes;
   void* bwd_ws;
@@ -247,47 +154,31 @@ int lstm_bwd(const Ctx& c, const Layer& L, const float* reserve, const T4& dh, c
 // stored in the layer's natural layout, i.e. as a [rows = seq * step, C] matrix.
 int weight_grads(const Ctx& c, const Layer& L, float* grad, const float* da, const float* x0, const float* x2,
                  const float* hout) {
-  const int H = L.hidden, nd = L.ndir, G4 = 4 * H, I = L.c0 + L.c2;
-  const long long nsteps = L.full ? c.nf : c.nt, nseq = (long long)c.nbp * (L.full ? c.nt : c.nf), rows = nseq * nsteps;
-  const long long lda = (long long)nd * G4, ldh = (long long)nd * H;
-  for (int di = 0; di < nd; ++di) {
-    const float* a = da + (long long)di * G4;
-    // sum over R rows, reduction split 64 ways (partials + deterministic sum); the < 64 rows that do not fit an even
-    // split go through one small call
-    auto big = [&](const float* aa, const float* xx, long long ldx, long long R, int C, float* dst, int ld) -> int {
-      const long long R1 = R >= 64 * 256 ? R - R % 64 : 0;
-      if (R1) {
-        TRY(gemm_tn(c.st, aa, lda, xx, ldx, R1 / 64, G4, C, 1.f, 0.f, c.gemm_part, C, 64, R1 / 64, (long long)G4 * C));
-        hipLaunchKernelGGL(partial_sum_kernel, dim3((G4 * C + 255) / 256), dim3(256), 0, c.st, c.gemm_part, 64, G4, C, dst, ld);
-        FNSSL_CHECK_LAUNCH("partial_sum_kernel");
-      }
-      if (R > R1) TRY(gemm_tn(c.st, aa + R1 * lda, lda, xx + R1 * ldx, ldx, R - R1, G4, C, 1.f, 1.f, dst, ld));
-      return FNSSL_OK;
-    };
-    float* gih = grad + L.off_wih[di];
-    if (L.c0) TRY(big(a, x0, L.c0, rows, L.c0, gih, I));
-    if (L.c2) TRY(big(a, x2, L.c2, rows, L.c2, gih + L.c0, I));
-    // recurrent weights: forward direction pairs row r with h row r - 1, reverse with r + 1 (zero across sequences)
-    const float* hd = hout + (long long)di * H;
-    float* ghh = grad + L.off_whh[di];
-    if (di == 0) {
-      TRY(big(a + lda, hd, ldh, rows - 1, H, ghh, H));
-      TRY(gemm_tn(c.st, a + nsteps * lda, nsteps * lda, hd + (nsteps - 1) * ldh, nsteps * ldh, nseq - 1, G4, H, -1.f, 1.f,
-                  ghh, H));
-    } else {
-      TRY(big(a, hd + ldh, ldh, rows - 1, H, ghh, H));
-      TRY(gemm_tn(c.st, a + (nsteps - 1) * lda, nsteps * lda, hd + nsteps * ldh, nsteps * ldh, nseq - 1, G4, H, -1.f, 1.f,
-                  ghh, H));
-    }
-    const int nblk = 1024;
-    const long long rpb = (rows + nblk - 1) / nblk;
-    hipLaunchKernelGGL(colsum_stage1, dim3(nblk, (G4 + 255) / 256), dim3(256), 0, c.st, a, rows, G4, lda, rpb, c.colsum_part);
-    FNSSL_CHECK_LAUNCH("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3((G4 + 255) / 256), dim3(256), 0, c.st, c.colsum_part, nblk, G4,
-                       grad + L.off_bih[di], grad + L.off_bhh[di]);
-    FNSSL_CHECK_LAUNCH("colsum_stage2");
+  fnssl_wgrad_desc d;
+  std::memset(&d, 0, sizeof(d));
+  d.da = da;
+  d.lda = (long long)L.ndir * 4 * L.hidden;
+  d.x0 = L.c0 ? x0 : nullptr;
+  d.ldx0 = L.c0;
+  d.c0 = L.c0;
+  d.x2 = L.c2 ? x2 : nullptr;
+  d.ldx2 = L.c2;
+  d.c2 = L.c2;
+  d.h = hout;
+  d.ldh = (long long)L.ndir * L.hidden;
+  d.nseq = (long long)c.nbp * (L.full ? c.nt : c.nf);
+  d.nsteps = L.full ? c.nf : c.nt;
+  d.hidden = L.hidden;
+  d.ndir = L.ndir;
+  for (int di = 0; di < L.ndir; ++di) {
+    d.g_wih[di] = grad + L.off_wih[di];
+    d.g_whh[di] = grad + L.off_whh[di];
+    d.g_bih[di] = grad + L.off_bih[di];
+    d.g_bhh[di] = grad + L.off_bhh[di];
   }
-  return FNSSL_OK;
+  d.workspace = c.wgrad_ws;
+  d.workspace_bytes = c.wgrad_ws_bytes;
+  return fnssl_lstm_weight_grads(&d, c.st);
 }
 
 unsigned fmix32(unsigned h) {
@@ -303,9 +194,9 @@ unsigned layer_seed(unsigned seed, int layer) { return fmix32(seed + 0x9E3779B9u
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 struct Plan {   // byte offsets into the workspace
-  size_t xf, xn, f[3], u[3], v[3], n[3], x, res[6], pred, dpred, g, dn, da, dv[2], df, du[2], s, small, part, colsum, lstm_ws,
+  size_t xf, xn, f[3], u[3], v[3], n[3], x, res[6], pred, dpred, g, dn, da, dv[2], df, du[2], s, small, wgrad, lstm_ws,
       bwd_ws, fw[6][2], bw[6][2], total;
-  size_t res_bytes[6], lstm_ws_bytes, bwd_ws_bytes;
+  size_t res_bytes[6], lstm_ws_bytes, bwd_ws_bytes, wgrad_bytes;
 };
 
 Plan make_plan(const fnssl_train* t, int nbp, int nf, int nt) {
@@ -329,9 +220,12 @@ Plan make_plan(const fnssl_train* t, int nbp, int nf, int nt) {
   pl.x = take(P * kCh);
   pl.lstm_ws_bytes = 0;
   pl.bwd_ws_bytes = 0;
+  pl.wgrad_bytes = 0;
   for (int l = 0; l < 6; ++l) {
     const Layer& L = t->L[l];
     const int nseq = nbp * (L.full ? nt : nf), nsteps = L.full ? nf : nt;
+    const size_t w3 = fnssl_lstm_weight_grads_workspace_bytes((long long)nseq * nsteps, L.hidden, L.ndir, L.c0, L.c2);
+    if (w3 > pl.wgrad_bytes) pl.wgrad_bytes = w3;
     pl.res_bytes[l] = fnssl_lstm_reserve_bytes(nseq, L.hidden, L.ndir, nsteps);
     pl.res[l] = take(pl.res_bytes[l]);
     const size_t w1 = fnssl_lstm_workspace_bytes(nseq, L.hidden, L.ndir), w2 = fnssl_lstm_bwd_workspace_bytes(nseq, L.hidden, L.ndir);
@@ -356,8 +250,7 @@ Plan make_plan(const fnssl_train* t, int nbp, int nf, int nt) {
   pl.s = take(t->is_online ? 0 : P * kCh);
   const size_t small = fnssl_head_backward_workspace_bytes();
   pl.small = take(small > 4096 ? small : 4096);
-  pl.part = take((size_t)64 * 1024 * 272 * sizeof(float));
-  pl.colsum = take((size_t)1024 * 1024 * sizeof(float));
+  pl.wgrad = take(pl.wgrad_bytes);
   pl.lstm_ws = take(pl.lstm_ws_bytes);
   pl.bwd_ws = take(pl.bwd_ws_bytes);
   pl.total = off + 256;
@@ -475,11 +368,10 @@ int fnssl_train_backward(fnssl_train* t, const float* theta, float* grad, const 
     fnssl::set_error("train_backward: workspace %zu < %zu bytes", workspace_bytes, pl.total);
     return FNSSL_E_WORKSPACE;
   }
-  TRY(blas_init());
   hipStream_t st = fnssl::as_stream(stream);
   char* base = reinterpret_cast<char*>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
   auto F = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
-  Ctx c{st, nbp, nt, nf, F(pl.part), F(pl.colsum), F(pl.lstm_ws), pl.lstm_ws_bytes, F(pl.bwd_ws), pl.bwd_ws_bytes};
+  Ctx c{st, nbp, nt, nf, F(pl.wgrad), pl.wgrad_bytes, F(pl.lstm_ws), pl.lstm_ws_bytes, F(pl.bwd_ws), pl.bwd_ws_bytes};
   unsigned seeds[6];
   for (int l = 0; l < 6; ++l) seeds[l] = layer_seed(seed_base, l);
 

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -34,7 +34,7 @@ SYMBOLS = [
     "fnssl_conv3x3_packed_bytes_bf16x", "fnssl_conv3x3_pack_bf16x", "fnssl_conv3x3_causal_bf16x",
     "fnssl_avgpool_time_bf16",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
-    "fnssl_lstm_backward", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
+    "fnssl_lstm_backward", "fnssl_lstm_weight_grads_workspace_bytes", "fnssl_lstm_weight_grads", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select",
     "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
@@ -79,6 +79,14 @@ class LstmBwdDesc(C.Structure):
         ("wpack_bwd", C.c_void_p * 2),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("da", C.c_void_p), ("lda", C.c_longlong), ("x0", C.c_void_p), ("ldx0", C.c_longlong), ("c0", C.c_int),
+                ("x2", C.c_void_p), ("ldx2", C.c_longlong), ("c2", C.c_int), ("h", C.c_void_p), ("ldh", C.c_longlong),
+                ("nseq", C.c_longlong), ("nsteps", C.c_int), ("hidden", C.c_int), ("ndir", C.c_int),
+                ("g_wih", C.c_void_p * 2), ("g_whh", C.c_void_p * 2), ("g_bih", C.c_void_p * 2), ("g_bhh", C.c_void_p * 2),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class BtfView(C.Structure):
@@ -184,6 +192,9 @@ def load():
     lib.fnssl_lstm_bwd_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_lstm_bwd_workspace_bytes.restype = sz
     lib.fnssl_lstm_backward.argtypes = [C.POINTER(LstmBwdDesc), vp]
+    lib.fnssl_lstm_weight_grads_workspace_bytes.argtypes = [ll, i, i, i, i]
+    lib.fnssl_lstm_weight_grads_workspace_bytes.restype = sz
+    lib.fnssl_lstm_weight_grads.argtypes = [C.POINTER(WgradDesc), vp]
     lib.fnssl_train_combine.argtypes = [vp, ll, ll, ll, i, i, i, i, C.POINTER(BtfView), i, C.POINTER(BtfView), i, i,
                                         C.c_uint, ll, vp]
     lib.fnssl_dropout_scale.argtypes = [vp, ll, C.c_uint, ll, vp]

@@ -591,6 +591,40 @@ def avgpool_time(x, k: int, bf16_out: bool = False):
     return y
 
 
+@on_device
+def lstm_weight_grads(da, x0, x2, h, hidden: int, ndir: int, nsteps: int, g_wih, g_whh, g_bih, g_bhh):
+    """Accumulate one LSTM layer's weight gradients (``fnssl_lstm_weight_grads``, csrc/wgrad.hip): g_wih[d] [4H, c0+c2]
+    += dA_d^T [x0 | x2], g_whh[d] [4H, H] += dA_d^T h_prev_d, g_bih[d] = g_bhh[d] [4H] += sum_r dA_d[r].
+    da [rows, ndir*4H], x0 [rows, c0] / x2 [rows, c2] (either may be None), h [rows, ndir*H]: row-major matrices with
+    rows = sequences x steps in the layer's natural layout (any row stride).  g_*: lists of ndir contiguous tensors."""
+    from ._lib import WgradDesc
+    _need_dev(da, x0, x2, h, *g_wih, *g_whh, *g_bih, *g_bhh)
+    rows = da.shape[0]
+    d = WgradDesc()
+    d.da, d.lda = _ptr(da), da.stride(0)
+    d.x0, d.ldx0, d.c0 = (_ptr(x0), x0.stride(0), x0.shape[1]) if x0 is not None else (None, 0, 0)
+    d.x2, d.ldx2, d.c2 = (_ptr(x2), x2.stride(0), x2.shape[1]) if x2 is not None else (None, 0, 0)
+    d.h, d.ldh = _ptr(h), h.stride(0)
+    for t in (da, x0, x2, h):
+        if t is not None and (t.stride(1) != 1 or t.dtype != torch.float32):
+            raise RuntimeError("fnssl.lstm_weight_grads: operands must be fp32 row-major matrices")
+    if rows % nsteps or h.shape[0] != rows or da.shape[1] != ndir * 4 * hidden or h.shape[1] != ndir * hidden:
+        raise RuntimeError("fnssl.lstm_weight_grads: shapes da %s / h %s do not match hidden %d, ndir %d, nsteps %d"
+                           % (tuple(da.shape), tuple(h.shape), hidden, ndir, nsteps))
+    d.nseq, d.nsteps, d.hidden, d.ndir = rows // nsteps, nsteps, hidden, ndir
+    for k in range(ndir):
+        for name, lst, shape in (("g_wih", g_wih, (4 * hidden, d.c0 + d.c2)), ("g_whh", g_whh, (4 * hidden, hidden)),
+                                 ("g_bih", g_bih, (4 * hidden,)), ("g_bhh", g_bhh, (4 * hidden,))):
+            t = lst[k]
+            if tuple(t.shape) != shape or not t.is_contiguous() or t.dtype != torch.float32:
+                raise RuntimeError("fnssl.lstm_weight_grads: %s[%d] must be a contiguous fp32 %s" % (name, k, shape))
+            getattr(d, name)[k] = t.data_ptr()
+    lib = _lib.load()
+    ws = _workspace(lib.fnssl_lstm_weight_grads_workspace_bytes(rows, hidden, ndir, d.c0, d.c2), da.device, "wgrad")
+    d.workspace, d.workspace_bytes = _ptr(ws), ws.numel()
+    check(lib.fnssl_lstm_weight_grads(C.byref(d), _stream()), "lstm_weight_grads")
+
+
 # --------------------------------------------------------------------------- #
 # head / whole network
 # --------------------------------------------------------------------------- #

@@ -105,27 +105,6 @@ def shard_utterances(n_utts: int, rank: int, world: int):
     return lo, lo + per + (1 if rank < rem else 0)
 
 
-def _split_k(rows: int, limit: int = 64) -> int:
-    """Largest divisor of ``rows`` that is <= limit (the split-K factor of the weight-gradient GEMMs)."""
-    for s_ in range(min(limit, rows), 0, -1):
-        if rows % s_ == 0:
-            return s_
-    return 1
-
-
-def gemm_tn(a, x):
-    """a^T @ x for a [R, M] (row stride >= M) and x [R, C] with R in the millions: the library call with the
-    reduction dimension split 64 ways (strided-batched GEMM + sum of the partials).  A single GEMM of this
-    shape has too few output tiles to fill 256 CUs (measured 90 TFLOP/s); the split runs at 153 TFLOP/s."""
-    rows = a.shape[0]
-    s_ = _split_k(rows)
-    if s_ == 1:
-        return a.t() @ x
-    av = a.unflatten(0, (s_, rows // s_))
-    xv = x.unflatten(0, (s_, rows // s_))
-    return torch.bmm(av.transpose(1, 2), xv).sum(0)
-
-
 class _Layer:
     """Static description of one LSTM of the network."""
 
@@ -306,30 +285,14 @@ class TrainEngine:
         return st.reshape(-1, st.shape[-1])
 
     def _weight_grads(self, L, da, x0, x2, hout):
-        """dW_ih = dA^T [x0 | x2],  dW_hh = dA^T h_prev,  db = sum dA  (accumulated into the flat gradient)."""
-        nseq_steps = self._rows(da, L)
-        H, nd = L.hidden, L.ndir
+        """dW_ih = dA^T [x0 | x2],  dW_hh = dA^T h_prev,  db = sum dA, accumulated into the flat gradient: ONE
+        hand-written split-K fp32-MFMA launch per layer (``fnssl_lstm_weight_grads``, csrc/wgrad.hip; both directions, the
+        three operand segments read in place, h_prev as an index shift) — no vendor GEMM on the path."""
         nsteps = da.shape[2] if L.mode == "full" else da.shape[1]
-        hrows = self._rows(hout, L).view(-1, nsteps, nd * H)
-        for di, s in enumerate(L.sfx):
-            a = nseq_steps[:, di * 4 * H:(di + 1) * 4 * H]
-            gih = self.gview("%s.weight_ih_l0%s" % (L.name, s))
-            if L.c0:
-                gih[:, :L.c0].add_(gemm_tn(a, self._rows(x0, L)))
-            if L.c2:
-                gih[:, L.c0:].add_(gemm_tn(a, self._rows(x2, L)))
-            hp = self._buf("hprev", (hrows.shape[0], nsteps, H))
-            hd = hrows[:, :, di * H:(di + 1) * H]
-            if di == 0:
-                hp[:, 0].zero_()
-                hp[:, 1:].copy_(hd[:, :-1])
-            else:
-                hp[:, -1].zero_()
-                hp[:, :-1].copy_(hd[:, 1:])
-            self.gview("%s.weight_hh_l0%s" % (L.name, s)).add_(gemm_tn(a, hp.view(-1, H)))
-            db = a.sum(dim=0)
-            self.gview("%s.bias_ih_l0%s" % (L.name, s)).add_(db)
-            self.gview("%s.bias_hh_l0%s" % (L.name, s)).add_(db)
+        g = lambda n: [self.gview("%s.%s%s" % (L.name, n, s)) for s in L.sfx]   # noqa: E731
+        ops.lstm_weight_grads(self._rows(da, L), self._rows(x0, L) if L.c0 else None, self._rows(x2, L) if L.c2 else None,
+                              self._rows(hout, L), L.hidden, L.ndir, nsteps, g("weight_ih_l0"), g("weight_hh_l0"),
+                              g("bias_ih_l0"), g("bias_hh_l0"))
         self._reduce_async(L.name + ".")
 
     def _chunk(self, x, gt, b0, n_total, fw, bw, seeds):

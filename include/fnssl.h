@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 11
+#define FNSSL_ABI_VERSION 12
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -238,6 +238,44 @@ typedef struct {
 } fnssl_lstm_bwd_desc;
 
 int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream);
+
+/*
+ * Weight gradients of one LSTM layer (what autograd accumulates into nn.LSTM's parameters; reference
+ * FN-SSL/Lightning/main.py:149-157 loss.backward()):
+ *     g_wih[dir] [4H, c0 + c2] += dA_dir^T [x0 | x2]      g_whh[dir] [4H, H] += dA_dir^T h_prev_dir
+ *     g_bih[dir], g_bhh[dir] [4H] += sum_r dA_dir[r]
+ * Every operand is a row-major [rows = nseq * nsteps, C] matrix (the layer's natural layout: sequence-major, then
+ * step), addressed in place:
+ *   da   [rows, ndir * 4H] (row stride lda)  gate pre-activation gradients left by fnssl_lstm_backward
+ *   x0   [rows, c0] (ldx0), x2 [rows, c2] (ldx2)  the layer's input segments (either may be absent: c = 0)
+ *   h    [rows, ndir * H] (ldh)  the layer's OUTPUT; h_prev is taken from it with a one-step shift inside each
+ *        sequence (zero at the sequence start / end), never materialised
+ * One split-K fp32-MFMA product per layer (csrc/wgrad.hip), partial tiles reduced in a fixed order (deterministic).
+ * c0, c2, H multiples of 4; 4H a multiple of 256; strides multiples of 4 floats; pointers 16-byte aligned.
+ */
+typedef struct {
+  const float* da;
+  long long lda;
+  const float* x0;
+  long long ldx0;
+  int c0;
+  const float* x2;
+  long long ldx2;
+  int c2;
+  const float* h;
+  long long ldh;
+  long long nseq;
+  int nsteps, hidden, ndir;
+  float* g_wih[2];
+  float* g_whh[2];
+  float* g_bih[2];
+  float* g_bhh[2];
+  void* workspace;
+  size_t workspace_bytes;
+} fnssl_wgrad_desc;
+
+size_t fnssl_lstm_weight_grads_workspace_bytes(long long rows, int hidden, int ndir, int c0, int c2);
+int fnssl_lstm_weight_grads(const fnssl_wgrad_desc* d, void* stream);
 
 /* A logical [nb, nt, nf, C] activation in any memory layout: element (b, t, f, c) at p[b*sb + t*st + f*sf + c]. */
 typedef struct {

@@ -351,3 +351,50 @@ def test_config4_real_shard_chunked_whole_deterministic_and_sampled_utterance_vs
     assert abs(loss_u - want_loss) <= 2e-5 * abs(want_loss), (loss_u, want_loss)
     for k in grads:
         rel_close(got[k], grads[k], 1e-3, "grad " + k + " (utterance 17 of the config-4 shard)")
+
+
+@pytest.mark.parametrize("H,ndir,c0,c2,nseq,nsteps", [(128, 2, 4, 0, 7, 9), (128, 2, 256, 0, 40, 33), (256, 1, 256, 4, 24, 50),
+                                                      (256, 1, 256, 0, 3, 300), (128, 2, 132, 8, 1, 17)])
+def test_weight_grads_kernel_vs_fp64_products(dev, H, ndir, c0, c2, nseq, nsteps):
+    """fnssl_lstm_weight_grads (csrc/wgrad.hip: split-K fp32-MFMA product, h_prev by index shift, both directions, bias
+    sums, deterministic reduction) against the float64 products it stands for: dW_ih = dA^T [x0 | x2],
+    dW_hh = dA^T h_prev (one-step shift inside each sequence, zero at the boundary), db = sum dA; accumulation (+=);
+    row counts that are not multiples of the 16-row stage; strided operands; run-to-run bit-stability."""
+    from fnssl import ops
+    rows = nseq * nsteps
+    rng = np.random.RandomState(H + c0 + nseq)
+    da = rng.standard_normal((rows, ndir * 4 * H + 8)).astype(np.float32)[:, :ndir * 4 * H]      # row stride > width
+    x0 = rng.standard_normal((rows, c0)).astype(np.float32)
+    x2 = rng.standard_normal((rows, c2)).astype(np.float32) if c2 else None
+    h = rng.standard_normal((rows, ndir * H)).astype(np.float32)
+    dad = to_dev(np.ascontiguousarray(rng.standard_normal((rows, ndir * 4 * H + 8)).astype(np.float32)), dev)[:, :ndir * 4 * H]
+    dad.copy_(to_dev(da, dev))
+    assert dad.stride(0) == ndir * 4 * H + 8
+    x0d, hd = to_dev(x0, dev), to_dev(h, dev)
+    x2d = to_dev(x2, dev) if c2 else None
+    init = 0.5
+
+    def run():
+        g = {k: [torch.full(s, init, device=dev) for _ in range(ndir)] for k, s in
+             (("wih", (4 * H, c0 + c2)), ("whh", (4 * H, H)), ("bih", (4 * H,)), ("bhh", (4 * H,)))}
+        ops.lstm_weight_grads(dad, x0d, x2d, hd, H, ndir, nsteps, g["wih"], g["whh"], g["bih"], g["bhh"])
+        return g
+
+    g1, g2 = run(), run()
+    x = np.concatenate([x0] + ([x2] if c2 else []), axis=1).astype(np.float64)
+    h3 = h.reshape(nseq, nsteps, ndir * H).astype(np.float64)
+    for d in range(ndir):
+        a = da[:, d * 4 * H:(d + 1) * 4 * H].astype(np.float64)
+        hp = np.zeros((nseq, nsteps, H))
+        if d == 0:
+            hp[:, 1:] = h3[:, :-1, :H]
+        else:
+            hp[:, :-1] = h3[:, 1:, H:]
+        want = {"wih": a.T @ x, "whh": a.T @ hp.reshape(rows, H), "bih": a.sum(0), "bhh": a.sum(0)}
+        for k, w in want.items():
+            got = g1[k][d].cpu().numpy().astype(np.float64) - init
+            scale = np.abs(w).max() + 1e-30
+            assert np.abs(got - w).max() <= 2e-5 * scale + 1e-5, (k, d, np.abs(got - w).max(), scale)
+            assert torch.equal(g1[k][d], g2[k][d]), "weight-gradient kernel is not deterministic"
+    with pytest.raises(RuntimeError):
+        ops.lstm_weight_grads(dad, x0d, x2d, hd[:, :-4], H, ndir, nsteps, g1["wih"], g1["whh"], g1["bih"], g1["bhh"])

@@ -293,10 +293,13 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   }
 
   // ---- launch planner ---------------------------------------------------------------
-  // Every wave does the same work, so a launch runs at the pace of its fullest CU.  Split the
-  // per-CU wave count W = ceil(total groups / CUs) into the fewest rounds of <= wmax waves and
-  // make the rounds as even as possible (config 2, full-band: 7200 groups -> 29 waves per CU ->
-  // rounds of 15 + 14 instead of 16 + 16).  Supported wave counts: the ring variants below.
+  // Every wave does the same work, so a round (one launch, one workgroup per CU) runs at the pace of its fullest SIMD:
+  // measured single rounds of the H = 128 layers (profiles/r02/n_h128_single_round_timings.txt) cost 36.8 ms at 12
+  // waves per CU (3 per SIMD) but 46.6 / 46.7 / 47.5 / 48.9 ms at 13 / 14 / 15 / 16 (4 on the fullest SIMD).  The
+  // per-CU wave count W = ceil(total groups / CUs) is therefore split into the CHEAPEST sequence of rounds by that
+  // cost table (units: one wave-time per SIMD + a small per-wave term): config 2's full-band layers, 7200 groups ->
+  // W = 29 -> 15 + 14 (no SIMD-balanced split covers 29); 191 of its 192 pairs, 7164 groups -> W = 28 -> 16 + 12, one
+  // wave-time per SIMD less (Model.FN_SSL peels the last pair onto a second stream for exactly this reason).
   struct Sup {
     int nw, variant;
   };
@@ -304,23 +307,39 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   static const Sup sup256[] = {{4, 2}, {8, 3}, {12, 4}};
   const Sup* sup = H == 128 ? sup128 : sup256;
   const int nsup = H == 128 ? 7 : 3;
-  const int wmax = sup[nsup - 1].nw;
-  auto pick = [&](int want) {   // smallest supported wave count >= want
-    for (int i = 0; i < nsup; ++i)
-      if (sup[i].nw >= want) return sup[i];
-    return sup[nsup - 1];
-  };
   const long long total = (long long)tasks * d->ndir;
   const int W = (int)((total + ncu - 1) / ncu);            // waves per CU if spread evenly
-  const int rounds = (W + wmax - 1) / wmax;
+  // + a fixed cost per round (a launch of 256-300 dependent steps) and a slightly convex per-wave term (ties go to
+  // the evenest split: 15 + 14 measured 94.2 ms against 95.5 for 16 + 13)
+  auto cost = [](int nw) { return 2.0 + 12.0 * ((nw + 3) / 4) + 0.06 * nw + 0.002 * nw * nw; };
+  // best[w] = cheapest cost to cover w waves per CU; first[w] = the round to run first (largest first)
+  constexpr int kMaxW = 4096;
+  FNSSL_REQUIRE(W <= kMaxW, "lstm_forward: %d waves per CU is beyond the launch planner", W);
+  std::vector<double> best(W + 1, 0.0);
+  std::vector<int> first(W + 1, 0);
+  for (int w = 1; w <= W; ++w) {
+    best[w] = 1e30;
+    for (int i = 0; i < nsup; ++i) {
+      const int rest = w - sup[i].nw > 0 ? w - sup[i].nw : 0;
+      const double c = cost(sup[i].nw) + best[rest];
+      if (c < best[w] - 1e-9 || (c < best[w] + 1e-9 && sup[i].nw > sup[first[w]].nw)) {
+        best[w] = c;
+        first[w] = i;
+      }
+    }
+  }
+  // run the rounds largest first (the last, possibly partial, round is the smallest)
+  std::vector<int> seq;
+  for (int w = W; w > 0;) {
+    seq.push_back(first[w]);
+    w -= sup[first[w]].nw;
+  }
+  std::sort(seq.begin(), seq.end(), [&](int a, int b) { return sup[a].nw > sup[b].nw; });
   const int wgs_per_dir_round = ncu / d->ndir > 0 ? ncu / d->ndir : 1;
   int t0 = 0;
-  for (int r = 0; r < rounds && t0 < tasks; ++r) {
-    const int left_rounds = rounds - r;
-    const long long left_total = (long long)(tasks - t0) * d->ndir;
-    const int want = (int)(((left_total + ncu - 1) / ncu + left_rounds - 1) / left_rounds);
-    const Sup s = pick(want);
-    int t1 = r + 1 == rounds ? tasks : t0 + wgs_per_dir_round * s.nw;
+  for (size_t r = 0; r < seq.size() && t0 < tasks; ++r) {
+    const Sup s = sup[seq[r]];
+    int t1 = r + 1 == seq.size() ? tasks : t0 + wgs_per_dir_round * s.nw;
     if (t1 > tasks) t1 = tasks;
     const int rc = launch_range(s.variant, t0, t1);
     if (rc != FNSSL_OK) return rc;

@@ -692,22 +692,67 @@ class DeviceNet:
         t = a.detach() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a, dtype=np.float32))
         return t.to(self.device, torch.float32).contiguous()
 
+    def _run(self, x0, out, chunk_pairs):
+        nb, nt, nf, _ = x0.shape
+        lib = _lib.load()
+        ws = _workspace(lib.fnssl_forward_workspace_bytes(nb, nf, nt, int(self.is_online), chunk_pairs), x0.device, "forward")
+        check(lib.fnssl_forward(C.byref(self.net), _ptr(x0), nb, nf, nt, _ptr(out), _ptr(ws), ws.numel(),
+                                chunk_pairs, _stream()), "forward")
+
     @on_device
     def forward(self, x0: torch.Tensor, chunk_pairs: int = 0) -> torch.Tensor:
-        """x0 [nb', nt, nf, input_size] -> [nb', nt//12, 2*nf] (or [.., 180] with the DOA layer)."""
+        """x0 [nb', nt, nf, input_size] -> [nb', nt//12, 2*nf] (or [.., 180] with the DOA layer).
+
+        EXPERIMENT, off by default (FNSSL_TAIL_PAIRS=n / FNSSL_TAIL_AUTO=1): pairs are independent and a launch runs at
+        the pace of its fullest SIMD, so when the batch overflows a whole number of wave-times per SIMD in the
+        full-band layers by a few pairs (BASELINE config 2: 7200 wave tasks on 1024 SIMDs = 7.03) those pairs can be
+        peeled off onto a second stream — the main part then fits SIMD-balanced rounds (16 + 12 waves per CU instead
+        of 15 + 14, launch planner in csrc/lstm.hip).  Measured on MI355X (profiles/r03/e_*): the main part does get
+        faster, but the peeled pair's own six dependent launches find no free SIMD slots beside the persistent main
+        kernels (3 x 146 registers of the narrow-band rounds, 4 waves per SIMD of the 16-wave rounds) and finish after
+        them: 604.6 ms against 560.4 ms per step.  Results are identical either way (every launch path is bit-identical)."""
         _need_dev(x0)
         x0 = x0.contiguous()
         nb, nt, nf, cin = x0.shape
         if cin != self.input_size:
             raise RuntimeError("fnssl.forward: expected %d input channels, got %d" % (self.input_size, cin))
-        lib = _lib.load()
-        wsb = lib.fnssl_forward_workspace_bytes(nb, nf, nt, int(self.is_online), chunk_pairs)
-        ws = _workspace(wsb, x0.device, "forward")
         last = 180 if self.is_doa else 2 * nf
         out = torch.empty((nb, nt // SEG_FRAMES, last), dtype=torch.float32, device=x0.device)
-        check(lib.fnssl_forward(C.byref(self.net), _ptr(x0), nb, nf, nt, _ptr(out), _ptr(ws), ws.numel(),
-                                chunk_pairs, _stream()), "forward")
+        tail = 0 if chunk_pairs else tail_pairs(nb, nt, torch.cuda.get_device_properties(x0.device).multi_processor_count)
+        if not tail:
+            self._run(x0, out, chunk_pairs)
+            return out
+        cur = torch.cuda.current_stream(x0.device)
+        side = getattr(self, "_side", None)
+        if side is None or side.device != x0.device:
+            side = self._side = torch.cuda.Stream(device=x0.device, priority=-1)
+        side.wait_stream(cur)                       # inputs and packed weights are ready on the caller's stream
+        with torch.cuda.stream(side):
+            self._run(x0[nb - tail:], out[nb - tail:], 0)
+        self._run(x0[:nb - tail], out[:nb - tail], 0)
+        cur.wait_stream(side)
         return out
+
+
+def tail_pairs(nb: int, nt: int, ncu: int) -> int:
+    """How many trailing pairs ``DeviceNet.forward`` runs on its second stream: the fewest that bring the full-band
+    layers' wave tasks (2 directions x ceil(pairs * frames / 16)) down to a whole number of wave-times per SIMD
+    (4 waves per SIMD, 4 SIMDs per CU) — if that is a small fraction of a large batch, else 0."""
+    import os
+    forced = os.environ.get("FNSSL_TAIL_PAIRS")
+    if forced:
+        return max(0, min(int(forced), nb - 1))
+    if not os.environ.get("FNSSL_TAIL_AUTO") or nb < 2 or ncu <= 0:      # measured slower (see DeviceNet.forward): opt-in
+        return 0
+    units = lambda n: -(-(2 * -(-(n * nt) // 16)) // (4 * ncu))   # noqa: E731  ceil(tasks / SIMDs)
+    u = units(nb)
+    if u < 3:
+        return 0
+    n = nb
+    while n > 0 and units(n) >= u:
+        n -= 1
+    tail = nb - n
+    return tail if n > 0 and tail <= max(1, nb // 32) else 0
 
 
 # --------------------------------------------------------------------------- #

@@ -448,14 +448,24 @@ class Ipdnet2Forward:
             return None
         on_bf16 = not self.fp32 and (dom in ("sn_encoder", "sn_mamba_in", "sn_mamba_xproj", "sn_mamba_out") or
                                      dom.startswith("sn_fconv"))
+        if dom == "sn_mamba_scan":
+            # The selective scan has NO matrix product: its roof is VALU issue.  Per (sequence, channel, step): 16 decays
+            # exp2(dt*A_n) + softplus + SiLU = 22 quarter-rate transcendentals (16 issue cycles each per wave) + ~60 packed /
+            # scalar fp32 instructions (4 cycles each) ~ 592 issue cycles per wave-step; a launch of S sequences x T steps
+            # has S*192/64 waves on 1024 SIMDs.  achieved / peak are reported in wave-steps per second (the unit says so).
+            k = kern[dom]
+            nb = self.nb
+            wave_steps = 2 * (nb * 16 * 192 // 64) * self.nt + 2 * (self.layers - 1) * (nb * 16 * 192 // 64) * (self.nt // 5)
+            clock = 2.4e9
+            peak = 1024 * clock / 592.0                                    # wave-steps per second, all SIMDs issuing
+            ach = wave_steps * (k["count"] / (2.0 * self.layers)) / (k["ms"] * 1e-3) if k["ms"] > 0 else 0.0
+            return {"name": dom, "bound": "valu", "kernel": "sn_mamba_scan (selective scan: no matrix product; roof = VALU / "
+                    "transcendental issue, 592 issue cycles per wave-step, DESIGN section 10)", "achieved": round(ach / 1e9, 3),
+                    "peak": round(peak / 1e9, 3), "unit": "G wave-steps/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "traffic_source": None, "launches": k["count"], "avg_ms": round(k["ms"] / max(1, k["count"]), 4)}
         r = kernel_roof(kern, dom, "%s (dominant kernel of the step%s)" % (dom, ", bf16 MFMA operands" if on_bf16 else
                                                                            ", fp32 arithmetic"),
                         PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS)
-        if r is not None and dom == "sn_mamba_scan":
-            r["note"] = ("the selective scan has no matrix product: per (sequence, channel, step) 16 decays exp2(dt*A_n) + softplus + "
-                         "SiLU = 22 quarter-rate transcendentals (352 issue cycles per wave) next to ~60 packed / scalar fp32 "
-                         "instructions (~250 cycles); its ceiling is VALU issue, ~0.25 of the fp32 roof quoted here, and the "
-                         "3 072 waves of a launch (1 024 sequences x 192 channels) are 3 per SIMD (DESIGN section 10)")
         return r
 
     def cpu_baseline(self):

@@ -11,6 +11,7 @@
 //   * pack_kernel: gathers the two mics of a pair, divides by (mu + eps), drops
 //     the DC bin and writes float4 = [Re i, Re j, Im i, Im j] per (pair, t, f).
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -341,6 +342,235 @@ pack_array_planes_kernel(const float2* __restrict__ spec, const float* __restric
   }
 }
 
+// ---- frame-row kernels (round 3) ------------------------------------------------------------------------------
+// One workgroup per (utterance, frame), its four waves take the channels in turn.
+//   * The frame's 512 samples of ALL channels are fetched once, cooperatively and coalesced for either waveform layout
+//     ([nb, ns, nch]: one contiguous 512 x nch piece; [nb, nch, ns]: nch contiguous 2-KB pieces), into an LDS image
+//     [channel][513] (the odd stride keeps the interleaved-layout writes conflict-free); the centred framing of
+//     torch.stft (reflection at both ends) is an index fold in that fetch.  stft_kernel read them straight from memory,
+//     per wave, at a 4 * nch-byte stride.
+//   * The 256-point complex FFT of the packed real frame runs as FOUR radix-4 stages in the wave's LDS buffer (one
+//     butterfly per lane and stage, digit-reversed input) instead of eight radix-2 stages: half the LDS round trips.
+//   * MODE 1 (magnitudes) writes only sum_k |X[k]| per (utterance, channel, frame); MODE 2 (features) runs the transform
+//     AGAIN, divides by (mu + eps) and stores the frame's feature row [256 bins][Re ch 0.. | Im ch 0..] as ONE contiguous
+//     piece.  The array front end (IPDnet, IPDnet2) is MODE 1 -> recursive mean -> MODE 2: the 2 x 257 x 8 B per channel-
+//     frame spectrum is never written or re-read (1.1 GB of traffic instead of 1.8 GB at BASELINE config 5); MODE 0 is
+//     the pair path's spectrum + magnitude-sum pass.
+constexpr int kXsStride = kWin + 1;
+
+__device__ __forceinline__ unsigned digitrev4_8(unsigned m) {      // reverse the four base-4 digits of an 8-bit index
+  return ((m & 3u) << 6) | ((m & 12u) << 2) | ((m & 48u) >> 2) | ((m & 192u) >> 6);
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+
+// 256-point complex FFT in place in z[256] (digit-reversed on entry, natural order on exit); tw[k] = exp(-2 pi i k / 512)
+__device__ __forceinline__ void fft256_radix4(float2* z, const float2* tw, int lane) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int L = 1 << (2 * s);
+    const int j = lane & (L - 1);
+    const int base = ((lane >> (2 * s)) << (2 * s + 2)) + j;
+    const int step = j * (128 >> (2 * s));                    // W_{4L}^j = tw[j * 512 / (4 L)]
+    const float2 a0 = z[base];
+    float2 a1 = z[base + L], a2 = z[base + 2 * L], a3 = z[base + 3 * L];
+    if (s > 0) {
+      a1 = cmul(a1, tw[step]);
+      a2 = cmul(a2, tw[2 * step]);
+      a3 = cmul(a3, tw[3 * step]);
+    }
+    const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y), t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+    const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y);
+    const float2 t3 = make_float2(a1.y - a3.y, a3.x - a1.x);  // -i (a1 - a3)
+    z[base] = make_float2(t0.x + t2.x, t0.y + t2.y);
+    z[base + L] = make_float2(t1.x + t3.x, t1.y + t3.y);
+    z[base + 2 * L] = make_float2(t0.x - t2.x, t0.y - t2.y);
+    z[base + 3 * L] = make_float2(t1.x - t3.x, t1.y - t3.y);   // a butterfly is in place: only the NEXT stage reads across lanes
+    wave_lds_sync();
+  }
+}
+
+struct RowParams {
+  const float* sig;
+  int nb, nch, nt, ns, hop, center;
+  long long sb, sn, sc;
+  float2* spec;          // MODE 0: [nb, nch, nt, 257]
+  float* magsum;         // MODE 0 / 1: [nb, nch, nt]
+  const float* mu;       // MODE 2: [nb, nt]
+  float eps;
+  float* x;              // MODE 2: [nb, nt, 256, 2 nch]
+};
+
+// NW waves per workgroup: as many as there are channels (rounded up to 4, 8 or 16), so that a frame's channels are
+// transformed side by side.  Measured (profiles/r03/g_*, BASELINE config 5: 240 k channel-frames): 0.41 ms per pass
+// against 0.55 ms for stft_kernel; what bounds it is the transform itself — ~530 vector instructions and ~70 LDS
+// operations (several with 4- to 8-way bank conflicts: the digit-reversed store, the stride-4 / stride-16 stages) per
+// channel-frame, ≈ 0.2 ms of pure VALU issue per pass — not the memory traffic, so the spectrum-free two-pass front
+// end (fnssl_array_frontend: two transform passes) is SLOWER than writing the spectrum once (0.92 vs 0.74 ms).
+template <int MODE, int NW>
+__global__ void __launch_bounds__(NW * 64) stft_rows_kernel(const RowParams p) {
+  constexpr int kRowWaves = NW;
+  extern __shared__ __attribute__((aligned(16))) float smem_rows[];
+  float2* tw = reinterpret_cast<float2*>(smem_rows);                    // [384]
+  float* hann = smem_rows + 768;                                          // [512]
+  float2* zbuf = reinterpret_cast<float2*>(smem_rows + 768 + 512);        // [4][256]
+  float* xs = smem_rows + 768 + 512 + kRowWaves * 512;                    // [nch][513]
+  float* row = xs + p.nch * kXsStride;                                    // MODE 2: [256][2 nch]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < 384; k += kRowWaves * 64) {
+    float sn_, cs_;
+    sincospif(-(float)k / 256.0f, &sn_, &cs_);
+    tw[k] = make_float2(cs_, sn_);
+  }
+  for (int n = tid; n < kWin; n += kRowWaves * 64) hann[n] = 0.5f - 0.5f * cospif((float)n / 256.0f);
+  // Persistent workgroup: it walks frames blockIdx.x, + gridDim.x, ...; the NEXT frame's samples are requested into
+  // registers before the current frame is transformed (a workgroup per frame left the ~2 us of HBM latency of its own
+  // fetch exposed: one workgroup fits a CU) and are written to the LDS image after it.
+  const long long nframes = (long long)p.nb * p.nt;
+  const int total = p.nch * kWin;
+  constexpr int PF = 8;                             // samples per thread: nch * 512 <= NW * 64 * 8 by the choice of NW
+  float pre[PF];
+  const float inv = 1.0f / (float)p.nch;
+  auto fetch = [&](long long fr) {
+    const int t = (int)(fr % p.nt);
+    const long long b = fr / p.nt;
+    const int n0 = t * p.hop - (p.center ? kWin / 2 : 0);
+    const float* ub = p.sig + b * p.sb;
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int i = tid + q * kRowWaves * 64;
+      int n, c;
+      if (p.sn == 1) {             // [nb, nch, ns]: channel-major, 2-KB runs
+        c = i >> 9;
+        n = i & (kWin - 1);
+      } else {                     // [nb, ns, nch] (sc == 1: one contiguous piece) or any other strides
+        n = (int)(((float)i + 0.5f) * inv);          // i / nch without the integer division (exact: i < 2^16)
+        c = i - n * p.nch;
+        if (c < 0) { c += p.nch; --n; }
+        if (c >= p.nch) { c -= p.nch; ++n; }
+      }
+      int src = n0 + n;
+      if (p.center) {              // torch.stft(center=True): reflection at both ends as an index fold
+        src = src < 0 ? -src : src;
+        src = src >= p.ns ? 2 * (p.ns - 1) - src : src;
+      }
+      pre[q] = i < total ? ub[(long long)src * p.sn + (long long)c * p.sc] : 0.f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int i = tid + q * kRowWaves * 64;
+      if (i < total) {
+        int n, c;
+        if (p.sn == 1) {
+          c = i >> 9;
+          n = i & (kWin - 1);
+        } else {
+          n = (int)(((float)i + 0.5f) * inv);
+          c = i - n * p.nch;
+          if (c < 0) { c += p.nch; --n; }
+          if (c >= p.nch) { c -= p.nch; ++n; }
+        }
+        xs[c * kXsStride + n] = pre[q];
+      }
+    }
+  };
+  long long fr = blockIdx.x;
+  if (fr < nframes) fetch(fr);
+  float2* z = zbuf + wave * 256;
+  for (; fr < nframes; fr += gridDim.x) {
+    __syncthreads();               // the previous frame's transforms (and row store) are done with xs / row; tables ready
+    commit();
+    __syncthreads();
+    if (fr + gridDim.x < nframes) fetch(fr + gridDim.x);
+    const int t = (int)(fr % p.nt);
+    const long long b = fr / p.nt;
+    float den = 1.f;
+    if (MODE == 2) den = __fadd_rn(p.mu[b * p.nt + t], p.eps);
+    for (int c = wave; c < p.nch; c += kRowWaves) {
+      const float* xc = xs + c * kXsStride;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = lane + 64 * r;
+        z[digitrev4_8(m)] = make_float2(hann[2 * m] * xc[2 * m], hann[2 * m + 1] * xc[2 * m + 1]);
+      }
+      wave_lds_sync();
+      fft256_radix4(z, tw, lane);
+      // split: X[k] = E[k] + W512^k O[k],  E = (Z[k] + conj Z[N-k])/2,  O = (Z[k] - conj Z[N-k])/(2i)
+      const long long cf = (b * p.nch + c) * p.nt + t;
+      float msum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int k = lane + 64 * r;
+        if (k <= 256) {
+          const float2 zk = z[k & 255];
+          const float2 zn = z[(256 - k) & 255];
+          const float er = 0.5f * (zk.x + zn.x), ei = 0.5f * (zk.y - zn.y);
+          const float dr = 0.5f * (zk.x - zn.x), di = 0.5f * (zk.y + zn.y);
+          const float orr = di, oi = -dr;
+          const float2 w = k < 256 ? tw[k] : make_float2(-1.f, 0.f);
+          const float xr = er + (orr * w.x - oi * w.y);
+          const float xi = ei + (orr * w.y + oi * w.x);
+          if (MODE == 0) p.spec[cf * kBins + k] = make_float2(xr, xi);
+          if (MODE != 2) msum += sqrtf(xr * xr + xi * xi);
+          if (MODE == 2 && k >= 1) {
+            row[(k - 1) * 2 * p.nch + c] = __fdiv_rn(xr, den);
+            row[(k - 1) * 2 * p.nch + p.nch + c] = __fdiv_rn(xi, den);
+          }
+        }
+      }
+      if (MODE != 2) {
+        msum = wave_sum(msum);
+        if (lane == 0) p.magsum[cf] = msum;
+      }
+      wave_lds_sync();                                         // z is reused by this wave's next channel
+    }
+    if (MODE == 2) {
+      __syncthreads();
+      float* o = p.x + (b * p.nt + t) * (long long)(kNF * 2 * p.nch);
+      const int n = kNF * 2 * p.nch;                           // multiple of 4; the row starts on a 16-byte boundary
+      for (int i = 4 * tid; i < n; i += 4 * kRowWaves * 64)
+        *reinterpret_cast<float4*>(o + i) = *reinterpret_cast<const float4*>(row + i);
+    }
+  }
+}
+
+int rows_waves(int nch) { return nch <= 4 ? 4 : (nch <= 8 ? 8 : 16); }
+
+size_t rows_lds_bytes(int nch, int mode) {
+  return (size_t)(768 + 512 + rows_waves(nch) * 512 + nch * kXsStride + (mode == 2 ? kNF * 2 * nch : 0)) * sizeof(float);
+}
+
+template <int MODE, int NW>
+int launch_rows_nw(const RowParams& p, const char* name, hipStream_t st) {
+  const size_t lds = rows_lds_bytes(p.nch, MODE);
+  const long long nframes = (long long)p.nb * p.nt;
+  // persistent: as many workgroups as fit the chip at once (LDS- and wave-limited), each walking its share of frames
+  const int per_cu_lds = (int)((160 * 1024) / lds), per_cu_waves = 32 / NW;
+  const int per_cu = per_cu_lds < per_cu_waves ? (per_cu_lds > 0 ? per_cu_lds : 1) : per_cu_waves;
+  long long nblk = (long long)fnssl::device_cus() * per_cu;
+  if (nblk > nframes) nblk = nframes;
+  if (lds > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_rows_kernel<MODE, NW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fnssl::TimedLaunch tl(name, st);
+  hipLaunchKernelGGL((stft_rows_kernel<MODE, NW>), dim3((unsigned)nblk), dim3(NW * 64), lds, st, p);
+  FNSSL_CHECK_LAUNCH("stft_rows_kernel");
+  return FNSSL_OK;
+}
+
+template <int MODE>
+int launch_rows(const RowParams& p, const char* name, hipStream_t st) {
+  FNSSL_REQUIRE(rows_lds_bytes(p.nch, MODE) <= 160 * 1024, "front end: %d channels do not fit the frame image in LDS", p.nch);
+  FNSSL_REQUIRE((long long)p.nb * p.nt < (1ll << 31), "front end: too many frames");
+  switch (rows_waves(p.nch)) {
+    case 4: return launch_rows_nw<MODE, 4>(p, name, st);
+    case 8: return launch_rows_nw<MODE, 8>(p, name, st);
+    default: return launch_rows_nw<MODE, 16>(p, name, st);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -386,6 +616,15 @@ int fnssl_stft_ex(const float* sig, int nb, int ns, int nch, long long sb, long 
                                : "stft: signal of %d samples is shorter than one %d-sample window",
                 ns, center ? kWin / 2 : kWin);
   FNSSL_REQUIRE(sig && spec, "stft: null pointer");
+  RowParams p{};
+  p.sig = sig;
+  p.nb = nb; p.nch = nch; p.nt = nt; p.ns = ns; p.hop = hop; p.center = center ? 1 : 0;
+  p.sb = sb; p.sn = sn; p.sc = sc;
+  p.spec = reinterpret_cast<float2*>(spec);
+  p.magsum = magsum;
+  if (magsum && rows_lds_bytes(nch, 0) <= 160 * 1024 && !getenv("FNSSL_STFT_PER_FRAME"))
+    return launch_rows<0>(p, "stft", fnssl::as_stream(stream));
+  // fallback (no magnitude sums wanted, or more channels than the frame image holds): one wave per (b, c, t)
   const long long nframes = (long long)nb * nch * nt;
   const long long nblk = (nframes + kFramesPerBlock - 1) / kFramesPerBlock;
   FNSSL_REQUIRE(nblk < (1ll << 31), "stft: too many frames");
@@ -470,6 +709,37 @@ int fnssl_array_features(const float* spec, const float* magsum, const float* co
     FNSSL_CHECK_LAUNCH("pack_array_kernel");
   }
   return FNSSL_OK;
+}
+
+int fnssl_array_frontend(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc, int hop,
+                         int center, const float* coef_a, const float* coef_b, float eps, float* magsum, float* mu, float* x,
+                         void* stream) {
+  FNSSL_REQUIRE(nb > 0 && nch > 0, "array_frontend: empty batch (nb %d, nch %d)", nb, nch);
+  FNSSL_REQUIRE(hop > 0 && hop <= kWin, "array_frontend: hop %d outside 1..%d", hop, kWin);
+  const int nt = fnssl_num_frames_ex(ns, hop, center);
+  FNSSL_REQUIRE(nt > 0, "array_frontend: signal of %d samples is too short", ns);
+  FNSSL_REQUIRE(sig && coef_a && coef_b && magsum && mu && x, "array_frontend: null pointer");
+  FNSSL_REQUIRE(rows_lds_bytes(nch, 2) <= 160 * 1024, "array_frontend: %d channels do not fit the frame image in LDS", nch);
+  hipStream_t st = fnssl::as_stream(stream);
+  RowParams p{};
+  p.sig = sig;
+  p.nb = nb; p.nch = nch; p.nt = nt; p.ns = ns; p.hop = hop; p.center = center ? 1 : 0;
+  p.sb = sb; p.sn = sn; p.sc = sc;
+  p.magsum = magsum;
+  p.mu = mu;
+  p.eps = eps;
+  p.x = x;
+  {
+    const int rc = launch_rows<1>(p, "stft", st);
+    if (rc != FNSSL_OK) return rc;
+  }
+  {
+    fnssl::TimedLaunch tl("ema", st);
+    hipLaunchKernelGGL(ema_array_kernel, dim3((nb + kEmaWaves - 1) / kEmaWaves), dim3(kEmaWaves * 64), 0, st, magsum,
+                       coef_a, coef_b, nb, nch, nt, mu);
+    FNSSL_CHECK_LAUNCH("ema_array_kernel");
+  }
+  return launch_rows<2>(p, "pack", st);
 }
 
 int fnssl_nchw_to_seq(const float* x, int n, int c, int nf, int nt, float* y, void* stream) {

@@ -19,13 +19,13 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
 SYMBOLS = [
     "fnssl_abi_version", "fnssl_last_error", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
-    "fnssl_num_frames_ex", "fnssl_stft_ex",
+    "fnssl_num_frames_ex", "fnssl_stft_ex", "fnssl_array_frontend",
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
@@ -166,6 +166,7 @@ def load():
     lib.fnssl_stft.argtypes = [vp, i, i, i, ll, ll, ll, vp, vp, vp]
     lib.fnssl_num_frames_ex.argtypes = [i, i, i]
     lib.fnssl_stft_ex.argtypes = [vp, i, i, i, ll, ll, ll, i, i, vp, vp, vp]
+    lib.fnssl_array_frontend.argtypes = [vp, i, i, i, ll, ll, ll, i, i, vp, vp, f, vp, vp, vp, vp]
     lib.fnssl_forgetting_coefs.argtypes = [i, i, vp, vp]
     lib.fnssl_pair_features.argtypes = [vp, vp, vp, vp, i, i, i, i, f, vp, vp, i, vp]
     lib.fnssl_nchw_to_seq.argtypes = [vp, i, i, i, i, vp, vp]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 12
+#define FNSSL_ABI_VERSION 13
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -411,6 +411,21 @@ int fnssl_array_features(const float* spec, const float* magsum,
                          const float* coef_a, const float* coef_b,
                          int nb, int nch, int nt, float eps,
                          float* mu, float* x, int layout, void* stream);
+
+/*
+ * The whole array front end in one call, waveforms -> features, WITHOUT materialising the spectrum (replaces the
+ * same reference lines as fnssl_stft_ex + fnssl_array_features: IPDnet/runIPDnetOn.py:240-254 with hop 256 /
+ * center 0 / sample_length 280, IPDnet2/Module.py:47-64 + run_IPDnet2.py:277-288 with hop 320 / center 1 / 249):
+ * a magnitude pass (sum_k |X| per utterance, channel, frame), the recursive mean, and a second transform pass that
+ * divides by (mu + eps) and writes each frame's feature row as one contiguous piece.
+ *   sig      as fnssl_stft_ex           coef_a/b  DEVICE [nt] from fnssl_forgetting_coefs
+ *   magsum   [nb, nch, nt] (written)    mu        [nb, nt] (written)
+ *   x        [nb, nt, 256, 2*nch]  channels [Re ch 0..nch-1, Im ch 0..nch-1], bins 1..256 (layout 0 of
+ *            fnssl_array_features; the reference's [nb, 2*nch, 256, nt] tensor is its permute(0, 3, 2, 1) view)
+ */
+int fnssl_array_frontend(const float* sig, int nb, int ns, int nch, long long sb, long long sn, long long sc,
+                         int hop, int center, const float* coef_a, const float* coef_b, float eps,
+                         float* magsum, float* mu, float* x, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* IPDnet head (next row 8f-3): causal 3x3 Conv2d + time pooling              */

@@ -418,6 +418,9 @@ def test_ipdnet2_waveform_frontend_vs_reference_golden(dev):
         assert torch.equal(x2, x)
         assert x.is_contiguous()
         assert torch.equal(ops.preprocess_ipdnet2(to_dev(sig, dev), sample_length=sl, frame_major=True), x)
+        # the one-call front end that never writes the spectrum: the same numbers
+        xf = ops.array_frontend(to_dev(sig, dev), sample_length=sl, hop=320, center=True)
+        assert torch.equal(xf.permute(0, 3, 2, 1), x)
         ci += 1
     assert ci == 4
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

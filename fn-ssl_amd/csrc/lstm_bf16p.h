@@ -29,7 +29,7 @@
 namespace fnssl_lstm {
 
 // ABL (make ABLATE=1 builds only): timing ablations, wrong results — 1 cheap gate math (no transcendentals), 4 no MFMAs
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false, bool ROTATE = false>
 __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   constexpr int NT = H / 8, NTW = NT / 2, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr int KP = KT / 2;                              // half a tile
@@ -96,10 +96,18 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   // pull the same piece at once — with one piece in flight the ring alone took 41 k cycles per step.
   const int fpar = w & 1;
   const unsigned src_role = (unsigned)(role * NTW * KT) * 1024u;
+  // Tile rotation (EXPERIMENT, off: FNSSL_BF16P_ROTATE=1): within a step the gate-row tiles only depend on h_{t-1}, so
+  // their ORDER is free; with ROTATE the workgroups of one XCD (blockIdx & 7) start their walk through the role's NTW
+  // tiles at different tiles, so that the CUs of an XCD pull DIFFERENT records from their shared L2 at any moment
+  // instead of the same one.  Measured at config 3 (profiles/r03/h_*): no gain — narrow-band layers 14.92 ms per step
+  // rotated against 14.50 in lock-step (same-line requests are evidently served together; spreading them loses that).
+  // Static tile index I <-> stream tile (I + rot) & (NTW - 1): the cell state of that tile lives in creg[I].
+  static_assert((NTW & (NTW - 1)) == 0, "tile rotation assumes a power-of-two tile count per role");
+  const int rot = ROTATE ? (int)((blockIdx.x >> 3) & (NTW - 1)) : 0;
   auto fetch_piece = [&](int j, int slot) {
     const int qt = j & 3;
     const int start = (qt >> 1) * KP + (qt & 1) * KQ0, size = (qt & 1) ? KQ1 : KQ0;
-    const unsigned sb = src_role + (unsigned)((j >> 2) * KT + start + fpar) * 1024u;
+    const unsigned sb = src_role + (unsigned)((((j >> 2) + rot) & (NTW - 1)) * KT + start + fpar) * 1024u;
     const unsigned lb = lds0 + (unsigned)(slot * SLOTB + (role * KQ0 + fpar) * 1024);
     // records fpar + 2 m: the first KPW - 1 always exist (2 (KPW - 2) + 1 < KQ1), the last one may run past a short
     // piece and then repeats the piece's last record
@@ -202,10 +210,11 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
     const v4bfw hb4 = __builtin_convertvector(hn, v4bfw);
     pend_f = hn;
     pend_b = hb4;
-    pend_off = oo_t + (OUTF ? 32 : 16) * I;
+    const int ta = (I + rot) & (NTW - 1);                 // the stream tile this static index stands for
+    pend_off = oo_t + (OUTF ? 32 : 16) * ta;
     pend_live = true;
-    // global tile G = role * NTW + I -> operand block G / 2, elements 4 (G & 1) .. + 3 (NTW is even or role 0 ...)
-    const int gt = role * NTW + I;
+    // global tile G = role * NTW + ta -> operand block G / 2, elements 4 (G & 1) .. + 3
+    const int gt = role * NTW + ta;
     *reinterpret_cast<v4bfw*>(hbuf + (gt >> 1) * 1024 + 8 * (gt & 1)) = hb4;
   };
   auto reload_h = [&]() {
@@ -316,7 +325,8 @@ int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
   // — bit-stable with one workgroup per CU (same kernel, LDS padded) and with drained barriers; the cause could not
   // be pinned from here, so the shape runs the canonical "vmcnt(0) + barrier" protocol: 3.99 -> 4.37 ms per launch
   // (three resident workgroups hide each other's waits).  The other shapes own their CU (114-158 KB of LDS).
-  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12)>;
+  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), false>;
+  if (getenv("FNSSL_BF16P_ROTATE")) k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), true>;   // A/B
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, st, p);

@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only, by is_online
-TRAFFIC_JSON = os.path.join("profiles", "r01", "hbm_traffic_lstm_h256.json")
+TRAFFIC_JSON = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
 
 
 def log(msg):

@@ -29,13 +29,17 @@
 namespace fnssl_lstm {
 
 // ABL (make ABLATE=1 builds only): timing ablations, wrong results — 1 cheap gate math (no transcendentals), 4 no MFMAs
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false, bool ROTATE = false>
-__global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
+// NG = 32-sequence groups per workgroup (2 roles each: 2 NG waves).  The ring, its barriers and the L2 weight stream
+// are per WORKGROUP and step, so more groups per workgroup amortise them: the 400-column full-band layer of IPDnet has
+// 1200 groups (64 utterances x 300 frames / 32, two directions) = 600 two-group workgroups = 2.34 rounds on 256 CUs run
+// as 3; with NG = 5 it is 240 workgroups = ONE round (and the step's ring traffic serves 160 sequences instead of 64).
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false, bool ROTATE = false, int NG = 2>
+__global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p) {
   constexpr int NT = H / 8, NTW = NT / 2, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr int KP = KT / 2;                              // half a tile
   // ring granule = a QUARTER tile per role ("piece": KQ0, KP - KQ0, KQ0, KP - KQ0 records), one barrier per piece
   constexpr int KQ0 = (KP + 1) / 2, KQ1 = KP - KQ0;
-  constexpr int KPW = (KQ0 + 1) / 2;                      // DMA requests per wave and piece (2 waves per role)
+  constexpr int KPW = (KQ0 + NG - 1) / NG;                // DMA requests per wave and piece (NG waves per role)
   // Ring accounting.  At the barrier that opens interval j every wave has REQUESTED pieces 0 .. j + NSLOT - 2 (the
   // prologue requests NSLOT - 1, one more follows each barrier) and waits until all but its INFL youngest piece
   // requests have landed, i.e. pieces <= j + LAND are complete in LDS for everybody after the barrier; the request
@@ -55,20 +59,20 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   // starts after its mid-tile barrier (the pair's exchange point); otherwise they run at the end of their own step
   constexpr bool LATE = 1 + NKX >= KQ0;
   static_assert(KT % 2 == 0 && NT % 2 == 0, "tiles are fetched in two pieces, shared by two roles");
-  static_assert(RING + 2 * HBUF <= 160 * 1024, "ring + h staging do not fit the LDS");
+  static_assert(RING + NG * HBUF <= 160 * 1024, "ring + h staging do not fit the LDS");
   static_assert(AD >= 1 && AD <= KQ1 && KQ1 <= KQ0 && (NTW * KT) % AD == 0, "A pipeline reaches at most one piece ahead");
   static_assert(INFL >= 1 && NSLOT >= 6, "cbs[] addresses six consecutive slots");
   static_assert(INFL * KPW <= 60, "vmcnt is a 6-bit counter");
-  static_assert(2 * (KPW - 2) + 1 < KQ1 || KPW == 1, "only the last request of a piece may need clamping");
+  static_assert(NG * (KPW - 1) - 1 < KQ1 || KPW == 1, "only the last request of a piece may need clamping");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int n = lane & 31, hb = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int role = w >> 1, grp = w & 1;                   // consumes tiles role * NTW + i of group grp
+  const int role = w / NG, grp = w - role * NG;           // consumes tiles role * NTW + i of group grp
   const int dir = blockIdx.x / p.wgs_per_dir;
   const int wg = blockIdx.x - dir * p.wgs_per_dir;
-  const int task = p.task0 + wg * 2 + grp;                // 32-sequence group
+  const int task = p.task0 + wg * NG + grp;               // 32-sequence group
   int q = task * 32 + n;
   const bool valid = q < p.nseq && task < p.task1;
   if (q >= p.nseq) q = p.nseq - 1;
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   // L2 is the wall here: every CU streams the whole matrix from L2 once per step (1.06 MB x 256 CUs x 300 steps =
   // 84 GB per launch = 2.4 ms at the 34.5 TB/s L2 peak), and a request waits ~1300 cycles when all 32 CUs of an XCD
   // pull the same piece at once — with one piece in flight the ring alone took 41 k cycles per step.
-  const int fpar = w & 1;
+  const int fpar = grp;                                    // my index among the NG waves that fetch for this role
   const unsigned src_role = (unsigned)(role * NTW * KT) * 1024u;
   // Tile rotation (EXPERIMENT, off: FNSSL_BF16P_ROTATE=1): within a step the gate-row tiles only depend on h_{t-1}, so
   // their ORDER is free; with ROTATE the workgroups of one XCD (blockIdx & 7) start their walk through the role's NTW
@@ -111,8 +115,8 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
     const unsigned lb = lds0 + (unsigned)(slot * SLOTB + (role * KQ0 + fpar) * 1024);
     // records fpar + 2 m: the first KPW - 1 always exist (2 (KPW - 2) + 1 < KQ1), the last one may run past a short
     // piece and then repeats the piece's last record
-    static_for<KPW - 1>([&](auto mc) { dma16_imm<decltype(mc)::value * 2 * 1024>(rw, vlane, sb, lb); });
-    const int rl = fpar + 2 * (KPW - 1) < size ? 2 * (KPW - 1) : size - 1 - fpar;
+    static_for<KPW - 1>([&](auto mc) { dma16_imm<decltype(mc)::value * NG * 1024>(rw, vlane, sb, lb); });
+    const int rl = fpar + NG * (KPW - 1) < size ? NG * (KPW - 1) : size - 1 - fpar;
     dma16_imm<0>(rw, vlane, sb + (unsigned)rl * 1024u, lb + (unsigned)rl * 1024u);
   };
   int fj = 0, fslot = 0;
@@ -311,25 +315,27 @@ __global__ void __launch_bounds__(256) lstm_bf16p_kernel(const LstmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NG = 2>
 int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
-  // 7 slots where a workgroup owns its CU anyway; the 144-column full-band layer (6 KB slots) keeps 6 so that three
-  // workgroups stay resident per CU (its 600 workgroups are 2.3 per CU)
+  // 7 slots where a workgroup owns its CU anyway; the 144-column full-band layer (6 KB slots) keeps 6 so that several
+  // workgroups stay resident per CU
   constexpr int NSLOT = KT <= 12 ? 6 : 7;
-  const size_t lds = (size_t)NSLOT * 2 * ((KT / 2 + 1) / 2) * 1024 + (size_t)2 * (H / 16) * 1024;
-  // DRAIN (the 144-column layer only, the one shape whose 52 KB workgroups share a CU three at a time): every barrier
+  const size_t lds = (size_t)NSLOT * 2 * ((KT / 2 + 1) / 2) * 1024 + (size_t)NG * (H / 16) * 1024;
+  // DRAIN (the 144-column layer only, the one shape whose workgroups share a CU): every barrier
   // waits for ALL of the wave's requests (vmcnt(0)) instead of leaving INFL pieces in flight.  Measured on MI355X
   // (profiles/r03/c_*): with counted waits this shape alone gave run-to-run differences at config 3's batch (a 32-sequence
   // group reading one stale weight record, a few times per launch) whenever several workgroups were resident per CU
   // — bit-stable with one workgroup per CU (same kernel, LDS padded) and with drained barriers; the cause could not
   // be pinned from here, so the shape runs the canonical "vmcnt(0) + barrier" protocol: 3.99 -> 4.37 ms per launch
   // (three resident workgroups hide each other's waits).  The other shapes own their CU (114-158 KB of LDS).
-  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), false>;
-  if (getenv("FNSSL_BF16P_ROTATE")) k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), true>;   // A/B
+  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), false, NG>;
+  if constexpr (NG == 2) {
+    if (getenv("FNSSL_BF16P_ROTATE")) k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), true, NG>;   // A/B
+  }
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(nwg), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(NG * 128), lds, st, p);
   FNSSL_CHECK_LAUNCH("lstm_bf16p_kernel");
   return FNSSL_OK;
 }

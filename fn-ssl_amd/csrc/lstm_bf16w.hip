@@ -25,10 +25,12 @@ int launch_bf16w(const LstmParams& p, int H, int NW, int flags, int nwg, hipStre
   return kNoStatic;
 }
 
+// NG_ = the largest groups-per-workgroup instantiation built for the shape (lstm_bf16p_kernel's NG; 2 = the pair of
+// groups every shape runs with — larger workgroups were measured and do not pay, see forward_bf16w)
 #define TRYP(H_, NB0_, NB2_, FL_)                                                    \
   if (H == H_ && p.c0 == 16 * NB0_ && p.c2 == 16 * NB2_ && flags == (FL_)) return launch_bf16p_k<H_, NB0_, NB2_, FL_>(p, nwg, st);
 
-// pair-split kernels (lstm_bf16p.h): workgroup = 2 groups of 32 sequences x 2 roles
+// pair-split kernels (lstm_bf16p.h): workgroup = ng groups of 32 sequences x 2 roles (ng = 2, or 5 for the H = 128 shapes)
 int launch_bf16p(const LstmParams& p, int H, int flags, int nwg, hipStream_t st) {
 #ifdef FNSSL_BUILD_ABLATE   // timing ablations of the config-3 narrow-band kernel (wrong results): make ABLATE=1 only
   if (const char* e = getenv("FNSSL_BF16W_ABL")) {
@@ -58,7 +60,14 @@ int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st) {
   p.task1 = groups;
   int rc;
   if (!getenv("FNSSL_BF16W_SOLO")) {
-    p.wgs_per_dir = (groups + 1) / 2;
+    // Two 32-sequence groups per workgroup.  lstm_bf16p_kernel takes NG groups (template), and 3 / 4 / 5 were built and
+    // measured at config 3 (profiles/r03/h_bf16p_groups_per_workgroup.txt) in the hope of turning the full-band layers'
+    // 600 workgroups (2.34 rounds run as 3) into 400 / 300 / 240: bit-identical, never faster (full-band layers 13.1 ms
+    // per step at 2 groups, 13.0 / 15.2 / 14.0 at 3 / 4 / 5) — a round's time grows with its groups, because every wave
+    // reads each 1-KiB weight record of its role from LDS once per 32-cycle MFMA: four waves already draw the LDS's
+    // 128 B/clk, so the formulation is bound by LDS bandwidth, not by rounds.
+    const int ng = 2;
+    p.wgs_per_dir = (groups + ng - 1) / ng;
     rc = launch_bf16p(p, H, flags, p.wgs_per_dir * p.ndir, st);
   } else {
     const int nw = (total <= 2ll * ncu || H >= 256) ? 2 : 4;

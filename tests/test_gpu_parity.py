@@ -1162,3 +1162,30 @@ def test_timing_select_brackets_one_kernel_name(dev):
     ops.nchw_to_seq(to_dev(rs_randn(5901, (1, 4, 8, 6)), dev))
     ops.timing_enable(False)
     assert set(ops.timing_collect()) == {"avgpool_time", "nchw_to_seq"}
+
+
+def test_tail_pairs_second_stream_is_bit_identical(dev, monkeypatch):
+    """The opt-in experiment of DeviceNet.forward (FNSSL_TAIL_PAIRS=n: the last n pairs through the same network on a
+    second, high-priority stream while the others run on the caller's): same kernels' arithmetic, so the output must be
+    bit-identical to the default single pass; and the heuristic that would choose n (`tail_pairs`, FNSSL_TAIL_AUTO=1)."""
+    import Model
+    from fnssl import ops
+    from fnssl import weights as W
+    sd = W.make_fnssl_state(5100, 4, 256, True)
+    net = Model.FN_SSL(is_online=True)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    net = net.to(dev).eval()
+    x0 = to_dev(rs_randn(5101, (5, 24, 256, 4)), dev)
+    monkeypatch.delenv("FNSSL_TAIL_PAIRS", raising=False)
+    monkeypatch.delenv("FNSSL_TAIL_AUTO", raising=False)
+    want = net.forward_seq(x0)
+    for n in (1, 2):
+        monkeypatch.setenv("FNSSL_TAIL_PAIRS", str(n))
+        got = net.forward_seq(x0)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), "tail of %d pair(s) on the second stream changed the result" % n
+    monkeypatch.delenv("FNSSL_TAIL_PAIRS")
+    assert ops.tail_pairs(192, 300, 256) == 0                       # off by default (measured slower)
+    monkeypatch.setenv("FNSSL_TAIL_AUTO", "1")
+    assert ops.tail_pairs(192, 300, 256) == 1 and ops.tail_pairs(384, 300, 256) == 2    # 7200 -> 7164 tasks on 1024 SIMDs
+    assert ops.tail_pairs(96, 300, 256) == 0 and ops.tail_pairs(6, 300, 256) == 0

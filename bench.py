@@ -170,8 +170,8 @@ class FnsslForward:
             with open(tpath) as f:
                 traffic = json.load(f).get("bytes_per_launch")
             src = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, not this run)"
-        return kernel_roof(kern, "lstm_h256", "lstm_rec_kernel<H=256> (narrow-band LSTM)", PEAK_FP32_MFMA_TFLOPS,
-                           traffic=traffic, traffic_source=src)
+        return kernel_roof(kern, "lstm_h256", "lstm_static2_kernel<H=256> (narrow-band LSTM, two hidden slices per pass)",
+                           PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
 
     def cpu_baseline(self):
         from oracle import torch_ref as R

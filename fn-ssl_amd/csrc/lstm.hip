@@ -97,13 +97,41 @@ int fnssl_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
   return FNSSL_OK;
 }
 
-size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {
-  if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
-  // cell state, one float4 per (lane, slice) per wave; the tail workgroup is
-  // padded to a whole workgroup (<= 16 waves), so every variant fits.
+// bytes of cell-state scratch at the front of the workspace (a multiple of 256)
+static size_t cell_scratch_bytes(int nseq, int hidden, int ndir) {
+  // one float4 per (lane, slice) per wave; the tail workgroup is padded to a whole workgroup (<= 16 waves), so every
+  // variant fits
   const size_t tasks = (size_t)(nseq + 15) / 16 + 16;
   return tasks * ndir * (size_t)(hidden / 16) * 64 * 16 + 256;
 }
+// the pair-interleaved copy of a weight stream (lstm_static2.h) lives behind the cell state: room for the largest
+// stream of the hidden size (c0 + c2 <= 272 channels) per direction
+static size_t pair_stream_bytes(int hidden, int ndir) {
+  return hidden == 256 ? (size_t)ndir * (hidden / 16) * quads_per_slice(256, 16, hidden) * 4096 : 0;
+}
+
+size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {
+  if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
+  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir);
+}
+
+namespace {
+// standard stream [slice][quad][4 records] -> pair-interleaved [slice pair][quad][slice in pair][4 records]; one thread
+// per float4 of the stream
+__global__ void __launch_bounds__(256) pair_stream_kernel(const float4* __restrict__ in, int qps, long long n4,
+                                                          float4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int l = (int)(i & 63);                      // float4 inside the 1-KiB record
+  const long long rec = i >> 6;                      // output record index = ((p * qps + q) * 2 + j) * 4 + r
+  const int r = (int)(rec & 3), j = (int)((rec >> 2) & 1);
+  const long long pq = rec >> 3;
+  const int q = (int)(pq % qps);
+  const long long pp = pq / qps;
+  const long long src = (((2 * pp + j) * qps + q) * 4 + r) * 64 + l;
+  out[i] = in[src];
+}
+}  // namespace
 
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   FNSSL_REQUIRE(d, "lstm_forward: null descriptor");
@@ -234,7 +262,26 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     if (d->variant == 0 && !env_int("FNSSL_LSTM_NO_STATIC", 1, 1)) {
       int rc = kNoStatic;
       if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
-      if (H == 256) rc = launch_static_h256(p, mode, vr.NW, nwg, st);
+      if (H == 256) {
+        // two hidden slices per pass (lstm_static2.h) for the full-chip narrow-band rounds of blocks 2 / 3: the stream
+        // is re-ordered into the workspace first (2 MB per direction, one tiny launch) — FNSSL_NO_STATIC2=1: A/B
+        if (vr.NW == 12 && d->c0 == 256 && d->c2 == 0 && !(mode & ~kSum) && !p.carry && !p.ablate &&
+            !env_int("FNSSL_NO_STATIC2", 1, 1)) {
+          LstmParams p2 = p;
+          const long long n4 = (long long)(H / 16) * p.quads_per_slice * 4 * 64;      // float4 per direction
+          char* dst = reinterpret_cast<char*>(d->workspace) + cell_scratch_bytes(d->nseq, H, d->ndir);
+          for (int di = 0; di < d->ndir; ++di) {
+            float4* o = reinterpret_cast<float4*>(dst + (size_t)di * n4 * 16);
+            hipLaunchKernelGGL(pair_stream_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const float4*>(p.wpack[di]), p.quads_per_slice, n4, o);
+            p2.wpack[di] = reinterpret_cast<const float*>(o);
+          }
+          FNSSL_CHECK_LAUNCH("pair_stream_kernel");
+          rc = launch_static2_h256(p2, mode, nwg, st);
+          if (rc != kNoStatic) return rc;
+        }
+        rc = launch_static_h256(p, mode, vr.NW, nwg, st);
+      }
       if (rc == kNoStatic && !env_int("FNSSL_NO_STATIC_IPDNET", 1, 1)) rc = launch_static_ipdnet(p, mode, H, vr.NW, nwg, st);
       if (rc != kNoStatic) return rc;
     }

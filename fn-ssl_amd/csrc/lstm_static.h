@@ -299,6 +299,7 @@ int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
 constexpr int kNoStatic = -100;
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
+int launch_static2_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static2.h, pair-interleaved stream
 int launch_static_ipdnet(const LstmParams& p, int mode, int H, int NW, int nwg, hipStream_t st);
 
 }  // namespace fnssl_lstm

@@ -232,11 +232,11 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
 #undef SQUAD2_1
 }
 
-template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE>
+template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE, int XD = 4>
 int launch_static2_k(const LstmParams& p, int nwg, hipStream_t st) {
   const size_t lds = (size_t)2 * CHQ * 8192;
   static_assert(2 * CHQ * 8192 <= 160 * 1024, "ring does not fit the LDS");
-  auto k = lstm_static2_kernel<H, NW, M, NV0, NS2, CHQ, PAD, MODE>;
+  auto k = lstm_static2_kernel<H, NW, M, NV0, NS2, CHQ, PAD, MODE, XD>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);

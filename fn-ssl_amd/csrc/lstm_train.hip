@@ -42,6 +42,8 @@ static int plan_rounds(int tasks, int ndir, int max_split, int split4_groups_per
   if (const int f = env_int("FNSSL_TRAIN_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
   if (split > max_split) split = max_split;
   if (split > 1) {
+    // (one group per workgroup — 512 four-wave workgroups, two per CU, which drift apart — was measured at config 4:
+    //  narrow-band BPTT 77.7 ms against 75.3 with two groups per workgroup)
     const int nw = (split == 4 && total >= 2LL * ncu) ? 8 : 4;
     return fn(Geometry{nw, split, 0, tasks});
   }

@@ -41,6 +41,53 @@ int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train
 int forward_bf16(LstmParams p, int H, hipStream_t st);             // lstm_bf16.hip
 }  // namespace fnssl_lstm
 
+// ---- launch planner (host) -------------------------------------------------------------------------------------
+// Rounds (one launch each, one workgroup per CU) for `tasks` 16-sequence groups per direction on `ncu` CUs: the CHEAPEST
+// sequence of supported workgroup sizes that covers W = ceil(tasks * ndir / ncu) waves per CU, largest first.
+static int plan_lstm_rounds(int H, int tasks, int ndir, int ncu, std::vector<int>& nw_out, std::vector<int>& var_out) {
+  struct Sup {
+    int nw, variant;
+  };
+  static const Sup sup128[] = {{4, 2}, {8, 3}, {12, 4}, {13, 9}, {14, 10}, {15, 11}, {16, 5}};
+  static const Sup sup256[] = {{4, 2}, {8, 3}, {12, 4}};
+  const Sup* sup = H == 128 ? sup128 : sup256;
+  const int nsup = H == 128 ? 7 : 3;
+  const long long total = (long long)tasks * ndir;
+  const int W = (int)((total + ncu - 1) / ncu);            // waves per CU if spread evenly
+  // + a fixed cost per round (a launch of 256-300 dependent steps) and a slightly convex per-wave term (ties go to
+  // the evenest split: 15 + 14 measured 94.2 ms against 95.5 for 16 + 13)
+  auto cost = [](int nw) { return 2.0 + 12.0 * ((nw + 3) / 4) + 0.06 * nw + 0.002 * nw * nw; };
+  // best[w] = cheapest cost to cover w waves per CU; first[w] = a round of that solution
+  constexpr int kMaxW = 4096;
+  FNSSL_REQUIRE(W >= 1 && W <= kMaxW, "lstm_forward: %d waves per CU is beyond the launch planner", W);
+  std::vector<double> best(W + 1, 0.0);
+  std::vector<int> first(W + 1, 0);
+  for (int w = 1; w <= W; ++w) {
+    best[w] = 1e30;
+    for (int i = 0; i < nsup; ++i) {
+      const int rest = w - sup[i].nw > 0 ? w - sup[i].nw : 0;
+      const double c = cost(sup[i].nw) + best[rest];
+      if (c < best[w] - 1e-9 || (c < best[w] + 1e-9 && sup[i].nw > sup[first[w]].nw)) {
+        best[w] = c;
+        first[w] = i;
+      }
+    }
+  }
+  std::vector<int> seq;
+  for (int w = W; w > 0;) {
+    seq.push_back(first[w]);
+    w -= sup[first[w]].nw;
+  }
+  std::sort(seq.begin(), seq.end(), [&](int a, int b) { return sup[a].nw > sup[b].nw; });   // the partial round last
+  nw_out.clear();
+  var_out.clear();
+  for (int i : seq) {
+    nw_out.push_back(sup[i].nw);
+    var_out.push_back(sup[i].variant);
+  }
+  return FNSSL_OK;
+}
+
 extern "C" {
 
 size_t fnssl_lstm_packed_floats(int c0, int c2, int hidden) {
@@ -108,6 +155,16 @@ static size_t cell_scratch_bytes(int nseq, int hidden, int ndir) {
 // stream of the hidden size (c0 + c2 <= 272 channels) per direction
 static size_t pair_stream_bytes(int hidden, int ndir) {
   return hidden == 256 ? (size_t)ndir * (hidden / 16) * quads_per_slice(256, 16, hidden) * 4096 : 0;
+}
+
+int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap) {
+  FNSSL_REQUIRE((hidden == 128 || hidden == 256) && nseq > 0 && (ndir == 1 || ndir == 2) && ncu > 0 && waves_per_wg && cap > 0,
+                "lstm_plan_rounds: bad arguments");
+  std::vector<int> nw, var;
+  const int rc = plan_lstm_rounds(hidden, (nseq + 15) / 16, ndir, ncu, nw, var);
+  if (rc != FNSSL_OK) return rc;
+  for (size_t i = 0; i < nw.size() && (int)i < cap; ++i) waves_per_wg[i] = nw[i];
+  return (int)nw.size();
 }
 
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {
@@ -347,48 +404,17 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   // cost table (units: one wave-time per SIMD + a small per-wave term): config 2's full-band layers, 7200 groups ->
   // W = 29 -> 15 + 14 (no SIMD-balanced split covers 29); 191 of its 192 pairs, 7164 groups -> W = 28 -> 16 + 12, one
   // wave-time per SIMD less (Model.FN_SSL peels the last pair onto a second stream for exactly this reason).
-  struct Sup {
-    int nw, variant;
-  };
-  static const Sup sup128[] = {{4, 2}, {8, 3}, {12, 4}, {13, 9}, {14, 10}, {15, 11}, {16, 5}};
-  static const Sup sup256[] = {{4, 2}, {8, 3}, {12, 4}};
-  const Sup* sup = H == 128 ? sup128 : sup256;
-  const int nsup = H == 128 ? 7 : 3;
-  const long long total = (long long)tasks * d->ndir;
-  const int W = (int)((total + ncu - 1) / ncu);            // waves per CU if spread evenly
-  // + a fixed cost per round (a launch of 256-300 dependent steps) and a slightly convex per-wave term (ties go to
-  // the evenest split: 15 + 14 measured 94.2 ms against 95.5 for 16 + 13)
-  auto cost = [](int nw) { return 2.0 + 12.0 * ((nw + 3) / 4) + 0.06 * nw + 0.002 * nw * nw; };
-  // best[w] = cheapest cost to cover w waves per CU; first[w] = the round to run first (largest first)
-  constexpr int kMaxW = 4096;
-  FNSSL_REQUIRE(W <= kMaxW, "lstm_forward: %d waves per CU is beyond the launch planner", W);
-  std::vector<double> best(W + 1, 0.0);
-  std::vector<int> first(W + 1, 0);
-  for (int w = 1; w <= W; ++w) {
-    best[w] = 1e30;
-    for (int i = 0; i < nsup; ++i) {
-      const int rest = w - sup[i].nw > 0 ? w - sup[i].nw : 0;
-      const double c = cost(sup[i].nw) + best[rest];
-      if (c < best[w] - 1e-9 || (c < best[w] + 1e-9 && sup[i].nw > sup[first[w]].nw)) {
-        best[w] = c;
-        first[w] = i;
-      }
-    }
+  std::vector<int> seq_nw, seq_var;
+  {
+    const int rc = plan_lstm_rounds(H, tasks, d->ndir, ncu, seq_nw, seq_var);
+    if (rc != FNSSL_OK) return rc;
   }
-  // run the rounds largest first (the last, possibly partial, round is the smallest)
-  std::vector<int> seq;
-  for (int w = W; w > 0;) {
-    seq.push_back(first[w]);
-    w -= sup[first[w]].nw;
-  }
-  std::sort(seq.begin(), seq.end(), [&](int a, int b) { return sup[a].nw > sup[b].nw; });
   const int wgs_per_dir_round = ncu / d->ndir > 0 ? ncu / d->ndir : 1;
   int t0 = 0;
-  for (size_t r = 0; r < seq.size() && t0 < tasks; ++r) {
-    const Sup s = sup[seq[r]];
-    int t1 = r + 1 == seq.size() ? tasks : t0 + wgs_per_dir_round * s.nw;
+  for (size_t r = 0; r < seq_nw.size() && t0 < tasks; ++r) {
+    int t1 = r + 1 == seq_nw.size() ? tasks : t0 + wgs_per_dir_round * seq_nw[r];
     if (t1 > tasks) t1 = tasks;
-    const int rc = launch_range(s.variant, t0, t1);
+    const int rc = launch_range(seq_var[r], t0, t1);
     if (rc != FNSSL_OK) return rc;
     t0 = t1;
   }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 13
+#define FNSSL_ABI_VERSION 14
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -197,6 +197,11 @@ int fnssl_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
                     int c0, int c2, int hidden, float* packed);
 
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir);
+
+/* Host-only query of the launch planner of fnssl_lstm_forward (full-chip fp32 launches, hidden 128 / 256): the rounds
+ * (one launch each, one workgroup of waves_per_wg[i] waves per CU) it runs for nseq sequences per direction on ncu CUs.
+ * Returns the number of rounds (waves_per_wg gets min(rounds, cap) entries) or a negative status. */
+int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap);
 
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
 

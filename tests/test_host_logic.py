@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.fnssl_abi_version() == 13
+    assert lib.fnssl_abi_version() == 14
 
 
 def test_shape_helpers_match_reference_formulas():
@@ -308,3 +308,28 @@ def test_bench_gpus_n_refuses_to_run_with_fewer_devices():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
+
+
+def test_launch_planner_picks_the_cheapest_rounds():
+    """The launch planner of fnssl_lstm_forward (host logic, queried without a GPU): a round costs one wave-time per
+    wave on its fullest SIMD, so config 2's full-band layers (57 600 sequences x 2 directions = 7 200 wave tasks on 256
+    CUs, 29 waves per CU) run 15 + 14, 191 of its 192 pairs (28 waves per CU) run 16 + 12, the narrow-band layers
+    (49 152 sequences, 12 waves per CU at 3 per SIMD) one round of 12, and small launches one round."""
+    lib = _lib.load()
+
+    def rounds(hidden, nseq, ndir, ncu=256):
+        buf = (C.c_int * 16)()
+        n = lib.fnssl_lstm_plan_rounds(hidden, nseq, ndir, ncu, buf, 16)
+        assert n > 0, lib.fnssl_last_error()
+        return [buf[i] for i in range(n)]
+
+    assert rounds(128, 192 * 300, 2) == [15, 14]
+    assert rounds(128, 191 * 300, 2) == [16, 12]
+    assert rounds(256, 192 * 256, 1) == [12]
+    assert rounds(256, 384 * 256, 1) == [12, 12]
+    assert rounds(128, 96 * 300, 2) == [15]                     # 3 600 tasks = 14.06 waves per CU
+    assert rounds(128, 16 * 300, 2) == [4]                      # (small launches take the split kernels before the planner)
+    for nseq in (1, 999, 57600, 123456):                        # every plan covers the work
+        for hidden, ndir in ((128, 2), (256, 1)):
+            assert sum(rounds(hidden, nseq, ndir)) * 256 >= ((nseq + 15) // 16) * ndir
+    assert lib.fnssl_lstm_plan_rounds(64, 100, 1, 256, (C.c_int * 4)(), 4) < 0

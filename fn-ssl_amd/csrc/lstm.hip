@@ -157,6 +157,13 @@ static size_t pair_stream_bytes(int hidden, int ndir) {
   return hidden == 256 ? (size_t)ndir * (hidden / 16) * quads_per_slice(256, 16, hidden) * 4096 : 0;
 }
 
+// the hand-off area of the cluster-resident bf16 kernel (lstm_bf16c.h) lives behind that: status word, tags, operand records
+static size_t cluster_bytes(int nseq, int hidden, int ndir) {
+  if (hidden != 256) return 0;
+  const size_t ncl = (size_t)ndir * ((nseq + kClusterSeqs - 1) / kClusterSeqs);
+  return 256 + ncl * (kClusterTagWords * 4) + ncl * kClusterHxBytes;
+}
+
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap) {
   FNSSL_REQUIRE((hidden == 128 || hidden == 256) && nseq > 0 && (ndir == 1 || ndir == 2) && ncu > 0 && waves_per_wg && cap > 0,
                 "lstm_plan_rounds: bad arguments");
@@ -169,7 +176,7 @@ int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_p
 
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {
   if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
-  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir);
+  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir) + cluster_bytes(nseq, hidden, ndir);
 }
 
 namespace {
@@ -249,6 +256,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.wpack[0] = d->wpack[0];
   p.wpack[1] = d->wpack[1];
   p.cscratch = d->workspace;
+  p.cluster_ws = reinterpret_cast<char*>(d->workspace) + cell_scratch_bytes(d->nseq, H, d->ndir) + pair_stream_bytes(H, d->ndir);
   p.reserve = d->reserve;
   p.ntasks = (d->nseq + 15) / 16;
   p.c0 = d->c0;

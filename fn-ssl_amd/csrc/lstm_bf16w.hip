@@ -7,6 +7,9 @@
 
 namespace fnssl_lstm {
 
+bool bf16c_handles(const LstmParams& p, int H, int flags);           // lstm_bf16c.hip
+int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st);
+
 // NW = 2: two consumer waves + two loader waves on the SIMDs the launch leaves idle; NW = 4: four consumers that
 // fetch their own stream (H = 128 only: at H = 256 the ring plus four h staging areas exceed the LDS)
 #define TRYW(H_, NB0_, NB2_, FL_)                                                                                \
@@ -58,6 +61,8 @@ int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st) {
   const long long total = (long long)groups * p.ndir;
   p.task0 = 0;
   p.task1 = groups;
+  // cluster-resident kernel (lstm_bf16c.h) for the shape it is built for: weights stay in LDS, h_t is exchanged through L2
+  if (bf16c_handles(p, H, flags)) return forward_bf16c(p, H, flags, st);
   int rc;
   if (!getenv("FNSSL_BF16W_SOLO")) {
     // Two 32-sequence groups per workgroup.  lstm_bf16p_kernel takes NG groups (template), and 3 / 4 / 5 were built and

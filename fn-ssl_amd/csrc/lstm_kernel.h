@@ -31,6 +31,7 @@ struct LstmParams {
   long long out_so, out_si, out_st;
   const float* wpack[2];
   float* cscratch;
+  char* cluster_ws;   // hand-off area of the cluster-resident bf16 kernel (lstm_bf16c.h): status, tags, operand records
   float* reserve;     // training forward (MODE bit kSave): gates + cell state per (dir, group, step, slice)
   int ntasks;         // 16-sequence groups per direction (reserve / cell-state indexing)
   int carry;          // streaming: 1 = h_{-1} is the row before `out` (host passes out - out_st), c_{-1} is in cscratch
@@ -42,6 +43,12 @@ struct LstmParams {
   int chq, pad;   // ring chunk (quads) and per-slice padding (quads); 0 for direct variants
   int ablate;     // timing experiments only (env FNSSL_ABLATE): bit flags, see lstm_rec_kernel
 };
+
+// cluster-resident bf16 kernel (lstm_bf16c.h): geometry of its workspace area
+constexpr int kClusterSeqs = 512;                           // sequences per cluster: 2 halves x 8 waves x 32
+constexpr int kClusterMembers = 8;
+constexpr size_t kClusterHxBytes = 2 * 2 * 8 * 16 * 1024;   // [parity][half][sequence tile][block][1 KiB]
+constexpr int kClusterTagWords = 2 * 8 * 8;                 // [half][wave][member]
 
 // kernel MODE bits
 constexpr int kHas1 = 1;   // input segment 0 is src0 + src1

@@ -52,12 +52,16 @@ struct ClusterParams {
   int cl0;             // first cluster of this launch (global index over directions)
   int ncl;             // clusters in this launch
   int cl_per_dir;
+  int stagger;         // experiment (FNSSL_CLUSTER_STAGGER): != 0 = every wave issues its loads at the group's first K-step
 };
 
-template <int H, int NB0, int NB2, int FLAGS>
+// ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 4 no MFMAs, 8 no recurrent-operand
+// loads, 16 no input loads, 32 no output stores, 64 no publish (operand stores, tag)
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
 __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, const ClusterParams cp) {
   constexpr int NT = H / 8, TPM = NT / kClusterMembers, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr bool F0 = FLAGS & kW_F0, F2 = FLAGS & kW_F2, OUTF = FLAGS & kW_OUTF;
+  constexpr int PUBG = (ABL & 128) ? 2 : (ABL & 256) ? 3 : 1;   // input group (K = 4 PUBG + 1) at which the previous half-step's tag is stored
   static_assert(TPM == 4 && NKH == 16 && NB0 == 16 && NB2 == 1 && !F0 && F2 && !OUTF,
                 "built for IPDnet's narrow-band shape: 256 <- [256 bf16 | 16 fp32], bf16 out");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
     off0[hf] = qo * p.src0.so + qi * p.src0.si + 8 * hb;
     off2[hf] = qo * p.src2.so + qi * p.src2.si + 8 * hb;
-    offo[hf] = qo * p.out_so + qi * p.out_si + dir * H + 8 * m * TPM + 4 * hb;
+    offo[hf] = qo * p.out_so + qi * p.out_si + dir * H + 8 * m * TPM + 16 * hb;   // (after the lane-pair swap below)
   }
   // (buffer descriptors are opaque scalars: one named variable per half, picked by the compile-time half index)
   const rsrc_t rx0_0 = split_addr_e<2>(p.src0.p, off0[0], vo0[0]), rx0_1 = split_addr_e<2>(p.src0.p, off0[1], vo0[1]);
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     constexpr int G = decltype(gc)::value;
     static_for<4>([&](auto i) {
       constexpr int B = 4 * G + decltype(i)::value;
-      win[4 * (G & 3) + decltype(i)::value] = __builtin_bit_cast(v8bfw, bld4(hf ? rx0_1 : rx0_0, vo0[hf], tt * st0 + 32 * B));
+      if constexpr (!(ABL & 16)) win[4 * (G & 3) + decltype(i)::value] = __builtin_bit_cast(v8bfw, bld4(hf ? rx0_1 : rx0_0, vo0[hf], tt * st0 + 32 * B));
     });
   };
   auto load_skip = [&](int hf, unsigned tt) {
@@ -143,7 +147,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     constexpr int G = decltype(gc)::value;
     static_for<4>([&](auto i) {
       constexpr int S = 4 * G + decltype(i)::value;
-      win[4 * (G & 3) + decltype(i)::value] = __builtin_bit_cast(v8bfw, bld4_l2(rhx, vlane, hx_off(par, hf, S)));
+      if constexpr (!(ABL & 8)) win[4 * (G & 3) + decltype(i)::value] = __builtin_bit_cast(v8bfw, bld4_l2(rhx, vlane, hx_off(par, hf, S)));
     });
   };
   auto load_tags = [&](int hf) {
@@ -203,11 +207,17 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       if constexpr (K >= 1 && K <= NB0 && (K - 1) % 4 == 0) {                  // input groups 0..3 start at K = 1, 5, 9, 13
         constexpr int G = (K - 1) / 4;
         if constexpr (G == 0) load_xgroup(ic<3>{}, HF, tt);
-        if constexpr (G == 1) {
-          if (HF == 1 || step > 0) pub_flush(HF ^ 1);
-          if (step > 0) wait_tags(HF, (unsigned)step);
+        if constexpr (G == PUBG) {
+          if constexpr (!(ABL & 64)) {
+            if (HF == 1 || step > 0) pub_flush(HF ^ 1);
+          }
         }
-        if constexpr (G >= 1) load_hgroup(ic<G - 1>{}, HF, par);        // recurrent groups 0..2
+        if constexpr (G == 1) {
+          if constexpr (!(ABL & 1)) {
+            if (step > 0) wait_tags(HF, (unsigned)step);
+          }
+        }
+        if constexpr (G >= 1) load_hgroup(ic<G - 1>{}, HF, par);              // recurrent groups 0..2
       }
       if constexpr (K >= 2 + NB0 && (K - 2 - NB0) % 4 == 0) {                  // recurrent groups 0..3 start at K = 18, 22, ..
         constexpr int G = (K - 2 - NB0) / 4;
@@ -229,18 +239,25 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
         bop = join8(__builtin_convertvector(sk0, v4bfw), __builtin_convertvector(sk1, v4bfw));
       else
         bop = win[(K - 2 - NB0) & 15];
-      // ---- A operands one K-step ahead, 4 MFMAs
+      // ---- A operands one K-step ahead, 4 MFMAs.  The scheduling fences keep the four LDS reads of K-step K + 1 in
+      // front of the MFMAs of K-step K: left alone the scheduler sinks each read next to its use (one MFMA ahead),
+      // and every MFMA then waits out an LDS round trip (measured: 51 cycles per MFMA instead of 32)
       v8bfw an[TPM];
       if constexpr (K + 1 < KT) static_for<TPM>([&](auto r) { an[decltype(r)::value] = arec(decltype(r)::value, K + 1); });
+      __builtin_amdgcn_sched_barrier(0);
       static_for<TPM>([&](auto r) {
         constexpr int R = decltype(r)::value;
-        if constexpr (K == 0) {
+        if constexpr (ABL & 4) {
+          if constexpr (K == 0) acc[R] = v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[R][K % 16] += (float)a[R][0] + (float)bop[0];
+        } else if constexpr (K == 0) {
           const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[R], bop, z, 0, 0, 0);
         } else {
           acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[R], bop, acc[R], 0, 0, 0);
         }
       });
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (K + 1 < KT) static_for<TPM>([&](auto r) { a[decltype(r)::value] = an[decltype(r)::value]; });
     });
 
@@ -253,18 +270,48 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     static_for<TPM>([&](auto r) {
       constexpr int R = decltype(r)::value;
       const v16f& ac = acc[R];
-      const v4f ig = sigmoid4(v4f{ac[0], ac[1], ac[2], ac[3]});
-      const v4f fg = sigmoid4(v4f{ac[4], ac[5], ac[6], ac[7]});
-      const v4f gg = tanh4(v4f{ac[8], ac[9], ac[10], ac[11]});
-      const v4f og = sigmoid4(v4f{ac[12], ac[13], ac[14], ac[15]});
-      const v4f cn = cell4(fg, c[HF][R], ig, gg);
-      const v4f hn = mul_rn4(og, tanh4(cn));
+      v4f cn, hn;
+      if constexpr (ABL & 2) {
+        cn = c[HF][R] * 0.5f + v4f{ac[0], ac[5], ac[10], ac[15]};
+        hn = cn * 0.5f + v4f{ac[1], ac[6], ac[11], ac[12]};
+      } else {
+        const v4f ig = sigmoid4(v4f{ac[0], ac[1], ac[2], ac[3]});
+        const v4f fg = sigmoid4(v4f{ac[4], ac[5], ac[6], ac[7]});
+        const v4f gg = tanh4(v4f{ac[8], ac[9], ac[10], ac[11]});
+        const v4f og = sigmoid4(v4f{ac[12], ac[13], ac[14], ac[15]});
+        cn = cell4(fg, c[HF][R], ig, gg);
+        hn = mul_rn4(og, tanh4(cn));
+      }
       c[HF][R] = cn;
       hq[R] = __builtin_convertvector(hn, v4bfw);
-      if (valid[HF]) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, hq[R]), HF ? ro_1 : ro_0, voo[HF], oo + 16 * R, 0);
     });
+    // Output row piece of this member: units 32 m .. 32 m + 31 (64 bytes per sequence).  Lane (n, hb) holds units
+    // 8 r + 4 hb + 0..3 of tile r: four 8-byte pieces 16 bytes apart.  v_permlane32_swap trades halves between lanes
+    // (n, 0) and (n, 1) so that lane (n, 0) ends up with tiles 0, 1 and lane (n, 1) with tiles 2, 3, 32 contiguous bytes
+    // each: two 16-byte stores instead of four 8-byte ones (the stores' acknowledgements hold back every younger load
+    // of the wave — vector memory operations retire in order — and cost 2 us per step as four: profiles/r03/j_*)
+    if constexpr (!(ABL & 32)) {
+      const v2u d0 = __builtin_bit_cast(v2u, hq[0]), d1 = __builtin_bit_cast(v2u, hq[1]);
+      const v2u d2 = __builtin_bit_cast(v2u, hq[2]), d3 = __builtin_bit_cast(v2u, hq[3]);
+      // swap(a, b): first result = {lanes 0-31: a's, lanes 32-63: b's lower half}; second = {a's upper half, b's}
+      const auto s00 = __builtin_amdgcn_permlane32_swap(d0[0], d2[0], false, false);
+      const auto s01 = __builtin_amdgcn_permlane32_swap(d0[1], d2[1], false, false);
+      const auto s10 = __builtin_amdgcn_permlane32_swap(d1[0], d3[0], false, false);
+      const auto s11 = __builtin_amdgcn_permlane32_swap(d1[1], d3[1], false, false);
+      const v4u lo = {s00[0], s01[0], s00[1], s01[1]};   // hb 0: tile 0 units 0-3, 4-7; hb 1: tile 2
+      const v4u hi = {s10[0], s11[0], s10[1], s11[1]};   // hb 0: tile 1;                hb 1: tile 3
+      if constexpr (ABL & 1024) {            // timing experiment: the same bytes to a compact area (wrong results)
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rhx, vlane, hx_off(step & 1, HF, 2 * m), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rhx, vlane, hx_off(step & 1, HF, 2 * m + 1), 0);
+      } else if (valid[HF]) {
+        constexpr int AUX = (ABL & 512) ? 2 : (ABL & 2048) ? 16 : 0;
+        __builtin_amdgcn_raw_buffer_store_b128(lo, HF ? ro_1 : ro_0, voo[HF], oo, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, HF ? ro_1 : ro_0, voo[HF], oo + 16, AUX);
+      }
+    }
     // tiles 4 m, 4 m + 1 -> block 2 m (bytes 0-7, 8-15 of the lane's 16); tiles 4 m + 2, 4 m + 3 -> block 2 m + 1
     const int wpar = step & 1;
+    if constexpr (!(ABL & 64)) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[0], hq[1])), rhx, vlane, hx_off(wpar, HF, 2 * m), 16);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[2], hq[3])), rhx, vlane, hx_off(wpar, HF, 2 * m + 1), 16);
     // publish, first half: a load issued behind the two stores.  Vector memory operations of a wave complete in order, so
@@ -274,6 +321,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
     asm volatile("" ::: "memory");   // (keeps the load here: sunk next to its use it would make that wait a full drain)
     pub_val = (unsigned)step + 1;
+    }
   };
 
   for (int step = 0; step < p.nsteps; ++step) {
@@ -284,11 +332,11 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int H, int NB0, int NB2, int FLAGS>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
 int launch_bf16c_k(const LstmParams& p, const ClusterParams& cp, hipStream_t st) {
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
   const size_t lds = (size_t)(H / 8 / kClusterMembers) * KT * 1024;
-  auto k = lstm_bf16c_kernel<H, NB0, NB2, FLAGS>;
+  auto k = lstm_bf16c_kernel<H, NB0, NB2, FLAGS, ABL>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = 64 * ((cp.ncl + 7) / 8);
   hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, st, p, cp);

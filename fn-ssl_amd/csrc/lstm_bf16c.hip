@@ -31,10 +31,37 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   // status word + tags, and the parity-1 operand records (step 0 reads h_{-1} = 0 from them)
   FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + (size_t)ncl * (kClusterTagWords * 4), st));
   FNSSL_HIP(hipMemsetAsync(cp.hx + cp.parity_stride, 0, cp.parity_stride, st));
+  cp.stagger = env_int("FNSSL_CLUSTER_STAGGER", 1, 1000);
   for (int c0 = 0; c0 < ncl; c0 += per_launch) {
     cp.cl0 = c0;
     cp.ncl = ncl - c0 < per_launch ? ncl - c0 : per_launch;
-    const int rc = launch_bf16c_k<256, 16, 1, kW_F2>(p, cp, st);
+    int rc = FNSSL_OK;
+#ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
+    switch (env_int("FNSSL_CLUSTER_ABL", 1, 4095)) {
+      case 1: rc = launch_bf16c_k<256, 16, 1, kW_F2, 1>(p, cp, st); break;
+      case 2: rc = launch_bf16c_k<256, 16, 1, kW_F2, 2>(p, cp, st); break;
+      case 4: rc = launch_bf16c_k<256, 16, 1, kW_F2, 4>(p, cp, st); break;
+      case 6: rc = launch_bf16c_k<256, 16, 1, kW_F2, 6>(p, cp, st); break;
+      case 9: rc = launch_bf16c_k<256, 16, 1, kW_F2, 9>(p, cp, st); break;
+      case 25: rc = launch_bf16c_k<256, 16, 1, kW_F2, 25>(p, cp, st); break;
+      case 128: rc = launch_bf16c_k<256, 16, 1, kW_F2, 128>(p, cp, st); break;
+      case 256: rc = launch_bf16c_k<256, 16, 1, kW_F2, 256>(p, cp, st); break;
+      case 512: rc = launch_bf16c_k<256, 16, 1, kW_F2, 512>(p, cp, st); break;
+      case 1024: rc = launch_bf16c_k<256, 16, 1, kW_F2, 1024>(p, cp, st); break;
+      case 2048: rc = launch_bf16c_k<256, 16, 1, kW_F2, 2048>(p, cp, st); break;
+      case 32: rc = launch_bf16c_k<256, 16, 1, kW_F2, 32>(p, cp, st); break;
+      case 64: rc = launch_bf16c_k<256, 16, 1, kW_F2, 64>(p, cp, st); break;
+      case 65: rc = launch_bf16c_k<256, 16, 1, kW_F2, 65>(p, cp, st); break;
+      case 97: rc = launch_bf16c_k<256, 16, 1, kW_F2, 97>(p, cp, st); break;
+      case 57: rc = launch_bf16c_k<256, 16, 1, kW_F2, 57>(p, cp, st); break;
+      case 89: rc = launch_bf16c_k<256, 16, 1, kW_F2, 89>(p, cp, st); break;
+      case 121: rc = launch_bf16c_k<256, 16, 1, kW_F2, 121>(p, cp, st); break;
+      case 123: rc = launch_bf16c_k<256, 16, 1, kW_F2, 123>(p, cp, st); break;
+      default: rc = launch_bf16c_k<256, 16, 1, kW_F2>(p, cp, st); break;
+    }
+#else
+    rc = launch_bf16c_k<256, 16, 1, kW_F2>(p, cp, st);
+#endif
     if (rc != FNSSL_OK) return rc;
   }
   return FNSSL_OK;

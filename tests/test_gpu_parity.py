@@ -1020,6 +1020,42 @@ def test_lstm_bf16_wide_matches_oracle_and_narrow_kernel(dev, mode, H, bidir, c0
     assert np.abs(got - O.bf16_round(want)).mean() < 2e-4
 
 
+@pytest.mark.parametrize("nb,nt,nf", [
+    (2, 7, 256),      # 512 sequences: exactly one cluster
+    (3, 5, 200),      # 600 sequences: a second cluster with 88 live sequences (ragged tile, idle waves)
+    (9, 4, 257),      # 2313 sequences: five clusters, q_inner not a multiple of 32
+])
+def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch, nb, nt, nf):
+    """lstm_bf16c.h (weights resident in the LDS of an 8-CU cluster, h_t exchanged through L2 with tagged hand-offs)
+    against the bf16-emulating oracle, and bit-for-bit against the pair-split kernels (FNSSL_NO_CLUSTER=1) it replaces
+    for IPDnet's narrow-band shape; twice, to catch a hand-off race."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    H, c0, c2 = 256, 256, 16
+    sd = lstm_state(c0 + c2, H, False, 5400 + nb)
+    x = O.bf16_round(rs_randn(5401 + nf, (nb, nt, nf, c0 + c2), 0.7))
+    seq = np.transpose(x, (0, 2, 1, 3)).reshape(nb * nf, nt, c0 + c2)
+    want = np.transpose(O.lstm(seq, sd, "L.", False, bf16=True).reshape(nb, nf, nt, -1), (0, 2, 1, 3))
+    w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0, c2, dev)]
+    xd = to_dev(x, dev)
+    x0, x2 = xd[..., :c0].contiguous().bfloat16(), xd[..., c0:].contiguous()
+
+    def run():
+        out = torch.full((nb, nt, nf, H), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops.lstm_layer("narrow", x0, None, x2, w, H, out, bf16=True, wide=True)
+        return out
+
+    monkeypatch.delenv("FNSSL_NO_CLUSTER", raising=False)
+    a, a2 = run(), run()
+    monkeypatch.setenv("FNSSL_NO_CLUSTER", "1")
+    b = run()
+    got = a.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= BF_ATOL + 2e-3, "vs bf16 oracle: %g" % np.abs(got - want).max()
+    assert torch.equal(a, b), "cluster kernel differs from the pair-split kernels"
+    assert torch.equal(a, a2), "cluster kernel is not repeatable"
+
+
 def test_lstm_bf16_wide_rejects_unbuilt_shapes(dev):
     from fnssl import ops
     sd = lstm_state(128, 256, False, 5200)

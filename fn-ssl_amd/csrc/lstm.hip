@@ -159,9 +159,9 @@ static size_t pair_stream_bytes(int hidden, int ndir) {
 
 // the hand-off area of the cluster-resident bf16 kernel (lstm_bf16c.h) lives behind that: status word, tags, operand records
 static size_t cluster_bytes(int nseq, int hidden, int ndir) {
-  if (hidden != 256) return 0;
-  const size_t ncl = (size_t)ndir * ((nseq + kClusterSeqs - 1) / kClusterSeqs);
-  return 256 + ncl * (kClusterTagWords * 4) + ncl * kClusterHxBytes;
+  if (hidden != 256 && hidden != 128) return 0;
+  const size_t ncl = (size_t)ndir * ((nseq + cluster_seqs(hidden) - 1) / cluster_seqs(hidden));
+  return 256 + ncl * (kClusterTagWords * 4) + ncl * 2 * cluster_parity_bytes(hidden);
 }
 
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap) {

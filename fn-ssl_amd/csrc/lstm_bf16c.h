@@ -40,36 +40,47 @@
 
 namespace fnssl_lstm {
 
-// (kClusterSeqs, kClusterMembers, kClusterHxBytes, kClusterTagWords: lstm_kernel.h)
+// Geometry per hidden size (cluster_geom in lstm_kernel.h has the host-side copy used for the workspace):
+//   H = 256 (narrow-band): 8 members x 4 tiles, 2 parts  -> 512 sequences per cluster
+//   H = 128 (full-band):   4 members x 4 tiles, 3 parts  -> 768 sequences per cluster (config 3: 19200 sequences per
+//                          direction = exactly 25 clusters, 50 clusters x 4 CUs in ONE launch; with 2 parts it would be
+//                          76 clusters = 304 workgroups, i.e. two rounds)
+// "part" = one 32-sequence tile per wave; a wave cycles through its NP parts, so a part's h_t has NP - 1 part-times
+// to reach the other members.
 constexpr unsigned kClusterSpinLimit = 1u << 20;
-constexpr size_t kClusterParityBytes = kClusterHxBytes / 2;   // one cluster's records of one step parity
 
 struct ClusterParams {
-  char* hx;            // [parity 2][cluster][half 2][sequence tile 8][block 16][1 KiB]; parity 1 zeroed before the launch (h_{-1} = 0)
-  unsigned parity_stride;   // bytes between the two parities = clusters of the call x kClusterParityBytes
-  unsigned* tags;      // [cluster] x kClusterTagWords, zeroed before the launch
-  unsigned* status;    // one word: 0 = fine
-  int cl0;             // first cluster of this launch (global index over directions)
-  int ncl;             // clusters in this launch
+  char* hx;                 // [parity 2][cluster][part][sequence tile 8][block H/16][1 KiB]; parity 1 zeroed before the launch (h_{-1} = 0)
+  unsigned parity_stride;   // bytes between the two parities = clusters of the call x bytes per cluster and parity
+  unsigned* tags;           // [cluster] x kClusterTagWords, zeroed before the launch
+  unsigned* status;         // one word: 0 = fine
+  int cl0;                  // first cluster of this launch (global index over directions)
+  int ncl;                  // clusters in this launch
   int cl_per_dir;
-  int stagger;         // experiment (FNSSL_CLUSTER_STAGGER): != 0 = every wave issues its loads at the group's first K-step
 };
 
-// ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 4 no MFMAs, 8 no recurrent-operand
-// loads, 16 no input loads, 32 no output stores, 64 no publish (operand stores, tag)
+// ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 8 no recurrent-operand loads,
+// 16 no input loads, 32 no output stores, 64 no publish (operand stores, tag)
 template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
 __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, const ClusterParams cp) {
-  constexpr int NT = H / 8, TPM = NT / kClusterMembers, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
+  constexpr int CL = cluster_members(H), NP = cluster_parts(H);
+  constexpr int NT = H / 8, TPM = NT / CL, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr bool F0 = FLAGS & kW_F0, F2 = FLAGS & kW_F2, OUTF = FLAGS & kW_OUTF;
-  constexpr int PUBG = (ABL & 128) ? 2 : (ABL & 256) ? 3 : 1;   // input group (K = 4 PUBG + 1) at which the previous half-step's tag is stored
-  static_assert(TPM == 4 && NKH == 16 && NB0 == 16 && NB2 == 1 && !F0 && F2 && !OUTF,
-                "built for IPDnet's narrow-band shape: 256 <- [256 bf16 | 16 fp32], bf16 out");
+  // B-operand window: groups of 4 blocks; GX input + GH recurrent groups per part; WG groups of registers; the group
+  // WG - 1 ahead is requested when a group starts, into the slots of the group consumed before it
+  constexpr int GX = NB0 / 4, GH = NKH / 4, GP = GX + GH;
+  constexpr int WG = GP % 4 == 0 ? 4 : 3, WS = 4 * WG;
+  static_assert(TPM == 4 && NB0 % 4 == 0 && NKH % 4 == 0 && NB2 == 1 && !F0 && F2 && !OUTF,
+                "built for IPDnet's shapes: [16 n bf16 channels | 16 fp32 channels] in, bf16 out");
+  static_assert(GP % WG == 0 && WG - 1 <= GX && GX >= 2, "window groups must tile a part; the look-ahead stays inside the next part's input groups");
+  constexpr int GTAG = GX - (WG - 1);                   // group at whose start the first recurrent group is requested
+  static_assert(GTAG >= 1, "the tag store of the previous part (group 1) precedes the tag wait");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- who am I: blocks of one cluster share blockIdx & 7 (observed: one XCD)
   const int b = blockIdx.x;
-  const int m = (b >> 3) & 7;
-  const int cl_local = ((b >> 6) << 3) + (b & 7);
+  const int m = (b >> 3) % CL;
+  const int cl_local = ((b >> 3) / CL) * 8 + (b & 7);
   if (cl_local >= cp.ncl) return;
   const int cg = cp.cl0 + cl_local;
   const int dir = cg / cp.cl_per_dir;
@@ -88,31 +99,36 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   }
   __syncthreads();
 
-  // ---- per-half addressing
-  unsigned vo0[2], vo2[2], voo[2];
-  bool valid[2];
-  long long off0[2], off2[2], offo[2];
+  // ---- per-part addressing (buffer descriptors are opaque scalars: named variables, picked by the part index)
+  unsigned vo0[3], vo2[3], voo[3];
+  bool valid[3];
+  long long off0[3], off2[3], offo[3];
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
-    int q = cd * kClusterSeqs + hf * 256 + w * 32 + n;
-    valid[hf] = q < p.nseq;
+  for (int pt = 0; pt < 3; ++pt) {
+    int q = cd * (NP * 256) + (pt < NP ? pt : 0) * 256 + w * 32 + n;
+    valid[pt] = q < p.nseq;
     if (q >= p.nseq) q = p.nseq - 1;
     const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
-    off0[hf] = qo * p.src0.so + qi * p.src0.si + 8 * hb;
-    off2[hf] = qo * p.src2.so + qi * p.src2.si + 8 * hb;
-    offo[hf] = qo * p.out_so + qi * p.out_si + dir * H + 8 * m * TPM + 16 * hb;   // (after the lane-pair swap below)
+    off0[pt] = qo * p.src0.so + qi * p.src0.si + 8 * hb;
+    off2[pt] = qo * p.src2.so + qi * p.src2.si + 8 * hb;
+    offo[pt] = qo * p.out_so + qi * p.out_si + dir * H + 8 * m * TPM + 16 * hb;   // (after the lane-pair swap below)
   }
-  // (buffer descriptors are opaque scalars: one named variable per half, picked by the compile-time half index)
-  const rsrc_t rx0_0 = split_addr_e<2>(p.src0.p, off0[0], vo0[0]), rx0_1 = split_addr_e<2>(p.src0.p, off0[1], vo0[1]);
-  const rsrc_t rx2_0 = split_addr_e<4>(p.src2.p, off2[0], vo2[0]), rx2_1 = split_addr_e<4>(p.src2.p, off2[1], vo2[1]);
-  const rsrc_t ro_0 = split_addr_e<2>(p.out, offo[0], voo[0]), ro_1 = split_addr_e<2>(p.out, offo[1], voo[1]);
+  const rsrc_t rx0_0 = split_addr_e<2>(p.src0.p, off0[0], vo0[0]), rx0_1 = split_addr_e<2>(p.src0.p, off0[1], vo0[1]),
+               rx0_2 = split_addr_e<2>(p.src0.p, off0[2], vo0[2]);
+  const rsrc_t rx2_0 = split_addr_e<4>(p.src2.p, off2[0], vo2[0]), rx2_1 = split_addr_e<4>(p.src2.p, off2[1], vo2[1]),
+               rx2_2 = split_addr_e<4>(p.src2.p, off2[2], vo2[2]);
+  const rsrc_t ro_0 = split_addr_e<2>(p.out, offo[0], voo[0]), ro_1 = split_addr_e<2>(p.out, offo[1], voo[1]),
+               ro_2 = split_addr_e<2>(p.out, offo[2], voo[2]);
+  auto RX0 = [&](int pt) { return pt == 0 ? rx0_0 : pt == 1 ? rx0_1 : rx0_2; };
+  auto RX2 = [&](int pt) { return pt == 0 ? rx2_0 : pt == 1 ? rx2_1 : rx2_2; };
+  auto RO = [&](int pt) { return pt == 0 ? ro_0 : pt == 1 ? ro_1 : ro_2; };
   const unsigned st0 = (unsigned)(p.src0.st * 2), st2 = (unsigned)(p.src2.st * 4), sto = (unsigned)(p.out_st * 2);
-  const rsrc_t rhx = make_rsrc(cp.hx + (size_t)cg * kClusterParityBytes);
+  const rsrc_t rhx = make_rsrc(cp.hx + (size_t)cg * cluster_parity_bytes(H));
   const rsrc_t rw = make_rsrc(p.wpack[dir]);
   const unsigned vlane = lane * 16;
   unsigned* const tag_base = cp.tags + (size_t)cg * kClusterTagWords;
-  // operand records of (parity, half): sequence tile w, block s
-  auto hx_off = [&](int par, int hf, int s) { return (unsigned)par * cp.parity_stride + (unsigned)(((hf * 8 + w) * 16 + s) * 1024); };
+  // operand records of (parity, part): sequence tile w, block s
+  auto hx_off = [&](int par, int pt, int s) { return (unsigned)par * cp.parity_stride + (unsigned)(((pt * 8 + w) * NKH + s) * 1024); };
 
   // ---- state
   v8bfw ones;
@@ -120,45 +136,43 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     const __bf16 o1 = (__bf16)(hb == 0 ? 1.0f : 0.0f);
     ones = v8bfw{o1, o1, o1, 0, 0, 0, 0, 0};
   }
-  v4f c[2][TPM];
+  v4f c[NP][TPM];
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
+  for (int pt = 0; pt < NP; ++pt)
 #pragma unroll
-    for (int r = 0; r < TPM; ++r) c[hf][r] = v4f{0.f, 0.f, 0.f, 0.f};
-  v8bfw win[16];                  // B operands in flight: group g (4 blocks) lives in slots 4 (g & 3) ..
-  v4f sk0, sk1;                   // the fp32 input block of the coming half-step (raw)
-  unsigned tagv = 0;              // tag of member (lane & 7) for the coming half-step
+    for (int r = 0; r < TPM; ++r) c[pt][r] = v4f{0.f, 0.f, 0.f, 0.f};
+  v8bfw win[WS];                  // B operands in flight: window group g (4 blocks) lives in slots 4 (g % WG) ..
+  v4f sk0, sk1;                   // the fp32 input block of the coming part (raw)
+  unsigned tagv = 0;              // tag of member (lane % CL) for the coming part
 
   const char* const lds_a = smem + lane * 16;
   auto arec = [&](int r, int k) { return __builtin_bit_cast(v8bfw, *reinterpret_cast<const v4f*>(lds_a + (r * KT + k) * 1024)); };
 
-  auto load_xgroup = [&](auto gc, int hf, unsigned tt) {          // input blocks 4 g .. 4 g + 3 of half hf at step tt
-    constexpr int G = decltype(gc)::value;
+  // window group T of part pt (T < GX: input blocks 4 T ..; else recurrent blocks 4 (T - GX) ..) into its slots
+  auto load_group = [&](auto tc, int pt, unsigned tt, int par) {
+    constexpr int T = decltype(tc)::value;
     static_for<4>([&](auto i) {
-      constexpr int B = 4 * G + decltype(i)::value;
-      if constexpr (!(ABL & 16)) win[4 * (G & 3) + decltype(i)::value] = __builtin_bit_cast(v8bfw, bld4(hf ? rx0_1 : rx0_0, vo0[hf], tt * st0 + 32 * B));
+      constexpr int I = decltype(i)::value;
+      if constexpr (T < GX) {
+        if constexpr (!(ABL & 16)) win[4 * (T % WG) + I] = __builtin_bit_cast(v8bfw, bld4(RX0(pt), vo0[pt], tt * st0 + 32 * (4 * T + I)));
+      } else {
+        if constexpr (!(ABL & 8)) win[4 * (T % WG) + I] = __builtin_bit_cast(v8bfw, bld4_l2(rhx, vlane, hx_off(par, pt, 4 * (T - GX) + I)));
+      }
     });
   };
-  auto load_skip = [&](int hf, unsigned tt) {
-    sk0 = bld4(hf ? rx2_1 : rx2_0, vo2[hf], tt * st2);
-    sk1 = bld4(hf ? rx2_1 : rx2_0, vo2[hf], tt * st2 + 16);
+  auto load_skip = [&](int pt, unsigned tt) {
+    sk0 = bld4(RX2(pt), vo2[pt], tt * st2);
+    sk1 = bld4(RX2(pt), vo2[pt], tt * st2 + 16);
   };
-  auto load_hgroup = [&](auto gc, int hf, int par) {              // recurrent blocks 4 g .. 4 g + 3
-    constexpr int G = decltype(gc)::value;
-    static_for<4>([&](auto i) {
-      constexpr int S = 4 * G + decltype(i)::value;
-      if constexpr (!(ABL & 8)) win[4 * (G & 3) + decltype(i)::value] = __builtin_bit_cast(v8bfw, bld4_l2(rhx, vlane, hx_off(par, hf, S)));
-    });
-  };
-  auto load_tags = [&](int hf) {
-    tagv = __hip_atomic_load(tag_base + (hf * 8 + w) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto load_tags = [&](int pt) {
+    tagv = __hip_atomic_load(tag_base + (pt * 8 + w) * 8 + (lane % CL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto tags_ready = [&](unsigned need) { return __builtin_amdgcn_ballot_w64(tagv < need) == 0; };
-  auto wait_tags = [&](int hf, unsigned need) {
+  auto wait_tags = [&](int pt, unsigned need) {
     if (tags_ready(need)) return;
     for (unsigned spins = 0;; ++spins) {
       __builtin_amdgcn_s_sleep(16);
-      load_tags(hf);
+      load_tags(pt);
       if (tags_ready(need)) return;
       if (spins > kClusterSpinLimit) {
         if (lane == 0) __hip_atomic_store(cp.status, 0x10000u | (unsigned)(cg & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -167,33 +181,33 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     }
   };
 
-  // deferred tag store of the previous half-step (see the end of half_step).  My tag words as 4-byte buffers: the store
-  // is issued by all lanes at offset 4 * lane, and the descriptor's range check drops lanes 1..63 (no branch)
+  // deferred tag store of the previous part (see the end of part_step).  My tag words as 4-byte buffers: the store is
+  // issued by all lanes at offset 4 * lane, and the descriptor's range check drops lanes 1..63 (no branch)
   const rsrc_t rtag_0 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (0 * 8 + w) * 8 + m, 0, 4, 0x00020000);
   const rsrc_t rtag_1 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (1 * 8 + w) * 8 + m, 0, 4, 0x00020000);
+  const rsrc_t rtag_2 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (2 * 8 + w) * 8 + m, 0, 4, 0x00020000);
   unsigned pub_dep = 0, pub_val = 0;
-  auto pub_flush = [&](int hf) {                       // hf: the half whose tag is pending
+  auto pub_flush = [&](int pt) {                       // pt: the part whose tag is pending
     unsigned tval = pub_val;
     asm volatile("; tag store ordered behind %1" : "+v"(tval) : "v"(pub_dep));
-    __builtin_amdgcn_raw_buffer_store_b32(tval, hf ? rtag_1 : rtag_0, lane * 4, 0, 16);   // sc1: write-through
+    __builtin_amdgcn_raw_buffer_store_b32(tval, pt == 0 ? rtag_0 : pt == 1 ? rtag_1 : rtag_2, lane * 4, 0, 16);   // sc1: write-through
   };
 
-  // ---- prologue: the first half-step's input groups 0..2 and its fp32 block
+  // ---- prologue: the first part's input groups 0 .. WG - 2 and its fp32 block
   const unsigned tt_first = rev ? p.nsteps - 1 : 0;
-  load_xgroup(ic<0>{}, 0, tt_first);
-  load_xgroup(ic<1>{}, 0, tt_first);
-  load_xgroup(ic<2>{}, 0, tt_first);
+  static_for<WG - 1>([&](auto g) { load_group(g, 0, tt_first, 0); });
   load_skip(0, tt_first);
   // drained once, with the builtin the compiler's wait-count bookkeeping sees: the step loop is then entered with nothing
   // in flight, and its header does not inherit a conservative vmcnt(0) from this path on every iteration
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt unconstrained
 
-  // one half-step of half HF at step `step`
-  auto half_step = [&](auto hfc, int step) {
-    constexpr int HF = decltype(hfc)::value;
+  // one part (32 sequences per wave) at step `step`
+  auto part_step = [&](auto ptc, int step) {
+    constexpr int PT = decltype(ptc)::value;
+    constexpr int PN = (PT + 1) % NP, PP = (PT + NP - 1) % NP;        // the part after / before this one
     const unsigned tt = rev ? p.nsteps - 1 - step : step;
-    // the half-step after this one: the other half, same step (HF = 0) or next step (HF = 1)
-    const int nstep = HF == 0 ? step : (step + 1 < p.nsteps ? step + 1 : step);
+    // the part after this one: same step, or the next step's part 0
+    const int nstep = PT + 1 < NP ? step : (step + 1 < p.nsteps ? step + 1 : step);
     const unsigned ttn = rev ? p.nsteps - 1 - nstep : nstep;
     // h_{step - 1} was published under parity (step - 1) & 1; step 0 reads the parity-1 records the host zeroed
     const int par = (step + 1) & 1;
@@ -203,54 +217,42 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     static_for<TPM>([&](auto r) { a[decltype(r)::value] = arec(decltype(r)::value, 0); });
     static_for<KT>([&](auto kc) {
       constexpr int K = decltype(kc)::value;
-      // ---- group boundaries: the group three ahead goes into the slots of the group just consumed
-      if constexpr (K >= 1 && K <= NB0 && (K - 1) % 4 == 0) {                  // input groups 0..3 start at K = 1, 5, 9, 13
-        constexpr int G = (K - 1) / 4;
-        if constexpr (G == 0) load_xgroup(ic<3>{}, HF, tt);
-        if constexpr (G == PUBG) {
+      // window position of this K-step's operand: input block K - 1, or NB0 + recurrent block; -1: ones / fp32 block
+      constexpr int POS = (K >= 1 && K <= NB0) ? K - 1 : (K >= NB0 + 2 ? K - 2 : -1);
+      if constexpr (POS >= 0 && POS % 4 == 0) {          // a window group starts: request the group WG - 1 ahead
+        constexpr int G = POS / 4, T = G + WG - 1;
+        if constexpr (G == 1) {
           if constexpr (!(ABL & 64)) {
-            if (HF == 1 || step > 0) pub_flush(HF ^ 1);
+            if (PT > 0 || step > 0) pub_flush(PP);
           }
         }
-        if constexpr (G == 1) {
+        if constexpr (G == GTAG) {
           if constexpr (!(ABL & 1)) {
-            if (step > 0) wait_tags(HF, (unsigned)step);
+            if (step > 0) wait_tags(PT, (unsigned)step);
           }
         }
-        if constexpr (G >= 1) load_hgroup(ic<G - 1>{}, HF, par);              // recurrent groups 0..2
-      }
-      if constexpr (K >= 2 + NB0 && (K - 2 - NB0) % 4 == 0) {                  // recurrent groups 0..3 start at K = 18, 22, ..
-        constexpr int G = (K - 2 - NB0) / 4;
-        if constexpr (G == 0) load_hgroup(ic<3>{}, HF, par);
-        if constexpr (G == 1) {
-          load_xgroup(ic<0>{}, HF ^ 1, ttn);
-          load_skip(HF ^ 1, ttn);                                             // (this half-step's block was used at K = 17)
-        }
-        if constexpr (G == 2) load_xgroup(ic<1>{}, HF ^ 1, ttn);
-        if constexpr (G == 3) load_xgroup(ic<2>{}, HF ^ 1, ttn);
+        if constexpr (T < GP)
+          load_group(ic<T>{}, PT, tt, par);
+        else
+          load_group(ic<T - GP>{}, PN, ttn, 0);           // (an input group of the next part)
+        if constexpr (G == GX) load_skip(PN, ttn);        // (this part's fp32 block was used at K = NB0 + 1)
       }
       // ---- B operand of this K-step
       v8bfw bop;
       if constexpr (K == 0)
         bop = ones;
-      else if constexpr (K <= NB0)
-        bop = win[(K - 1) & 15];
       else if constexpr (K == NB0 + 1)
         bop = join8(__builtin_convertvector(sk0, v4bfw), __builtin_convertvector(sk1, v4bfw));
       else
-        bop = win[(K - 2 - NB0) & 15];
+        bop = win[POS % WS];
       // ---- A operands one K-step ahead, 4 MFMAs.  The scheduling fences keep the four LDS reads of K-step K + 1 in
-      // front of the MFMAs of K-step K: left alone the scheduler sinks each read next to its use (one MFMA ahead),
-      // and every MFMA then waits out an LDS round trip (measured: 51 cycles per MFMA instead of 32)
+      // front of the MFMAs of K-step K (left alone the scheduler sinks each read next to its use, one MFMA ahead)
       v8bfw an[TPM];
       if constexpr (K + 1 < KT) static_for<TPM>([&](auto r) { an[decltype(r)::value] = arec(decltype(r)::value, K + 1); });
       __builtin_amdgcn_sched_barrier(0);
       static_for<TPM>([&](auto r) {
         constexpr int R = decltype(r)::value;
-        if constexpr (ABL & 4) {
-          if constexpr (K == 0) acc[R] = v16f{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[R][K % 16] += (float)a[R][0] + (float)bop[0];
-        } else if constexpr (K == 0) {
+        if constexpr (K == 0) {
           const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[R], bop, z, 0, 0, 0);
         } else {
@@ -261,8 +263,8 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       if constexpr (K + 1 < KT) static_for<TPM>([&](auto r) { a[decltype(r)::value] = an[decltype(r)::value]; });
     });
 
-    // the tags the NEXT half-step waits for: requested now, looked at five K-steps into it
-    load_tags(HF ^ 1);
+    // the tags the NEXT part waits for: requested now, looked at a few K-steps into it
+    load_tags(PN);
 
     // ---- gates of my 4 tiles (units 8 (4 m + r) + 4 hb + 0..3 of sequence n), output, operand records
     const unsigned oo = tt * sto;
@@ -272,24 +274,24 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       const v16f& ac = acc[R];
       v4f cn, hn;
       if constexpr (ABL & 2) {
-        cn = c[HF][R] * 0.5f + v4f{ac[0], ac[5], ac[10], ac[15]};
+        cn = c[PT][R] * 0.5f + v4f{ac[0], ac[5], ac[10], ac[15]};
         hn = cn * 0.5f + v4f{ac[1], ac[6], ac[11], ac[12]};
       } else {
         const v4f ig = sigmoid4(v4f{ac[0], ac[1], ac[2], ac[3]});
         const v4f fg = sigmoid4(v4f{ac[4], ac[5], ac[6], ac[7]});
         const v4f gg = tanh4(v4f{ac[8], ac[9], ac[10], ac[11]});
         const v4f og = sigmoid4(v4f{ac[12], ac[13], ac[14], ac[15]});
-        cn = cell4(fg, c[HF][R], ig, gg);
+        cn = cell4(fg, c[PT][R], ig, gg);
         hn = mul_rn4(og, tanh4(cn));
       }
-      c[HF][R] = cn;
+      c[PT][R] = cn;
       hq[R] = __builtin_convertvector(hn, v4bfw);
     });
     // Output row piece of this member: units 32 m .. 32 m + 31 (64 bytes per sequence).  Lane (n, hb) holds units
     // 8 r + 4 hb + 0..3 of tile r: four 8-byte pieces 16 bytes apart.  v_permlane32_swap trades halves between lanes
     // (n, 0) and (n, 1) so that lane (n, 0) ends up with tiles 0, 1 and lane (n, 1) with tiles 2, 3, 32 contiguous bytes
     // each: two 16-byte stores instead of four 8-byte ones (the stores' acknowledgements hold back every younger load
-    // of the wave — vector memory operations retire in order — and cost 2 us per step as four: profiles/r03/j_*)
+    // of the wave — vector memory operations retire in order: profiles/r03/j_*)
     if constexpr (!(ABL & 32)) {
       const v2u d0 = __builtin_bit_cast(v2u, hq[0]), d1 = __builtin_bit_cast(v2u, hq[1]);
       const v2u d2 = __builtin_bit_cast(v2u, hq[2]), d3 = __builtin_bit_cast(v2u, hq[3]);
@@ -300,45 +302,38 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       const auto s11 = __builtin_amdgcn_permlane32_swap(d1[1], d3[1], false, false);
       const v4u lo = {s00[0], s01[0], s00[1], s01[1]};   // hb 0: tile 0 units 0-3, 4-7; hb 1: tile 2
       const v4u hi = {s10[0], s11[0], s10[1], s11[1]};   // hb 0: tile 1;                hb 1: tile 3
-      if constexpr (ABL & 1024) {            // timing experiment: the same bytes to a compact area (wrong results)
-        __builtin_amdgcn_raw_buffer_store_b128(lo, rhx, vlane, hx_off(step & 1, HF, 2 * m), 0);
-        __builtin_amdgcn_raw_buffer_store_b128(hi, rhx, vlane, hx_off(step & 1, HF, 2 * m + 1), 0);
-      } else if (valid[HF]) {
-        constexpr int AUX = (ABL & 512) ? 2 : (ABL & 2048) ? 16 : 0;
-        __builtin_amdgcn_raw_buffer_store_b128(lo, HF ? ro_1 : ro_0, voo[HF], oo, AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(hi, HF ? ro_1 : ro_0, voo[HF], oo + 16, AUX);
+      if (valid[PT]) {
+        __builtin_amdgcn_raw_buffer_store_b128(lo, RO(PT), voo[PT], oo, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, RO(PT), voo[PT], oo + 16, 0);
       }
     }
     // tiles 4 m, 4 m + 1 -> block 2 m (bytes 0-7, 8-15 of the lane's 16); tiles 4 m + 2, 4 m + 3 -> block 2 m + 1
     const int wpar = step & 1;
     if constexpr (!(ABL & 64)) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[0], hq[1])), rhx, vlane, hx_off(wpar, HF, 2 * m), 16);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[2], hq[3])), rhx, vlane, hx_off(wpar, HF, 2 * m + 1), 16);
-    // publish, first half: a load issued behind the two stores.  Vector memory operations of a wave complete in order, so
-    // once its value has arrived the stores have been acknowledged; the tag store itself follows five K-steps into the
-    // next half-step (pub_flush), where waiting for that value no longer drains the wave's younger loads.
-    asm volatile("" ::: "memory");
-    pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
-    asm volatile("" ::: "memory");   // (keeps the load here: sunk next to its use it would make that wait a full drain)
-    pub_val = (unsigned)step + 1;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[0], hq[1])), rhx, vlane, hx_off(wpar, PT, 2 * m), 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[2], hq[3])), rhx, vlane, hx_off(wpar, PT, 2 * m + 1), 16);
+      // publish, first half: a load issued behind the two stores.  Vector memory operations of a wave complete in order,
+      // so once its value has arrived the stores have been acknowledged; the tag store itself follows five K-steps into
+      // the next part (pub_flush), where waiting for that value no longer drains the wave's younger loads.
+      asm volatile("" ::: "memory");
+      pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
+      asm volatile("" ::: "memory");   // (keeps the load here: sunk next to its use it would make that wait a full drain)
+      pub_val = (unsigned)step + 1;
     }
   };
 
-  for (int step = 0; step < p.nsteps; ++step) {
-    half_step(ic<0>{}, step);
-    half_step(ic<1>{}, step);
-  }
-  pub_flush(1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
+  for (int step = 0; step < p.nsteps; ++step) static_for<NP>([&](auto pt) { part_step(pt, step); });
+  pub_flush(NP - 1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
 int launch_bf16c_k(const LstmParams& p, const ClusterParams& cp, hipStream_t st) {
-  constexpr int KT = 1 + NB0 + NB2 + H / 16;
-  const size_t lds = (size_t)(H / 8 / kClusterMembers) * KT * 1024;
+  constexpr int KT = 1 + NB0 + NB2 + H / 16, CL = cluster_members(H);
+  const size_t lds = (size_t)(H / 8 / CL) * KT * 1024;
   auto k = lstm_bf16c_kernel<H, NB0, NB2, FLAGS, ABL>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int nwg = 64 * ((cp.ncl + 7) / 8);
+  const int nwg = 8 * CL * ((cp.ncl + 7) / 8);
   hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, st, p, cp);
   FNSSL_CHECK_LAUNCH("lstm_bf16c_kernel");
   return FNSSL_OK;

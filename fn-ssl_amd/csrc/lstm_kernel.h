@@ -44,11 +44,14 @@ struct LstmParams {
   int ablate;     // timing experiments only (env FNSSL_ABLATE): bit flags, see lstm_rec_kernel
 };
 
-// cluster-resident bf16 kernel (lstm_bf16c.h): geometry of its workspace area
-constexpr int kClusterSeqs = 512;                           // sequences per cluster: 2 halves x 8 waves x 32
-constexpr int kClusterMembers = 8;
-constexpr size_t kClusterHxBytes = 2 * 2 * 8 * 16 * 1024;   // [parity][half][sequence tile][block][1 KiB]
-constexpr int kClusterTagWords = 2 * 8 * 8;                 // [half][wave][member]
+// cluster-resident bf16 kernels (lstm_bf16c.h): geometry, shared by the kernels and the workspace sizing
+__host__ __device__ constexpr int cluster_members(int H) { return H == 256 ? 8 : 4; }        // CUs per cluster (4 gate-row tiles each)
+__host__ __device__ constexpr int cluster_parts(int H) { return H == 256 ? 2 : 3; }          // 32-sequence tiles per wave
+__host__ __device__ constexpr int cluster_seqs(int H) { return cluster_parts(H) * 256; }     // sequences per cluster: parts x 8 waves x 32
+__host__ __device__ constexpr size_t cluster_parity_bytes(int H) {                           // [part][sequence tile 8][block H/16][1 KiB]
+  return (size_t)cluster_parts(H) * 8 * (H / 16) * 1024;
+}
+constexpr int kClusterTagWords = 256;                       // per cluster: [part][wave 8][member 8] words, padded to 1 KiB
 
 // kernel MODE bits
 constexpr int kHas1 = 1;   // input segment 0 is src0 + src1

@@ -7,9 +7,13 @@ sys.path.insert(0, os.path.join(ROOT, "fn-ssl_amd")); sys.path.insert(0, os.path
 import torch
 from fnssl import ops, weights as W
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
-H, c0, c2 = 256, 256, 16
-sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0 + c2, H, False)], seed=1)
-w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0, c2, dev)]
+LAYER = os.environ.get("LAYER", "narrow")            # narrow: H = 256 over time; full: H = 128, both directions, over frequency
+H, c0, c2 = (256 if LAYER == "narrow" else 128), 256, 16
+BIDIR = LAYER == "full"
+sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0 + c2, H, BIDIR)], seed=1)
+w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0" + sfx], sd["L.weight_hh_l0" + sfx], sd["L.bias_ih_l0" + sfx], sd["L.bias_hh_l0" + sfx], c0, c2, dev)
+     for sfx in ([""] + (["_reverse"] if BIDIR else []))]
+ND = 2 if BIDIR else 1
 
 
 def run(x0, x2, cluster, reps=1):
@@ -18,16 +22,19 @@ def run(x0, x2, cluster, reps=1):
         os.environ.pop("FNSSL_NO_CLUSTER", None)
     else:
         os.environ["FNSSL_NO_CLUSTER"] = "1"
-    out = torch.full((nb, nf, nt, H), float("nan"), device=dev, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    if LAYER == "narrow":
+        out = torch.full((nb, nf, nt, H), float("nan"), device=dev, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    else:
+        out = torch.full((nb, nt, nf, ND * H), float("nan"), device=dev, dtype=torch.bfloat16)
     for _ in range(reps):
-        ops.lstm_layer("narrow", x0, None, x2, w, H, out, bf16=True, wide=True)
+        ops.lstm_layer(LAYER, x0, None, x2, w, H, out, bf16=True, wide=True)
     torch.cuda.synchronize()
     return out
 
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 if mode in ("all", "check"):
-    for nb, nt, nf in [(2, 6, 256), (5, 9, 256), (3, 40, 200), (16, 30, 256)]:
+    for nb, nt, nf in ([(2, 6, 256), (5, 9, 256), (3, 40, 200), (16, 30, 256)] if LAYER == "narrow" else [(3, 256, 7), (5, 300, 9), (4, 333, 12), (16, 300, 20)]):
         g = torch.Generator(device="cpu").manual_seed(nb * 100 + nt)
         x0 = (torch.randn((nb, nt, nf, c0), generator=g) * 0.5).to(dev).bfloat16()
         x2 = (torch.randn((nb, nt, nf, c2), generator=g) * 0.5).to(dev)
@@ -39,7 +46,7 @@ if mode in ("all", "check"):
               (nb, nt, nf, bool(torch.isfinite(a.float()).all()), d, torch.equal(a, b), torch.equal(a, a2)), flush=True)
 if mode in ("all", "time"):
     for nb in (64, 32):
-        nt, nf = 300, 256
+        nt, nf = 300, (256 if LAYER == "narrow" else 257)
         x0 = (torch.randn((nb, nt, nf, c0), device=dev) * 0.5).bfloat16()
         x2 = torch.randn((nb, nt, nf, c2), device=dev) * 0.5
         for cluster in (True, False):
@@ -47,9 +54,9 @@ if mode in ("all", "time"):
             t0 = time.perf_counter()
             run(x0, x2, cluster, 3)
             dt = (time.perf_counter() - t0) / 3
-            fl = 2.0 * 4 * H * (c0 + c2 + H) * nb * nf * nt
+            fl = 2.0 * 4 * H * (c0 + c2 + H) * nb * nf * nt * ND
             print("nb %d %s: %.3f ms  %.0f TFLOP/s (%.2f of 2.5 PF)  %.2f us/step" %
-                  (nb, "cluster" if cluster else "pair   ", dt * 1e3, fl / dt / 1e12, fl / dt / 2.5e15, dt / nt * 1e6), flush=True)
+                  (nb, "cluster" if cluster else "pair   ", dt * 1e3, fl / dt / 1e12, fl / dt / 2.5e15, dt / (nt if LAYER == "narrow" else nf) * 1e6), flush=True)
         a = run(x0, x2, True)
         b = run(x0, x2, False)
         print("nb %d equal %s" % (nb, torch.equal(a, b)), flush=True)

@@ -61,7 +61,7 @@ struct ClusterParams {
 
 // ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 8 no recurrent-operand loads,
 // 16 no input loads, 32 no output stores, 64 no publish (operand stores, tag)
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int WG_ = 0, int AD = 1>
 __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, const ClusterParams cp) {
   constexpr int CL = cluster_members(H), NP = cluster_parts(H);
   constexpr int NT = H / 8, TPM = NT / CL, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   // B-operand window: groups of 4 blocks; GX input + GH recurrent groups per part; WG groups of registers; the group
   // WG - 1 ahead is requested when a group starts, into the slots of the group consumed before it
   constexpr int GX = NB0 / 4, GH = NKH / 4, GP = GX + GH;
-  constexpr int WG = GP % 4 == 0 ? 4 : 3, WS = 4 * WG;
+  constexpr int WG = WG_ ? WG_ : (GP % 4 == 0 ? 4 : 3), WS = 4 * WG;   // AD: K-steps the A operands are read ahead
   static_assert(TPM == 4 && NB0 % 4 == 0 && NKH % 4 == 0 && NB2 == 1 && !F0 && F2 && !OUTF,
                 "built for IPDnet's shapes: [16 n bf16 channels | 16 fp32 channels] in, bf16 out");
   static_assert(GP % WG == 0 && WG - 1 <= GX && GX >= 2, "window groups must tile a part; the look-ahead stays inside the next part's input groups");
@@ -213,8 +213,9 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     const int par = (step + 1) & 1;
 
     v16f acc[TPM];
-    v8bfw a[TPM];
-    static_for<TPM>([&](auto r) { a[decltype(r)::value] = arec(decltype(r)::value, 0); });
+    v8bfw ar[AD + 1][TPM];                                            // A operands of K-steps K .. K + AD (rotating)
+    __builtin_amdgcn_s_setprio(2);   // the matrix phase outranks the SIMD partner's gate phase at issue (measured: 1-2 %)
+    static_for<AD>([&](auto d) { static_for<TPM>([&](auto r) { ar[decltype(d)::value][decltype(r)::value] = arec(decltype(r)::value, decltype(d)::value); }); });
     static_for<KT>([&](auto kc) {
       constexpr int K = decltype(kc)::value;
       // window position of this K-step's operand: input block K - 1, or NB0 + recurrent block; -1: ones / fp32 block
@@ -245,24 +246,23 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
         bop = join8(__builtin_convertvector(sk0, v4bfw), __builtin_convertvector(sk1, v4bfw));
       else
         bop = win[POS % WS];
-      // ---- A operands one K-step ahead, 4 MFMAs.  The scheduling fences keep the four LDS reads of K-step K + 1 in
+      // ---- A operands AD K-steps ahead, 4 MFMAs.  The scheduling fences keep the four LDS reads of K-step K + AD in
       // front of the MFMAs of K-step K (left alone the scheduler sinks each read next to its use, one MFMA ahead)
-      v8bfw an[TPM];
-      if constexpr (K + 1 < KT) static_for<TPM>([&](auto r) { an[decltype(r)::value] = arec(decltype(r)::value, K + 1); });
+      if constexpr (K + AD < KT) static_for<TPM>([&](auto r) { ar[(K + AD) % (AD + 1)][decltype(r)::value] = arec(decltype(r)::value, K + AD); });
       __builtin_amdgcn_sched_barrier(0);
       static_for<TPM>([&](auto r) {
         constexpr int R = decltype(r)::value;
         if constexpr (K == 0) {
           const v16f z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[R], bop, z, 0, 0, 0);
+          acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[K % (AD + 1)][R], bop, z, 0, 0, 0);
         } else {
-          acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[R], bop, acc[R], 0, 0, 0);
+          acc[R] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[K % (AD + 1)][R], bop, acc[R], 0, 0, 0);
         }
       });
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (K + 1 < KT) static_for<TPM>([&](auto r) { a[decltype(r)::value] = an[decltype(r)::value]; });
     });
 
+    __builtin_amdgcn_s_setprio(0);
     // the tags the NEXT part waits for: requested now, looked at a few K-steps into it
     load_tags(PN);
 
@@ -327,11 +327,11 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int WG_ = 0, int AD = 1>
 int launch_bf16c_k(const LstmParams& p, const ClusterParams& cp, hipStream_t st) {
   constexpr int KT = 1 + NB0 + NB2 + H / 16, CL = cluster_members(H);
   const size_t lds = (size_t)(H / 8 / CL) * KT * 1024;
-  auto k = lstm_bf16c_kernel<H, NB0, NB2, FLAGS, ABL>;
+  auto k = lstm_bf16c_kernel<H, NB0, NB2, FLAGS, ABL, WG_, AD>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = 8 * CL * ((cp.ncl + 7) / 8);
   hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, st, p, cp);

@@ -28,6 +28,8 @@ static int launch_one(const LstmParams& p, const ClusterParams& cp, hipStream_t 
     default: break;
   }
 #endif
+  // (kernel template knobs WG_ / AD — a two-group operand window, A operands read two K-steps ahead — were measured at
+  // config 3 and change nothing: profiles/r03/j_cluster_kernel_timing_and_ablations.txt; the defaults are built)
   return launch_bf16c_k<H, 16, 1, kW_F2>(p, cp, st);
 }
 

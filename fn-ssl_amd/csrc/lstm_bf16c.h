@@ -69,12 +69,15 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   // B-operand window: groups of 4 blocks; GX input + GH recurrent groups per part; WG groups of registers; the group
   // WG - 1 ahead is requested when a group starts, into the slots of the group consumed before it
   constexpr int GX = NB0 / 4, GH = NKH / 4, GP = GX + GH;
-  constexpr int WG = WG_ ? WG_ : (GP % 4 == 0 ? 4 : 3), WS = 4 * WG;   // AD: K-steps the A operands are read ahead
-  static_assert(TPM == 4 && NB0 % 4 == 0 && NKH % 4 == 0 && NB2 == 1 && !F0 && F2 && !OUTF,
+  // (GX = 0 — block 1's full-band layer, whose only input is the fp32 block: the window is the part's recurrent groups,
+  //  requested at the end of the PREVIOUS part's matrix phase, before its gate math)
+  constexpr int WG = GX == 0 ? GH : WG_ ? WG_ : (GP % 4 == 0 ? 4 : 3), WS = 4 * WG;   // AD: K-steps the A operands are read ahead
+  static_assert(TPM == 4 && NB0 % 4 == 0 && NKH % 4 == 0 && NB2 == 1 && !F0 && F2 && !OUTF,   // (block 1: the launcher passes the fp32 input as src2)
                 "built for IPDnet's shapes: [16 n bf16 channels | 16 fp32 channels] in, bf16 out");
-  static_assert(GP % WG == 0 && WG - 1 <= GX && GX >= 2, "window groups must tile a part; the look-ahead stays inside the next part's input groups");
+  static_assert(GP % WG == 0 && (GX == 0 || (WG - 1 <= GX && GX >= 2)), "window groups must tile a part; the look-ahead stays inside the next part's input groups");
   constexpr int GTAG = GX - (WG - 1);                   // group at whose start the first recurrent group is requested
-  static_assert(GTAG >= 1, "the tag store of the previous part (group 1) precedes the tag wait");
+  static_assert(GX == 0 || GTAG >= 1, "the tag store of the previous part (group 1) precedes the tag wait");
+  static_assert(GX > 0 || GH >= 2, "the tag store of the previous part sits at the second recurrent group");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- who am I: blocks of one cluster share blockIdx & 7 (observed: one XCD)
@@ -193,9 +196,12 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     __builtin_amdgcn_raw_buffer_store_b32(tval, pt == 0 ? rtag_0 : pt == 1 ? rtag_1 : rtag_2, lane * 4, 0, 16);   // sc1: write-through
   };
 
-  // ---- prologue: the first part's input groups 0 .. WG - 2 and its fp32 block
+  // ---- prologue: the first part's input groups 0 .. WG - 2 (GX = 0: its recurrent groups = the zeroed h_{-1}) and its fp32 block
   const unsigned tt_first = rev ? p.nsteps - 1 : 0;
-  static_for<WG - 1>([&](auto g) { load_group(g, 0, tt_first, 0); });
+  if constexpr (GX > 0)
+    static_for<WG - 1>([&](auto g) { load_group(g, 0, tt_first, 0); });
+  else
+    static_for<GH>([&](auto g) { load_group(g, 0, tt_first, 1); });
   load_skip(0, tt_first);
   // drained once, with the builtin the compiler's wait-count bookkeeping sees: the step loop is then entered with nothing
   // in flight, and its header does not inherit a conservative vmcnt(0) from this path on every iteration
@@ -220,7 +226,14 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       constexpr int K = decltype(kc)::value;
       // window position of this K-step's operand: input block K - 1, or NB0 + recurrent block; -1: ones / fp32 block
       constexpr int POS = (K >= 1 && K <= NB0) ? K - 1 : (K >= NB0 + 2 ? K - 2 : -1);
-      if constexpr (POS >= 0 && POS % 4 == 0) {          // a window group starts: request the group WG - 1 ahead
+      if constexpr (GX == 0) {
+        if constexpr (K == 0) load_tags(PN);             // looked at after this part's matrix phase
+        if constexpr (POS == 4) {
+          if constexpr (!(ABL & 64)) {
+            if (PT > 0 || step > 0) pub_flush(PP);
+          }
+        }
+      } else if constexpr (POS >= 0 && POS % 4 == 0) {   // a window group starts: request the group WG - 1 ahead
         constexpr int G = POS / 4, T = G + WG - 1;
         if constexpr (G == 1) {
           if constexpr (!(ABL & 64)) {
@@ -263,8 +276,19 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     });
 
     __builtin_amdgcn_s_setprio(0);
-    // the tags the NEXT part waits for: requested now, looked at a few K-steps into it
-    load_tags(PN);
+    if constexpr (GX > 0) {
+      // the tags the NEXT part waits for: requested now, looked at a few K-steps into it
+      load_tags(PN);
+    } else {
+      // the NEXT part's recurrent operands and fp32 block: requested now, they land under this part's gate math
+      if (PT + 1 < NP || step + 1 < p.nsteps) {
+        if constexpr (!(ABL & 1)) {
+          if (nstep > 0) wait_tags(PN, (unsigned)nstep);
+        }
+        static_for<GH>([&](auto g) { load_group(g, PN, ttn, (nstep + 1) & 1); });
+      }
+      load_skip(PN, ttn);
+    }
 
     // ---- gates of my 4 tiles (units 8 (4 m + r) + 4 hb + 0..3 of sequence n), output, operand records
     const unsigned oo = tt * sto;

@@ -9,6 +9,8 @@ namespace fnssl_lstm {
 // kernels of lstm_bf16p.h, which give the same bits — A/B, and the path of shapes / batches not covered here)
 bool bf16c_handles(const LstmParams& p, int H, int flags) {
   if (getenv("FNSSL_NO_CLUSTER")) return false;
+  if (H == 128 && p.c0 == 16 && p.c2 == 0 && flags == kW_F0)   // block 1's full-band layer: 16 fp32 feature channels
+    return p.nseq >= cluster_seqs(128) && !getenv("FNSSL_NO_CLUSTER_B1");
   if (p.c0 != 256 || p.c2 != 16 || flags != kW_F2) return false;
   if (H == 256) return p.nseq >= cluster_seqs(256);
   if (H == 128) return p.nseq >= cluster_seqs(128) && !getenv("FNSSL_NO_CLUSTER_H128");
@@ -17,6 +19,9 @@ bool bf16c_handles(const LstmParams& p, int H, int flags) {
 
 template <int H>
 static int launch_one(const LstmParams& p, const ClusterParams& cp, hipStream_t st) {
+  if constexpr (H == 128) {
+    if (p.c0 == 0) return launch_bf16c_k<128, 0, 1, kW_F2>(p, cp, st);   // block 1 (its input travels as the fp32 block)
+  }
 #ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
   switch (env_int("FNSSL_CLUSTER_ABL", 1, 127)) {
     case 1: return launch_bf16c_k<H, 16, 1, kW_F2, 1>(p, cp, st);
@@ -35,7 +40,11 @@ static int launch_one(const LstmParams& p, const ClusterParams& cp, hipStream_t 
 
 // Launches of at most CUs / members clusters (one workgroup per CU: every member of every cluster of a launch is resident).
 int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
-  (void)flags;
+  if (flags == kW_F0) {   // block 1's full-band layer: the kernel's one fp32 block is src2; same record layout in the stream
+    p.src2 = p.src0;
+    p.c2 = p.c0;
+    p.c0 = 0;
+  }
   const int ncu = fnssl::device_cus();
   const int per_launch = ncu / cluster_members(H);
   FNSSL_REQUIRE(per_launch >= 1, "lstm_forward: the cluster kernel needs at least %d CUs", cluster_members(H));

@@ -8,7 +8,10 @@ import torch
 from fnssl import ops, weights as W
 dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
 LAYER = os.environ.get("LAYER", "narrow")            # narrow: H = 256 over time; full: H = 128, both directions, over frequency
-H, c0, c2 = (256 if LAYER == "narrow" else 128), 256, 16
+B1 = LAYER == "full1"                                 # block 1's full-band layer: 16 fp32 feature channels only
+if B1:
+    LAYER = "full"
+H, c0, c2 = (256 if LAYER == "narrow" else 128), (16 if B1 else 256), (0 if B1 else 16)
 BIDIR = LAYER == "full"
 sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0 + c2, H, BIDIR)], seed=1)
 w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0" + sfx], sd["L.weight_hh_l0" + sfx], sd["L.bias_ih_l0" + sfx], sd["L.bias_hh_l0" + sfx], c0, c2, dev)
@@ -36,8 +39,9 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 if mode in ("all", "check"):
     for nb, nt, nf in ([(2, 6, 256), (5, 9, 256), (3, 40, 200), (16, 30, 256)] if LAYER == "narrow" else [(3, 256, 7), (5, 300, 9), (4, 333, 12), (16, 300, 20)]):
         g = torch.Generator(device="cpu").manual_seed(nb * 100 + nt)
-        x0 = (torch.randn((nb, nt, nf, c0), generator=g) * 0.5).to(dev).bfloat16()
-        x2 = (torch.randn((nb, nt, nf, c2), generator=g) * 0.5).to(dev)
+        x0 = (torch.randn((nb, nt, nf, c0), generator=g) * 0.5).to(dev)
+        x0 = x0 if B1 else x0.bfloat16()
+        x2 = None if B1 else (torch.randn((nb, nt, nf, c2), generator=g) * 0.5).to(dev)
         a = run(x0, x2, True)
         b = run(x0, x2, False)
         a2 = run(x0, x2, True)
@@ -47,8 +51,9 @@ if mode in ("all", "check"):
 if mode in ("all", "time"):
     for nb in (64, 32):
         nt, nf = 300, (256 if LAYER == "narrow" else 257)
-        x0 = (torch.randn((nb, nt, nf, c0), device=dev) * 0.5).bfloat16()
-        x2 = torch.randn((nb, nt, nf, c2), device=dev) * 0.5
+        x0 = torch.randn((nb, nt, nf, c0), device=dev) * 0.5
+        x0 = x0 if B1 else x0.bfloat16()
+        x2 = None if B1 else torch.randn((nb, nt, nf, c2), device=dev) * 0.5
         for cluster in (True, False):
             run(x0, x2, cluster, 2)
             t0 = time.perf_counter()

@@ -254,8 +254,8 @@ class IpdnetForward:
     def roofline(self, kern):
         if self.fp32:
             return kernel_roof(kern, "lstm_h256", "narrow-band LSTM H=256 (fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS)
-        r = kernel_roof(kern, "lstm_h256", "lstm_bf16 kernel H=256 (narrow-band LSTM, bf16 MFMA operands)",
-                        PEAK_BF16_MFMA_TFLOPS)
+        r = kernel_roof(kern, "lstm_h256", "lstm_bf16c_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands, weights resident "
+                        "in the LDS of an 8-CU cluster)", PEAK_BF16_MFMA_TFLOPS)
         if r is not None and not os.environ.get("FNSSL_IPDNET_ONE_STREAM"):
             r["note"] = ("the two half-batches run on two streams: in the timed region a launch shares the chip with the "
                          "other stream's kernels, so its duration there is not exclusive; `alone` = the same kernel in "

@@ -196,6 +196,10 @@ size_t fnssl_lstm_packed_floats(int c0, int c2, int hidden);
 int fnssl_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                     int c0, int c2, int hidden, float* packed);
 
+/* Scratch a call of fnssl_lstm_forward needs: cell state of a carried (streaming) call, the re-ordered weight stream of the
+ * two-slices-per-pass kernel (hidden 256) and — hidden 128 / 256 — the hand-off area of the cluster-resident bf16 kernels
+ * (status word, tags, two parities of h_t operand records: 0.5 / 0.4 MiB per 512 / 768 sequences).  One workspace per stream:
+ * two calls in flight must not share it. */
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir);
 
 /* Host-only query of the launch planner of fnssl_lstm_forward (full-chip fp32 launches, hidden 128 / 256): the rounds

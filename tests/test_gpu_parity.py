@@ -1024,6 +1024,7 @@ def test_lstm_bf16_wide_matches_oracle_and_narrow_kernel(dev, mode, H, bidir, c0
     (2, 7, 256),      # 512 sequences: exactly one cluster
     (3, 5, 200),      # 600 sequences: a second cluster with 88 live sequences (ragged tile, idle waves)
     (9, 4, 257),      # 2313 sequences: five clusters, q_inner not a multiple of 32
+    (65, 3, 256),     # 16640 sequences: 33 clusters = two launches (32 clusters fill the 256 CUs)
 ])
 def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch, nb, nt, nf):
     """lstm_bf16c.h (weights resident in the LDS of an 8-CU cluster, h_t exchanged through L2 with tagged hand-offs)

@@ -1,7 +1,7 @@
 // Cluster-resident bf16 LSTM kernel (lstm_bf16c.h): instantiation for IPDnet's narrow-band layer shape and its launcher.
 #include <cstdlib>
 
-#include "lstm_bf16d.h"
+#include "lstm_bf16c.h"
 
 namespace fnssl_lstm {
 
@@ -35,21 +35,10 @@ static int launch_one(const LstmParams& p, const ClusterParams& cp, hipStream_t 
 #endif
   // (kernel template knobs WG_ / AD — a two-group operand window, A operands read two K-steps ahead — were measured at
   // config 3 and change nothing: profiles/r03/j_cluster_kernel_timing_and_ablations.txt; the defaults are built)
-  if constexpr (H == 256) {   // 64 sequences per wave (lstm_bf16d.h): experiment switch for now
-    if (getenv("FNSSL_CLUSTER_V2")) {
-#ifdef FNSSL_BUILD_ABLATE
-      switch (env_int("FNSSL_CLUSTER_ABL", 1, 511)) {
-        case 256: return launch_bf16d_k<256, 16, 1, kW_F2, 256>(p, cp, st);
-        case 1: return launch_bf16d_k<256, 16, 1, kW_F2, 1>(p, cp, st);
-        case 2: return launch_bf16d_k<256, 16, 1, kW_F2, 2>(p, cp, st);
-        case 25: return launch_bf16d_k<256, 16, 1, kW_F2, 25>(p, cp, st);
-        case 32: return launch_bf16d_k<256, 16, 1, kW_F2, 32>(p, cp, st);
-        default: break;
-      }
-#endif
-      return launch_bf16d_k<256, 16, 1, kW_F2>(p, cp, st);
-    }
-  }
+  // (a 64-sequences-per-wave formulation — one wave per SIMD, two accumulator sets, the previous part's gate math issued
+  //  between the MFMAs — was built and measured: bit-identical, 8.3 ms against 5.7 for the narrow-band layer; the gate math
+  //  of 64 sequences needs every issue cycle the MFMAs leave free, and one wave per SIMD exposes every store
+  //  acknowledgement and tag wait: profiles/r03/l_cluster_64_sequences_per_wave_not_kept.txt, git history for the code)
   return launch_bf16c_k<H, 16, 1, kW_F2>(p, cp, st);
 }
 

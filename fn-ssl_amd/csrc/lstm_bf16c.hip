@@ -9,11 +9,17 @@ namespace fnssl_lstm {
 // kernels of lstm_bf16p.h, which give the same bits — A/B, and the path of shapes / batches not covered here)
 bool bf16c_handles(const LstmParams& p, int H, int flags) {
   if (getenv("FNSSL_NO_CLUSTER")) return false;
+  // Measured on MI355X (profiles/r03/j_*, "small batches"): the narrow-band kernel wins at every batch (12.5 against 19.7 us
+  // per step from 512 sequences up: no weight stream at all); the full-band kernels walk three parts per step (~18 us)
+  // where one round of pair-split workgroups takes ~10, so they take over when the pair-split launch would need more
+  // than one workgroup per CU (config 3: 600 workgroups, 33.6 against 23.9 us per step).
+  const long long pair_wgs = (long long)((p.nseq + 63) / 64) * p.ndir;
+  const bool past_one_round = pair_wgs > fnssl::device_cus();
   if (H == 128 && p.c0 == 16 && p.c2 == 0 && flags == kW_F0)   // block 1's full-band layer: 16 fp32 feature channels
-    return p.nseq >= cluster_seqs(128) && !getenv("FNSSL_NO_CLUSTER_B1");
+    return past_one_round && !getenv("FNSSL_NO_CLUSTER_B1");
   if (p.c0 != 256 || p.c2 != 16 || flags != kW_F2) return false;
-  if (H == 256) return p.nseq >= cluster_seqs(256);
-  if (H == 128) return p.nseq >= cluster_seqs(128) && !getenv("FNSSL_NO_CLUSTER_H128");
+  if (H == 256) return true;
+  if (H == 128) return past_one_round && !getenv("FNSSL_NO_CLUSTER_H128");
   return false;
 }
 

@@ -49,7 +49,7 @@ if mode in ("all", "check"):
         print("nb %d nt %d nf %d: finite %s  max|cluster - pair| %.3g  equal %s  repeat-equal %s" %
               (nb, nt, nf, bool(torch.isfinite(a.float()).all()), d, torch.equal(a, b), torch.equal(a, a2)), flush=True)
 if mode in ("all", "time"):
-    for nb in (64, 32):
+    for nb in [int(v) for v in os.environ.get("NBS", "64,32").split(",")]:
         nt, nf = 300, (256 if LAYER == "narrow" else 257)
         x0 = torch.randn((nb, nt, nf, c0), device=dev) * 0.5
         x0 = x0 if B1 else x0.bfloat16()

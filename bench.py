@@ -226,9 +226,11 @@ class IpdnetForward:
         self.frames_per_step = self.nb * self.nt
         self.dtype = "f32" if self.fp32 else "bf16"
         self.metric = "TF-frames/sec IPDnet DP-IPD forward, 8-mic 257-bin x 300-frame"
-        # the timed region runs the two half-batch streams (that is the product path and the `value`); the per-kernel
-        # breakdown and roofline.alone come from an instrumented pass on one stream, where a launch owns the chip
-        self.probe_env = {} if (self.fp32 or os.environ.get("FNSSL_IPDNET_ONE_STREAM")) else {"FNSSL_IPDNET_ONE_STREAM": "1"}
+        # one stream is the product path; with FNSSL_IPDNET_STREAMS >= 2 (opt-in) the timed region runs part-batches on
+        # several streams, and the per-kernel breakdown / roofline.alone come from an instrumented pass on one stream
+        self.multi_stream = (not self.fp32) and os.environ.get("FNSSL_IPDNET_STREAMS", "1") not in ("", "0", "1") \
+            and not os.environ.get("FNSSL_IPDNET_ONE_STREAM")
+        self.probe_env = {"FNSSL_IPDNET_ONE_STREAM": "1"} if self.multi_stream else {}
         log("rank %d/%d: IPDnet %d utt x %d mics x %d frames, %s" % (rank, world, self.nb, self.mics, self.nt, self.dtype))
 
     def step(self):
@@ -256,9 +258,9 @@ class IpdnetForward:
             return kernel_roof(kern, "lstm_h256", "narrow-band LSTM H=256 (fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS)
         r = kernel_roof(kern, "lstm_h256", "lstm_bf16c_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands, weights resident "
                         "in the LDS of an 8-CU cluster)", PEAK_BF16_MFMA_TFLOPS)
-        if r is not None and not os.environ.get("FNSSL_IPDNET_ONE_STREAM"):
-            r["note"] = ("the two half-batches run on two streams: in the timed region a launch shares the chip with the "
-                         "other stream's kernels, so its duration there is not exclusive; `alone` = the same kernel in "
+        if r is not None and self.multi_stream:
+            r["note"] = ("part-batches run on several streams: in the timed region a launch shares the chip with the "
+                         "other streams' kernels, so its duration there is not exclusive; `alone` = the same kernel in "
                          "the one-stream instrumented pass")
         return r
 

@@ -284,9 +284,16 @@ class IPDnet(nn.Module):
         self._side = None                                           # streams of the two half-batches (bf16 wide path)
 
     def _two_streams(self, nb):
-        """Two half-batches on two streams: the wide bf16 path at a batch whose launches leave partial rounds
-        (``FNSSL_IPDNET_ONE_STREAM=1`` keeps a single stream)."""
-        return (_is_bf16(self) and self.block_1._wide() and nb >= 8 and not os.environ.get("FNSSL_IPDNET_ONE_STREAM"))
+        """Opt-in (``FNSSL_IPDNET_STREAMS=2``): half-batches on separate streams.  It was the default while the pair-split
+        LSTM kernels left partial rounds (600 full-band workgroups on 256 CUs); with the cluster-resident kernels every
+        launch fills the chip by itself and one stream is both faster (24.9-25.0 against 25.3-25.4 ms at config 3) and
+        deterministic in its timing."""
+        try:
+            ns = int(os.environ.get("FNSSL_IPDNET_STREAMS", "1"))
+        except ValueError:
+            ns = 1
+        return (_is_bf16(self) and self.block_1._wide() and nb >= 8 and ns >= 2
+                and not os.environ.get("FNSSL_IPDNET_ONE_STREAM"))
 
     @ops.on_device
     def forward(self, x, offline_inference=False):
@@ -317,10 +324,8 @@ class IPDnet(nn.Module):
             return self.conv.run(y.permute(0, 2, 1, 3), xc.permute(0, 2, 1, 3))   # [nb, nf, nt2, ceil4(Cout)]
 
         if self._two_streams(nb):
-            # Utterances are independent, and the layers' launches do not divide the chip evenly (config 3: 600
-            # full-band workgroups on 256 CUs = 2.34 rounds run as 3; 256 narrow-band workgroups = exactly one): the two
-            # halves of the batch go down two streams, so one half's partial round shares the chip with the other
-            # half's kernels instead of leaving CUs idle.  Same kernels, same results (batch slices).
+            # Utterances are independent: parts of the batch go down separate streams, so that one part's partial round
+            # can share the chip with the other part's kernels.  Same kernels, same results (batch slices).
             cur = torch.cuda.current_stream()
             ns = max(2, min(int(os.environ.get("FNSSL_IPDNET_STREAMS", "2")), nb))
             if self._side is None or len(self._side) != ns or self._side[0].device != x.device:

@@ -789,7 +789,7 @@ def test_ipdnet_bf16_two_stream_branch_vs_oracle_and_one_stream(dev, monkeypatch
     from oracle import fnssl_oracle as O
     M = _ipdnet_module()
     monkeypatch.delenv("FNSSL_IPDNET_ONE_STREAM", raising=False)
-    monkeypatch.delenv("FNSSL_IPDNET_STREAMS", raising=False)
+    monkeypatch.setenv("FNSSL_IPDNET_STREAMS", "2")          # (opt-in since the cluster kernels: one stream is the default)
     sd = W.make_ipdnet_state(4500, 16, 256, 2, True)
     net = M.IPDnet(input_size=16, hidden_size=256, max_track=2, is_online=True).eval()
     net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})

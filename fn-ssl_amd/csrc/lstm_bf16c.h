@@ -57,6 +57,7 @@ struct ClusterParams {
   int cl0;                  // first cluster of this launch (global index over directions)
   int ncl;                  // clusters in this launch
   int cl_per_dir;
+  int spread;               // test knob (FNSSL_CLUSTER_SPREAD=1): members of a cluster = CONSECUTIVE blocks, i.e. different XCDs
 };
 
 // ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 8 no recurrent-operand loads,
@@ -82,8 +83,8 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
 
   // ---- who am I: blocks of one cluster share blockIdx & 7 (observed: one XCD)
   const int b = blockIdx.x;
-  const int m = (b >> 3) % CL;
-  const int cl_local = ((b >> 3) / CL) * 8 + (b & 7);
+  const int m = cp.spread ? b % CL : (b >> 3) % CL;
+  const int cl_local = cp.spread ? b / CL : ((b >> 3) / CL) * 8 + (b & 7);
   if (cl_local >= cp.ncl) return;
   const int cg = cp.cl0 + cl_local;
   const int dir = cg / cp.cl_per_dir;

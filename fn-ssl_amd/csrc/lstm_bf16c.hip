@@ -68,6 +68,8 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   FNSSL_REQUIRE((size_t)ncl * 2 * cluster_parity_bytes(H) < 0xf0000000ull, "lstm_forward: too many sequences for one call of the cluster kernel");
   cp.parity_stride = (unsigned)((size_t)ncl * cluster_parity_bytes(H));
   cp.cl_per_dir = cl_per_dir;
+  // placement is a speed matter only; the knob puts the members of a cluster on DIFFERENT XCDs so that tests can show it
+  cp.spread = getenv("FNSSL_CLUSTER_SPREAD") ? 1 : 0;
   // status word + tags, and the parity-1 operand records (step 0 reads h_{-1} = 0 from them)
   FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, head, st));
   FNSSL_HIP(hipMemsetAsync(cp.hx + cp.parity_stride, 0, cp.parity_stride, st));

@@ -1047,7 +1047,12 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
         return out
 
     monkeypatch.delenv("FNSSL_NO_CLUSTER", raising=False)
+    monkeypatch.delenv("FNSSL_CLUSTER_SPREAD", raising=False)
     a, a2 = run(), run()
+    monkeypatch.setenv("FNSSL_CLUSTER_SPREAD", "1")        # members of a cluster on different XCDs: placement must not matter
+    s1, s2 = run(), run()
+    monkeypatch.delenv("FNSSL_CLUSTER_SPREAD")
+    assert torch.equal(a, s1) and torch.equal(a, s2), "the hand-off depends on which XCD a member runs on"
     monkeypatch.setenv("FNSSL_NO_CLUSTER", "1")
     b = run()
     got = a.float().cpu().numpy()

@@ -197,6 +197,18 @@ __global__ void __launch_bounds__(256) pair_stream_kernel(const float4* __restri
 }
 }  // namespace
 
+int fnssl_lstm_cluster_status(const void* workspace, size_t workspace_bytes, int nseq, int hidden, int ndir, void* stream,
+                              unsigned* status) {
+  FNSSL_REQUIRE(workspace && status && nseq > 0 && ndir > 0, "lstm_cluster_status: null pointer / empty problem");
+  FNSSL_REQUIRE(workspace_bytes >= fnssl_lstm_workspace_bytes(nseq, hidden, ndir) && cluster_bytes(nseq, hidden, ndir) > 0,
+                "lstm_cluster_status: not a workspace of a cluster-kernel shape (hidden %d)", hidden);
+  const char* word = reinterpret_cast<const char*>(workspace) + cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir);
+  hipStream_t st = fnssl::as_stream(stream);
+  FNSSL_HIP(hipMemcpyAsync(status, word, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  FNSSL_HIP(hipStreamSynchronize(st));
+  return FNSSL_OK;
+}
+
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   FNSSL_REQUIRE(d, "lstm_forward: null descriptor");
   const int H = d->hidden;

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 CH_MODE = {"M": 0, "MM": 1}
 
 # every symbol include/fnssl.h declares
@@ -27,7 +27,7 @@ SYMBOLS = [
     "fnssl_abi_version", "fnssl_last_error", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
     "fnssl_num_frames_ex", "fnssl_stft_ex", "fnssl_array_frontend",
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
-    "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_plan_rounds", "fnssl_lstm_forward", "fnssl_head", "fnssl_linear",
+    "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_plan_rounds", "fnssl_lstm_forward", "fnssl_lstm_cluster_status", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features", "fnssl_conv3x3_packed_floats_bf16", "fnssl_conv3x3_pack_bf16",
     "fnssl_conv3x3_causal_bf16", "fnssl_conv3x3_causal_bf16a",
@@ -194,6 +194,7 @@ def load():
     lib.fnssl_lstm_bwd_workspace_bytes.restype = sz
     lib.fnssl_lstm_backward.argtypes = [C.POINTER(LstmBwdDesc), vp]
     lib.fnssl_lstm_plan_rounds.argtypes = [i, i, i, i, vp, i]
+    lib.fnssl_lstm_cluster_status.argtypes = [vp, sz, i, i, i, vp, vp]
     lib.fnssl_lstm_weight_grads_workspace_bytes.argtypes = [ll, i, i, i, i]
     lib.fnssl_lstm_weight_grads_workspace_bytes.restype = sz
     lib.fnssl_lstm_weight_grads.argtypes = [C.POINTER(WgradDesc), vp]

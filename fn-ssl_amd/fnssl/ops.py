@@ -432,6 +432,18 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     return out
 
 
+def lstm_cluster_status(nseq: int, hidden: int, ndir: int, device=None) -> int:
+    """Status word the cluster-resident bf16 LSTM kernels leave in the current stream's LSTM workspace (0 = every hand-off
+    arrived; see fnssl_lstm_cluster_status).  `nseq, hidden, ndir` as in the lstm_layer call that used the workspace."""
+    lib = _lib.load()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _workspace(lib.fnssl_lstm_workspace_bytes(nseq, hidden, ndir), device, "lstm")
+    out = C.c_uint(0xffffffff)
+    check(lib.fnssl_lstm_cluster_status(ws.data_ptr(), ws.numel(), nseq, hidden, ndir, _stream(), C.byref(out)),
+          "lstm_cluster_status")
+    return int(out.value)
+
+
 def lstm_state_workspace(nseq: int, hidden: int, device):
     """Persistent per-layer cell-state buffer for streaming (uni-directional) LSTM calls."""
     n = _lib.load().fnssl_lstm_workspace_bytes(nseq, hidden, 1)

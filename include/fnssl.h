@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 14
+#define FNSSL_ABI_VERSION 15
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -208,6 +208,12 @@ size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir);
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap);
 
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
+
+/* Status word of the cluster-resident bf16 kernels in a workspace that fnssl_lstm_forward has used with the same
+ * (nseq, hidden, ndir): 0 = fine; 0x1nnnn = a wave of cluster nnnn waited ~2 s for a hand-off tag that never came (the
+ * kernel traps after recording it, so the launch itself has already failed loudly).  Synchronises with `stream`. */
+int fnssl_lstm_cluster_status(const void* workspace, size_t workspace_bytes, int nseq, int hidden, int ndir, void* stream,
+                              unsigned* status);
 
 /* ---- training (next row 8f-1): back-propagation through time ---------------------------------- */
 

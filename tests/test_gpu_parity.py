@@ -1053,6 +1053,8 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
     s1, s2 = run(), run()
     monkeypatch.delenv("FNSSL_CLUSTER_SPREAD")
     assert torch.equal(a, s1) and torch.equal(a, s2), "the hand-off depends on which XCD a member runs on"
+    with torch.cuda.device(dev):
+        assert ops.lstm_cluster_status(nb * nf, H, 1, dev) == 0        # no bounded wait ran out
     monkeypatch.setenv("FNSSL_NO_CLUSTER", "1")
     b = run()
     got = a.float().cpu().numpy()

@@ -19,6 +19,7 @@ ones = [net(x) for _ in range(3)]
 torch.cuda.synchronize()
 print("one-stream runs equal:", [bool(torch.equal(ones[0], o)) for o in ones])
 del os.environ["FNSSL_IPDNET_ONE_STREAM"]
+os.environ.setdefault("FNSSL_IPDNET_STREAMS", "2")      # part-batches on separate streams are opt-in since the cluster kernels
 outs = [net(x) for _ in range(8)]
 torch.cuda.synchronize()
 for i, o in enumerate(outs):

@@ -333,3 +333,19 @@ def test_launch_planner_picks_the_cheapest_rounds():
         for hidden, ndir in ((128, 2), (256, 1)):
             assert sum(rounds(hidden, nseq, ndir)) * 256 >= ((nseq + 15) // 16) * ndir
     assert lib.fnssl_lstm_plan_rounds(64, 100, 1, 256, (C.c_int * 4)(), 4) < 0
+
+
+def test_lstm_workspace_covers_the_cluster_hand_off_area():
+    """fnssl_lstm_workspace_bytes (host logic): hidden 128 / 256 workspaces hold the hand-off area of the cluster-resident
+    bf16 kernels — a status word, 1 KiB of tags and two parities of operand records per cluster of 512 (H = 256:
+    2 x 2 parts x 8 tiles x 16 KiB) or 768 (H = 128: 2 x 3 x 8 x 8 KiB) sequences per direction; other hidden sizes none."""
+    lib = _lib.load()
+    ws = lib.fnssl_lstm_workspace_bytes
+    per256, per128 = 1024 + 2 * 2 * 8 * 16 * 1024, 1024 + 2 * 3 * 8 * 8 * 1024
+    assert ws(16384, 256, 1) - ws(16384 - 512, 256, 1) >= per256            # one cluster more
+    assert ws(16384, 256, 1) >= 32 * per256
+    assert ws(19200, 128, 2) >= 50 * per128                                  # config 3's full-band layers: 25 clusters x 2
+    assert ws(768, 128, 1) - ws(767, 128, 1) < per128                        # 767 and 768 sequences: one cluster each
+    assert ws(769, 128, 1) - ws(768, 128, 1) >= per128
+    assert ws(16384, 64, 1) < 16384 // 16 * 2 * 4 * 1024                     # H = 64: cell state only
+    assert ws(0, 256, 1) == 0

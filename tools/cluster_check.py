@@ -54,14 +54,23 @@ if mode in ("all", "time"):
         x0 = torch.randn((nb, nt, nf, c0), device=dev) * 0.5
         x0 = x0 if B1 else x0.bfloat16()
         x2 = None if B1 else torch.randn((nb, nt, nf, c2), device=dev) * 0.5
-        for cluster in (True, False):
+        for cluster in ((True, False) if not os.environ.get("AB") else (True, "ab", True, "ab")):
+            if os.environ.get("AB"):
+                if cluster == "ab":
+                    os.environ[os.environ["AB"]] = "1"
+                else:
+                    os.environ.pop(os.environ["AB"], None)
+                label = "B (%s=1)" % os.environ["AB"] if cluster == "ab" else "A"
+                cluster = True
+            else:
+                label = "cluster" if cluster else "pair   "
             run(x0, x2, cluster, 2)
             t0 = time.perf_counter()
             run(x0, x2, cluster, 3)
             dt = (time.perf_counter() - t0) / 3
             fl = 2.0 * 4 * H * (c0 + c2 + H) * nb * nf * nt * ND
             print("nb %d %s: %.3f ms  %.0f TFLOP/s (%.2f of 2.5 PF)  %.2f us/step" %
-                  (nb, "cluster" if cluster else "pair   ", dt * 1e3, fl / dt / 1e12, fl / dt / 2.5e15, dt / (nt if LAYER == "narrow" else nf) * 1e6), flush=True)
+                  (nb, label, dt * 1e3, fl / dt / 1e12, fl / dt / 2.5e15, dt / (nt if LAYER == "narrow" else nf) * 1e6), flush=True)
         a = run(x0, x2, True)
         b = run(x0, x2, False)
         print("nb %d equal %s" % (nb, torch.equal(a, b)), flush=True)

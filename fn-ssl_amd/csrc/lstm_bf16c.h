@@ -1,39 +1,42 @@
-// Cluster-resident bf16 LSTM recurrence (BASELINE config 3, IPDnet's narrow-band layers): the gate rows of ONE layer are
-// split over a cluster of 8 workgroups (8 CUs); every member keeps its 1/8 of the weight matrix in LDS for the whole
-// launch and the cluster exchanges h_t through L2 once per step.
+// Cluster-resident bf16 LSTM recurrence (BASELINE config 3: IPDnet's narrow-band and full-band layers): the gate rows of
+// ONE layer are split over a cluster of 8 (H = 256) or 4 (H = 128) workgroups = CUs; every member keeps its slice of the
+// weight matrix in LDS for the whole launch and the cluster exchanges h_t through L2 once per step.
 //
-// Why (profiles/r02/f_ablate_bf16p.txt, profiles/r03/h_*): lstm_bf16p_kernel runs 64 sequences per CU against ALL gate
-// rows, so every CU pulls the whole 1.06 MB matrix from L2 once per step (84 GB per launch at config 3); two launches
-// on two streams take twice as long each as one alone — the L2 delivers ~11 TB/s to that pattern and that is the wall.
-// Here a member owns 4 of the 32 gate-row tiles (136 records = 136 KiB of LDS, loaded once) and the cluster runs 512
-// sequences against them: the per-step traffic of a CU is the B operands [x_t | h_{t-1}] of its 512 sequences
-// (~0.57 MB from L2, of which x is shared by the 8 members) and no weight byte leaves the LDS again.
+// Why (profiles/r02/f_ablate_bf16p.txt, profiles/r03/h_*, j_*): lstm_bf16p_kernel runs 64 sequences per CU against ALL
+// gate rows, so every CU pulls the whole matrix (1.06 MB at H = 256) from L2 once per step — 88 GB per launch at config 3,
+// and the L2 hands that pattern ~11 TB/s.  Here a member owns 4 of the gate-row tiles (136 / 104 / 40 KiB of LDS, loaded
+// once) and the cluster runs 512 / 768 sequences against them: the per-step traffic of a CU is the B operands
+// [x_t | h_{t-1}] of those sequences (0.57 MB at H = 256, of which x is shared by the members: 43 GB per launch) and no
+// weight byte leaves the LDS again.
 //
-// Work split inside a member: 8 waves (two per SIMD, so that one wave's gate math runs under its partner's MFMAs
-// without a hand-made software pipeline).  Wave w owns two 32-sequence tiles — tile w of each HALF of the cluster's
-// batch — and alternates between them: while the h_t of one half travels to the other members, the wave works on the
-// other half (a hand-off is ~2-3 us on a loaded chip; half a step is ~4 us).
+// Work split inside a member: 8 waves, two per SIMD.  Wave w owns one 32-sequence tile — tile w — of each of the
+// cluster's NP "parts" and cycles through them: while the h_t of one part travels to the other members, the wave works on
+// the next part (a hand-off is ~2-3 us on a loaded chip; a part takes ~8 us).  Measured (k_pmc_sq_*): the two waves of a
+// SIMD mostly take turns — MFMAs 55 % of the cycles, gate math most of the rest, both at once 9 %.
 //
 // Hand-off protocol (MI355X_MICROARCH.md, "inter-workgroup visibility"; nothing here depends on which XCD a member
-// runs on — members of a cluster are PLACED on one XCD via blockIdx & 7 only because a same-XCD reader is faster):
+// runs on — members of a cluster are PLACED on one XCD via blockIdx & 7 only because a same-XCD reader is faster;
+// FNSSL_CLUSTER_SPREAD=1 places them on different XCDs: same bits, 14 % slower):
 //   * producer wave: its two 1-KiB operand records (blocks 2m, 2m + 1 of its sequence tile: exactly the units this
-//     member computes) are stored write-through (16-byte sc1 stores); the TAG word of (half, wave, member) is stored
-//     (relaxed, agent scope = sc1) only after a load issued BEHIND those stores has returned: vector memory operations
-//     of a wave complete in order on gfx9, so the stores have been acknowledged by then — without draining the wave's
-//     prefetch window the way s_waitcnt vmcnt(0) would;
-//   * consumer wave: loads the 8 tags of its (half, wave) a few K-steps before it needs them (relaxed agent loads),
-//     and only after all 8 show the step it waits for does it issue the sc1 loads of the operand records (sc1 loads
-//     bypass the CU's L1, which other CUs' stores never refresh).  Tags are monotonic (step + 1) and zeroed by the
-//     host before every launch; the records are double-buffered by step parity: a member can be at most one step ahead
-//     of the slowest one, because step t + 1 needs every member's h_t.
-//   * every wait is bounded: a tag that does not arrive within ~2 s records a code in the launch's status word and
-//     traps (the launch fails loudly instead of hanging the device).  All 8 members are resident at once by
-//     construction: a launch has at most one workgroup per CU (136 KiB of LDS each, <= 256 workgroups).
+//     member computes) are stored write-through (16-byte sc1 stores); the TAG word of (part, wave, member) is stored
+//     (sc1) only after a load issued BEHIND those stores has returned: vector memory operations of a wave complete in
+//     order on gfx9, so the stores have been acknowledged by then — without draining the wave's prefetch window the way
+//     s_waitcnt vmcnt(0) would;
+//   * consumer wave: loads the tags of its (part, wave) at the end of the previous part (relaxed agent loads), looks at
+//     them a few K-steps later, and only after all members show the step it waits for does it issue the sc1 loads of
+//     the operand records (sc1 loads bypass the CU's L1, which other CUs' stores never refresh).  Tags are monotonic
+//     (step + 1) and zeroed by the host before every call; the records are double-buffered by step parity: a member can be
+//     at most one step ahead of the slowest one, because step t + 1 needs every member's h_t; the parity-1 records are
+//     zeroed by the host, so step 0 reads h_{-1} = 0 like any other step;
+//   * every wait is bounded: a tag that does not arrive within ~2 s records a code in the call's status word
+//     (fnssl_lstm_cluster_status) and traps — the launch fails loudly instead of hanging the device.  All members of a
+//     cluster are resident at once by construction: a launch has at most one workgroup per CU (its LDS) and at most
+//     CUs / members clusters.
 //
 // Arithmetic: per 32-row tile the MFMA chain is the one of lstm_bf16p_kernel — ones block (bias), input blocks, recurrent
 // blocks, in that order, into one fp32 accumulator — and the gate math is the same code, so the results are
 // bit-identical to the pair-split kernels'.  The weight stream is fnssl_lstm_pack_bf16w's, unchanged: tile-major, so
-// a member's slice is one contiguous 136 KiB chunk.
+// a member's slice is one contiguous chunk.
 #pragma once
 
 #include "lstm_bf16w.h"

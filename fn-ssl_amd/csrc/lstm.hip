@@ -39,6 +39,8 @@ extern template int launch_split_h<128>(int, const LstmParams&, int, int, hipStr
 extern template int launch_split_h<256>(int, const LstmParams&, int, int, hipStream_t);
 int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train.hip
 int forward_bf16(LstmParams p, int H, hipStream_t st);             // lstm_bf16.hip
+bool f32c_handles(const LstmParams& p, int H, int mode);           // lstm_f32c.hip
+int forward_f32c(LstmParams p, int mode, hipStream_t st);
 }  // namespace fnssl_lstm
 
 // ---- launch planner (host) -------------------------------------------------------------------------------------
@@ -327,6 +329,12 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     p.task1 = tasks;
     p.wgs_per_dir = 0;
     return forward_save(p, H, mode, st);
+  }
+
+  // H = 128 full-band layers at full-chip size: hidden slices over clusters of 8 CUs, groups as work items (lstm_f32c.h)
+  if (d->variant == 0 && !(mode & kHas1) && f32c_handles(p, H, mode)) {
+    FNSSL_REQUIRE(d->workspace_bytes >= need, "lstm_forward: workspace");
+    return forward_f32c(p, mode, st);
   }
 
   // one launch of `nw` waves per workgroup over the 16-sequence groups [t0, t1) of every direction

@@ -1,0 +1,305 @@
+// Cluster-resident fp32 LSTM recurrence for the H = 128 full-band layers of FN-SSL (BASELINE config 2, the headline).
+//
+// Why: lstm_static_kernel gives every WAVE a 16-sequence group for the whole recurrence, so a launch is paced by its
+// fullest SIMD: config 2's full-band layers are 7200 groups on 1024 SIMDs = 7.03 per SIMD, run as rounds of 15 + 14 waves
+// per CU = 8 wave-times (pigeonhole: 0.879 of the roof before any other loss; measured 0.78).  Here the hidden SLICES of
+// the layer are split over a cluster of 8 CUs — member m keeps slice m of the packed weight stream (25 quads = 100 KiB,
+// or 10 quads for block 1) in LDS for the whole launch — and the 16-sequence groups become work items that the member's
+// 12 waves take in turn: 225 groups per cluster = 18.75 per wave, run as 19 = 0.987 of the roof.  Every member computes
+// its 16 hidden units for ALL groups of the cluster; h_t travels between the members through the OUTPUT tensor itself
+// (the row of step t is written once and read at step t + 1 by everybody, exactly where lstm_static_kernel re-reads its
+// own h): write-through (sc1) stores, sc1 loads, and one tag word per (group, member) = step + 1.  A hand-off has a
+// whole step (19 group-steps, ~0.3 ms) to arrive.  Waits are bounded (status word + trap), as in lstm_bf16c.h.
+//
+// Arithmetic: per group and slice the MFMA chain is lstm_static_kernel's — accumulators start from the bias quad, input
+// quads, recurrent quads, k-ordered — and the gate math is the same code: results are bit-identical.
+#pragma once
+
+#include "lstm_static.h"
+
+namespace fnssl_lstm {
+
+constexpr int kF32cWaves = 12;
+constexpr unsigned kF32cSpinLimit = 1u << 20;
+
+struct F32ClusterParams {
+  unsigned* tags;       // [direction][cluster][group in cluster][member 8], zeroed before the launch
+  unsigned* status;
+  int clusters_per_dir;
+  int groups_per_cluster;
+};
+
+// NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad (block 1); MODE: 0 or kSum
+template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2>
+__global__ void __launch_bounds__(kF32cWaves * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
+  constexpr int H = 128, NS = H / 16, NW = kF32cWaves;
+  constexpr bool SUM = (MODE & kSum) != 0;
+  constexpr int QPS = 1 + NV0 + NS0 + NS;
+  // DRIFT: a wave starts the recurrent part of its k-th group of a step only when EVERY member has finished its
+  // (k - DRIFT)-th: the eight members then read a group's input rows within a few group-times of each other and the seven
+  // later ones find them in the XCD's L2 (4 MB for four clusters) instead of fetching them again from memory
+  constexpr int XD = 8;   // input ring: block v is requested XD - 1 quads (~3.6 k cycles) before its use — the other members have pushed it out of L2
+  static_assert(!(NV0 && NS0) && (NV0 == 0 || NV0 % XD == 0), "block-only or remainder-only input");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int b = blockIdx.x;
+  const int m = (b >> 3) & 7;                                 // member = hidden slice
+  const int cl = ((b >> 6) << 3) + (b & 7);                   // cluster (members share blockIdx & 7: one XCD, for speed only)
+  if (cl >= cp.clusters_per_dir * p.ndir) return;
+  const int dir = cl / cp.clusters_per_dir;
+  const int ck = cl - dir * cp.clusters_per_dir;
+  const int g0 = ck * cp.groups_per_cluster;
+  const int g1 = g0 + cp.groups_per_cluster < p.ntasks ? g0 + cp.groups_per_cluster : p.ntasks;
+
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool rev = dir == 1;
+  const unsigned vlane = lane * 16;
+
+  {   // my slice of the weight stream -> LDS, once
+    const v4f* src = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(p.wpack[dir]) + (size_t)(m * QPS) * 4096);
+    v4f* dst = reinterpret_cast<v4f*>(smem);
+    for (int i = threadIdx.x; i < QPS * 4 * 64; i += NW * 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const char* const lds_rd = smem + lane * 16;
+  auto rec = [&](int q, int j) { return *reinterpret_cast<const v4f*>(lds_rd + (q * 4 + j) * 1024); };
+
+  const unsigned st0 = (unsigned)(p.src0.st * 4), sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
+  const rsrc_t rw = make_rsrc(p.wpack[dir]);
+  unsigned* const tag_cl = cp.tags + (size_t)cl * cp.groups_per_cluster * 8;
+  const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // deferred tag store of the previous group-step (the load behind its stores has returned = they are acknowledged)
+  unsigned pub_dep = 0, pub_val = 0;
+  unsigned* pub_tag = nullptr;
+  auto pub_flush = [&]() {
+    if (pub_tag) {
+      unsigned tval = pub_val;
+      asm volatile("; tag store ordered behind %1" : "+v"(tval) : "v"(pub_dep));
+      if (lane == 0) __hip_atomic_store(pub_tag, tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pub_tag = nullptr;
+    }
+  };
+
+  // ---- a group-step's addressing and its early requests (first input blocks, cell state, residual operand, tags) are
+  // set up ONE group-step ahead, under the previous group-step's recurrent part: nothing of it is waited for at the top
+  struct Grp {
+    unsigned vo0, voo, vok, voo2;
+    bool valid;
+    int task, step;
+  };
+  // Addressing without the per-group 64-bit minimum search and division of split_addr (they cost 9 of 97 ms here, one
+  // group-step every ~6 us per SIMD): the launcher has checked that offsets grow with the sequence index (so >= (q_inner - 1)
+  // si, q_inner >= 16), so the wave's minimum is its first sequence, whose (qo, qi) the wave carries along incrementally;
+  // a lane's distance from it is d si, plus (so - q_inner si) if the group crosses into the next outer index.
+  auto locate = [&](int task, int qo0, int qi0, Grp& gr, rsrc_t& rx0, rsrc_t& ro, rsrc_t& rsk, rsrc_t& ro2) {
+    const int q0 = task * 16;
+    gr.valid = q0 + n < p.nseq;
+    const int d = q0 + n < p.nseq ? n : p.nseq - 1 - q0;
+    const bool crossed = qi0 + d >= p.q_inner;
+    auto one = [&](const float* base, long long so, long long si, int extra, unsigned& voff) {
+      const long long delta = (long long)d * si + (crossed ? so - (long long)p.q_inner * si : 0ll);
+      voff = (unsigned)(delta * 4) + (unsigned)(extra * 4);
+      return make_rsrc(base + ((long long)qo0 * so + (long long)qi0 * si));
+    };
+    rx0 = one(p.src0.p, p.src0.so, p.src0.si, NS0 ? g : 4 * g, gr.vo0);
+    ro = one(p.out, p.out_so, p.out_si, dir * H + 4 * g, gr.voo);
+    gr.vok = gr.voo2 = 0;
+    rsk = SUM ? one(p.skip.p, p.skip.so, p.skip.si, dir * H + 4 * g, gr.vok) : rx0;
+    ro2 = SUM ? one(p.out_sum, p.out_so, p.out_si, dir * H + 4 * g, gr.voo2) : ro;
+  };
+  auto tt_of = [&](int step) { return (unsigned)(rev ? p.nsteps - 1 - step : step); };
+  auto rc_of = [&](int task) {
+    return make_rsrc(reinterpret_cast<const char*>(p.cscratch) + ((size_t)dir * (p.ntasks + 16) + task) * (NS * 1024));
+  };
+
+  if (g0 + w >= g1) return;                                   // (a wave without a group: nobody waits for it)
+  const bool single = g0 + w + NW >= g1;                      // one group per wave: its c_t is not written yet when the next
+                                                              // group-step's requests go out, so c is requested at the top
+  Grp cur, nxt;
+  rsrc_t rx0, ro, rsk, ro2, nrx0, nro, nrsk, nro2;
+  v4f xr[XD];
+  float xs0 = 0.f;
+  v4f cprev = zero4, skipv = zero4;
+  unsigned tagv = 0, tagd = 0;
+  auto request = [&](const Grp& gr, rsrc_t qx0, rsrc_t qsk, bool with_c) {   // early requests of group-step gr
+    const unsigned tt = tt_of(gr.step);
+    if constexpr (NV0 > 0)
+      static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
+    else
+      xs0 = bld1(qx0, gr.vo0, tt * st0);
+    if (SUM) skipv = bld4(qsk, gr.vok, tt * stk + 64 * m);
+    if (gr.step > 0) {
+      tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (with_c) cprev = bld4(rc_of(gr.task), vlane, m * 1024);
+    }
+    if (DRIFT > 0 && gr.task - DRIFT * NW >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
+      tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NW - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  cur.task = g0 + w;
+  cur.step = 0;
+  const int qo_first = (cur.task * 16) / p.q_inner, qi_first = cur.task * 16 - qo_first * p.q_inner;
+  int qo0 = qo_first, qi0 = qi_first;                         // (qo, qi) of the first sequence of the NEXT group to locate
+  locate(cur.task, qo0, qi0, cur, rx0, ro, rsk, ro2);
+  request(cur, rx0, rsk, true);
+
+  for (;;) {
+    const int step = cur.step, task = cur.task;
+    const unsigned tt = tt_of(step);
+    const unsigned o0 = tt * st0, oo = tt * sto;
+    const unsigned op = (rev ? tt + 1 : tt - 1) * sto;         // row of h_{step - 1}
+    const rsrc_t rc = rc_of(task);
+    unsigned* const tag_g = tag_cl + (size_t)(task - g0) * 8;
+    if (single && step > 0) cprev = bld4(rc, vlane, m * 1024);
+    const v4f cprev_cur = step > 0 ? cprev : zero4, skip_cur = skipv;
+
+    // h_{step - 1} of the whole row: every member's slice, once all 8 tags show it
+    v4f hold[NS];
+    auto fetch_h = [&]() {
+      if (DRIFT > 0 && !(ABL & 4) && task - DRIFT * NW >= g0) {
+        unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NW - g0) * 8;
+        for (unsigned spins = 0; __builtin_amdgcn_ballot_w64(tagd < (unsigned)step + 1) != 0; ++spins) {
+          __builtin_amdgcn_s_sleep(8);
+          tagd = __hip_atomic_load(tag_d + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (spins > kF32cSpinLimit) {
+            if (lane == 0) __hip_atomic_store(cp.status, 0x40000u | (unsigned)(cl & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_trap();
+          }
+        }
+      }
+      if (step > 0) {
+        for (unsigned spins = 0; !(ABL & 4) && __builtin_amdgcn_ballot_w64(tagv < (unsigned)step) != 0; ++spins) {
+          __builtin_amdgcn_s_sleep(16);
+          tagv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (spins > kF32cSpinLimit) {
+            if (lane == 0) __hip_atomic_store(cp.status, 0x30000u | (unsigned)(cl & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_trap();
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) hold[s] = bld4_l2(ro, cur.voo, op + 64 * s);
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) hold[s] = zero4;
+      }
+    };
+
+    // ---- matrix phase: record j of quad Q + 1 is read from LDS right after the MFMAs that used record j of quad Q
+    v4f acc[4];
+    acc[0] = rec(0, 0);
+    acc[1] = rec(0, 1);
+    acc[2] = rec(0, 2);
+    acc[3] = rec(0, 3);
+    v4f ra[4];
+    static_for<4>([&](auto j) { ra[j.value] = rec(1, j.value); });
+    auto quad = [&](auto qc, float b0, float b1, float b2, float b3) {
+      constexpr int Q = decltype(qc)::value;
+      MFMA4(acc, ra[0], b0);
+      if constexpr (Q + 1 < QPS) ra[0] = rec(Q + 1, 0);
+      MFMA4(acc, ra[1], b1);
+      if constexpr (Q + 1 < QPS) ra[1] = rec(Q + 1, 1);
+      MFMA4(acc, ra[2], b2);
+      if constexpr (Q + 1 < QPS) ra[2] = rec(Q + 1, 2);
+      MFMA4(acc, ra[3], b3);
+      if constexpr (Q + 1 < QPS) ra[3] = rec(Q + 1, 3);
+    };
+    auto quad1 = [&](auto qc, float b0) {   // remainder quad: one record
+      constexpr int Q = decltype(qc)::value;
+      MFMA4(acc, ra[0], b0);
+      if constexpr (Q + 1 < QPS) static_for<4>([&](auto j) { ra[j.value] = rec(Q + 1, j.value); });
+    };
+    if constexpr (NV0 > 0) {
+      static_for<NV0>([&](auto v) {
+        constexpr int V = decltype(v)::value;
+        if constexpr (V == NV0 / 2) {          // half the input part is left to cover the recurrent operands' round trip
+          pub_flush();
+          fetch_h();
+        }
+        const v4f xb = xr[V % XD];
+        quad(ic<1 + V>{}, xb.x, xb.y, xb.z, xb.w);
+        if constexpr (V + XD < NV0) xr[V % XD] = bld4(rx0, cur.vo0, o0 + 64 * (V + XD));
+      });
+    } else {
+      pub_flush();
+      fetch_h();
+      quad1(ic<1>{}, xs0);
+    }
+    // ---- the next group-step: where it is, and its early requests (the input ring is free now)
+    nxt.task = task + NW < g1 ? task + NW : g0 + w;
+    nxt.step = task + NW < g1 ? step : step + 1;
+    const bool more = nxt.step < p.nsteps;
+    if (more) {
+      if constexpr (ABL & 1) {   // timing ablation (wrong results): every group-step uses the first group's addressing
+        nxt.vo0 = cur.vo0; nxt.voo = cur.voo; nxt.vok = cur.vok; nxt.voo2 = cur.voo2; nxt.valid = cur.valid;
+        nrx0 = rx0; nro = ro; nrsk = rsk; nro2 = ro2;
+      } else {
+        if (nxt.step == step) {                               // next group of this wave: 16 NW sequences further
+          qi0 += 16 * NW;
+          while (qi0 >= p.q_inner) {
+            qi0 -= p.q_inner;
+            ++qo0;
+          }
+        } else {
+          qo0 = qo_first;
+          qi0 = qi_first;
+        }
+        locate(nxt.task, qo0, qi0, nxt, nrx0, nro, nrsk, nro2);
+      }
+      request(nxt, nrx0, nrsk, !single);
+    }
+    static_for<NS>([&](auto sp) {
+      constexpr int SP = decltype(sp)::value;
+      quad(ic<1 + NV0 + NS0 + SP>{}, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
+    });
+
+    // ---- cell update of my 16 units, stores, publish
+    v4f cn, hn;
+    if constexpr (ABL & 2) {     // timing ablation: cheap gates
+      cn = acc[1] + cprev_cur + acc[0];
+      hn = acc[3] + acc[2];
+    } else {
+      const v4f ig = sigmoid4(acc[0]);
+      const v4f fg = sigmoid4(acc[1]);
+      const v4f gg = tanh4(acc[2]);
+      const v4f og = sigmoid4(acc[3]);
+      cn = cell4(fg, cprev_cur, ig, gg);
+      hn = mul_rn4(og, tanh4(cn));
+    }
+    asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
+    bst4(cn, rc, vlane, m * 1024);
+    if (cur.valid) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hn), ro, cur.voo, oo + 64 * m, 16);   // sc1: the hand-off
+      if (SUM) bst4(add_rn4(hn, skip_cur), ro2, cur.voo2, oo + 64 * m);
+    }
+    asm volatile("" ::: "memory");
+    pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
+    asm volatile("" ::: "memory");
+    pub_val = (unsigned)step + 1;
+    pub_tag = tag_g + m;
+    if (!more) break;
+    cur = nxt;
+    rx0 = nrx0;
+    ro = nro;
+    rsk = nrsk;
+    ro2 = nro2;
+  }
+  pub_flush();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2>
+int launch_f32c_k(const LstmParams& p, const F32ClusterParams& cp, hipStream_t st) {
+  constexpr int QPS = 1 + NV0 + NS0 + 8;
+  const size_t lds = (size_t)QPS * 4096;
+  auto k = lstm_f32c_kernel<NV0, NS0, MODE, ABL, DRIFT>;
+  if (lds > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int ncl = cp.clusters_per_dir * p.ndir;
+  hipLaunchKernelGGL(k, dim3(64 * ((ncl + 7) / 8)), dim3(kF32cWaves * 64), lds, st, p, cp);
+  FNSSL_CHECK_LAUNCH("lstm_f32c_kernel");
+  return FNSSL_OK;
+}
+
+}  // namespace fnssl_lstm

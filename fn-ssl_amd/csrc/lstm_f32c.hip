@@ -1,0 +1,47 @@
+// Cluster-resident fp32 LSTM kernel (lstm_f32c.h): instantiations for FN-SSL's H = 128 full-band layers and the launcher.
+#include <cstdlib>
+
+#include "lstm_f32c.h"
+
+namespace fnssl_lstm {
+
+// Full-chip launches of the two full-band shapes of the network (block 1: 4 input channels; blocks 2-3: 256, fused
+// residual output).  FNSSL_NO_F32_CLUSTER=1 keeps lstm_static_kernel's rounds (same bits): A/B.
+bool f32c_handles(const LstmParams& p, int H, int mode) {
+  if (getenv("FNSSL_NO_F32_CLUSTER")) return false;
+  if (H != 128 || p.carry || p.reserve || p.c2 != 0 || p.ablate) return false;
+  // (block 1's layer, 4 input channels = 144 MFMAs per group-step, runs 42.7 ms here against 36.3 in rounds: not taken)
+  if (!(p.c0 == 256 && (mode == kSum || mode == 0))) return false;
+  // the kernel's addressing takes a group's first sequence as its lowest address
+  auto grows = [&](long long so, long long si) { return si >= 0 && so >= (long long)(p.q_inner - 1) * si; };
+  if (p.q_inner < 16 || !grows(p.src0.so, p.src0.si) || !grows(p.out_so, p.out_si) ||
+      ((mode & kSum) && !grows(p.skip.so, p.skip.si)))
+    return false;
+  const int ncu = fnssl::device_cus();
+  if (ncu < 8 * p.ndir) return false;
+  return (long long)p.ntasks * p.ndir >= 12LL * ncu;   // at least one full round of three waves per SIMD
+}
+
+int forward_f32c(LstmParams p, int mode, hipStream_t st) {
+  const int ncu = fnssl::device_cus();
+  F32ClusterParams cp;
+  cp.clusters_per_dir = (ncu / 8) / p.ndir;
+  cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
+  cp.status = reinterpret_cast<unsigned*>(p.cluster_ws);
+  cp.tags = reinterpret_cast<unsigned*>(p.cluster_ws + 256);
+  const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * 8 * sizeof(unsigned);
+  FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));
+#ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
+  if (mode == kSum) switch (env_int("FNSSL_F32C_ABL", 1, 7)) {
+      case 1: return launch_f32c_k<16, 0, kSum, 1>(p, cp, st);
+      case 2: return launch_f32c_k<16, 0, kSum, 2>(p, cp, st);
+      case 4: return launch_f32c_k<16, 0, kSum, 4>(p, cp, st);
+      case 7: return launch_f32c_k<16, 0, kSum, 7>(p, cp, st);
+      default: break;
+    }
+#endif
+  if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
+  return launch_f32c_k<16, 0, 0>(p, cp, st);
+}
+
+}  // namespace fnssl_lstm

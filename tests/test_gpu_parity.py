@@ -1064,6 +1064,50 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
     assert torch.equal(a, a2), "cluster kernel is not repeatable"
 
 
+@pytest.mark.parametrize("nb,nt,nf,summed", [
+    (96, 256, 5, True),      # 24576 sequences x 2 directions = 3072 groups: exactly one 12-wave round, 96 groups per cluster
+    (97, 300, 4, True),      # 29100 sequences: ragged last group (12 live sequences), groups that cross an utterance boundary
+    (96, 256, 3, False),     # without the fused residual output
+])
+def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, nt, nf, summed):
+    """lstm_f32c.h (H = 128 full-band layers at full-chip size: hidden slices over clusters of 8 CUs, 16-sequence groups as
+    work items, h_t handed over through the output tensor) bit-for-bit against the per-wave rounds of lstm_static_kernel
+    (FNSSL_NO_F32_CLUSTER=1), twice, and a few sequences against the oracle."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    H, c0 = 128, 256
+    sd = lstm_state(c0, H, True, 5600 + nb)
+    w = [ops.pack_lstm(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, 0, dev)
+         for s_ in ("", "_reverse")]
+    g = torch.Generator(device="cpu").manual_seed(5601 + nf)
+    x = (torch.randn((nb, nt, nf, c0), generator=g) * 0.5).to(dev)
+    skip = (torch.randn((nb, nt, nf, 2 * H), generator=g) * 0.5).to(dev) if summed else None
+
+    def run():
+        out = torch.full((nb, nt, nf, 2 * H), float("nan"), device=dev)
+        osum = torch.full_like(out, float("nan")) if summed else None
+        ops.lstm_layer("full", x, None, None, w, H, out, skip=skip, out_sum=osum)
+        return out, osum
+
+    monkeypatch.delenv("FNSSL_NO_F32_CLUSTER", raising=False)
+    a, asum = run()
+    a2, _ = run()
+    monkeypatch.setenv("FNSSL_NO_F32_CLUSTER", "1")
+    b, bsum = run()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, a2), "cluster kernel differs from the rounds / is not repeatable"
+    if summed:
+        assert torch.equal(asum, bsum)
+        assert torch.equal(asum, a + skip)
+    with torch.cuda.device(dev):
+        assert ops.lstm_cluster_status(nb * nt, H, 2, dev) == 0
+    rows = [(0, 0), (nb // 2, nt - 1), (nb - 1, nt - 1)]                       # first / boundary-crossing / ragged group
+    seq = np.stack([x[b_, t_].cpu().numpy() for b_, t_ in rows])             # [3, nf, c0]
+    want = O.lstm(seq, sd, "L.", True)
+    got = np.stack([a[b_, t_].cpu().numpy() for b_, t_ in rows])
+    assert_close(got, want, RTOL, ATOL, "fp32 cluster kernel vs oracle")
+
+
 def test_lstm_bf16_wide_rejects_unbuilt_shapes(dev):
     from fnssl import ops
     sd = lstm_state(128, 256, False, 5200)

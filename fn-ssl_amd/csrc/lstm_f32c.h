@@ -5,7 +5,8 @@
 // per CU = 8 wave-times (pigeonhole: 0.879 of the roof before any other loss; measured 0.78).  Here the hidden SLICES of
 // the layer are split over a cluster of 8 CUs — member m keeps slice m of the packed weight stream (25 quads = 100 KiB,
 // or 10 quads for block 1) in LDS for the whole launch — and the 16-sequence groups become work items that the member's
-// 12 waves take in turn: 225 groups per cluster = 18.75 per wave, run as 19 = 0.987 of the roof.  Every member computes
+// 16 waves take in turn: 225 groups per cluster = 14 per wave and one left over: the fullest SIMD runs 57 group-steps per
+// step against 56.25 on average = 0.987 of the roof.  Every member computes
 // its 16 hidden units for ALL groups of the cluster; h_t travels between the members through the OUTPUT tensor itself
 // (the row of step t is written once and read at step t + 1 by everybody, exactly where lstm_static_kernel re-reads its
 // own h): write-through (sc1) stores, sc1 loads, and one tag word per (group, member) = step + 1.  A hand-off has a
@@ -19,7 +20,7 @@
 
 namespace fnssl_lstm {
 
-constexpr int kF32cWaves = 12;
+constexpr int kF32cWaves = 16;   // four per SIMD (measured: 100.8 against 102.3 ms per layer with 12 = three per SIMD); 225 groups = 14 each + 1
 constexpr unsigned kF32cSpinLimit = 1u << 20;
 
 struct F32ClusterParams {
@@ -30,15 +31,15 @@ struct F32ClusterParams {
 };
 
 // NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad (block 1); MODE: 0 or kSum
-template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2>
-__global__ void __launch_bounds__(kF32cWaves * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
-  constexpr int H = 128, NS = H / 16, NW = kF32cWaves;
+template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2, int NW_ = kF32cWaves>
+__global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
+  constexpr int H = 128, NS = H / 16, NW = NW_;
   constexpr bool SUM = (MODE & kSum) != 0;
   constexpr int QPS = 1 + NV0 + NS0 + NS;
   // DRIFT: a wave starts the recurrent part of its k-th group of a step only when EVERY member has finished its
   // (k - DRIFT)-th: the eight members then read a group's input rows within a few group-times of each other and the seven
   // later ones find them in the XCD's L2 (4 MB for four clusters) instead of fetching them again from memory
-  constexpr int XD = 8;   // input ring: block v is requested XD - 1 quads (~3.6 k cycles) before its use — the other members have pushed it out of L2
+  constexpr int XD = NW_ > 12 ? 4 : 8;   // input ring: block v is requested XD - 1 quads (~3.6 k cycles) before its use — the other members have pushed it out of L2
   static_assert(!(NV0 && NS0) && (NV0 == 0 || NV0 % XD == 0), "block-only or remainder-only input");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -289,15 +290,15 @@ __global__ void __launch_bounds__(kF32cWaves * 64) lstm_f32c_kernel(const LstmPa
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2>
+template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2, int NW_ = kF32cWaves>
 int launch_f32c_k(const LstmParams& p, const F32ClusterParams& cp, hipStream_t st) {
   constexpr int QPS = 1 + NV0 + NS0 + 8;
   const size_t lds = (size_t)QPS * 4096;
-  auto k = lstm_f32c_kernel<NV0, NS0, MODE, ABL, DRIFT>;
+  auto k = lstm_f32c_kernel<NV0, NS0, MODE, ABL, DRIFT, NW_>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int ncl = cp.clusters_per_dir * p.ndir;
-  hipLaunchKernelGGL(k, dim3(64 * ((ncl + 7) / 8)), dim3(kF32cWaves * 64), lds, st, p, cp);
+  hipLaunchKernelGGL(k, dim3(64 * ((ncl + 7) / 8)), dim3(NW_ * 64), lds, st, p, cp);
   FNSSL_CHECK_LAUNCH("lstm_f32c_kernel");
   return FNSSL_OK;
 }

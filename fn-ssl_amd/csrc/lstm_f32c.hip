@@ -19,7 +19,7 @@ bool f32c_handles(const LstmParams& p, int H, int mode) {
     return false;
   const int ncu = fnssl::device_cus();
   if (ncu < 8 * p.ndir) return false;
-  return (long long)p.ntasks * p.ndir >= 12LL * ncu;   // at least one full round of three waves per SIMD
+  return (long long)p.ntasks * p.ndir >= 12LL * ncu;   // at least what one full round of three waves per SIMD would cover
 }
 
 int forward_f32c(LstmParams p, int mode, hipStream_t st) {
@@ -40,6 +40,7 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
       default: break;
     }
 #endif
+  if (mode == kSum && getenv("FNSSL_F32C_W12")) return launch_f32c_k<16, 0, kSum, 0, 2, 12>(p, cp, st);   // A/B: three waves per SIMD
   if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
   return launch_f32c_k<16, 0, 0>(p, cp, st);
 }

@@ -10,8 +10,9 @@ namespace fnssl_lstm {
 bool f32c_handles(const LstmParams& p, int H, int mode) {
   if (getenv("FNSSL_NO_F32_CLUSTER")) return false;
   if (H != 128 || p.carry || p.reserve || p.c2 != 0 || p.ablate) return false;
-  // (block 1's layer, 4 input channels = 144 MFMAs per group-step, runs 42.7 ms here against 36.3 in rounds: not taken)
-  if (!(p.c0 == 256 && (mode == kSum || mode == 0))) return false;
+  // (block 1's layer, 4 input channels = 144 MFMAs per group-step, ties with the rounds — 36.5 ms both — and stays there;
+  //  FNSSL_F32C_B1=1 routes it here: A/B)
+  if (!(p.c0 == 256 && (mode == kSum || mode == 0)) && !(p.c0 == 4 && mode == 0 && getenv("FNSSL_F32C_B1"))) return false;
   // the kernel's addressing takes a group's first sequence as its lowest address
   auto grows = [&](long long so, long long si) { return si >= 0 && so >= (long long)(p.q_inner - 1) * si; };
   if (p.q_inner < 16 || !grows(p.src0.so, p.src0.si) || !grows(p.out_so, p.out_si) ||
@@ -40,6 +41,7 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
       default: break;
     }
 #endif
+  if (p.c0 == 4) return launch_f32c_k<0, 1, 0>(p, cp, st);   // (experiment switch FNSSL_F32C_B1)
   if (mode == kSum && getenv("FNSSL_F32C_W12")) return launch_f32c_k<16, 0, kSum, 0, 2, 12>(p, cp, st);   // A/B: three waves per SIMD
   if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
   return launch_f32c_k<16, 0, 0>(p, cp, st);

@@ -32,7 +32,7 @@ def run(x, w, summed, cluster, reps=1):
 
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
-for c0, summed in (((256, True),) if os.environ.get("ONLY256") else ((256, True), (4, False), (256, False))):
+for c0, summed in (((256, True),) if os.environ.get("ONLY256") else ((4, False),) if os.environ.get("ONLY4") else ((256, True), (4, False), (256, False))):
     w = make(c0, 11 + c0)
     if mode in ("all", "check"):
         for nb, nt, nf in ((96, 256, 6), (97, 300, 5)):               # 24576 / 29100 sequences: full-chip, the second ragged

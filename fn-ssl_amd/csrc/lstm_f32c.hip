@@ -42,6 +42,12 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
     }
 #endif
   if (p.c0 == 4) return launch_f32c_k<0, 1, 0>(p, cp, st);   // (experiment switch FNSSL_F32C_B1)
+  if (mode == kSum) switch (env_int("FNSSL_F32C_DRIFT", 1, 4)) {   // experiment knob
+      case 1: return launch_f32c_k<16, 0, kSum, 0, 1>(p, cp, st);
+      case 3: return launch_f32c_k<16, 0, kSum, 0, 3>(p, cp, st);
+      case 4: return launch_f32c_k<16, 0, kSum, 0, 4>(p, cp, st);
+      default: break;
+    }
   if (mode == kSum && getenv("FNSSL_F32C_W12")) return launch_f32c_k<16, 0, kSum, 0, 2, 12>(p, cp, st);   // A/B: three waves per SIMD
   if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
   return launch_f32c_k<16, 0, 0>(p, cp, st);

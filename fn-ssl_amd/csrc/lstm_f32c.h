@@ -197,14 +197,24 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     static_for<4>([&](auto j) { ra[j.value] = rec(1, j.value); });
     auto quad = [&](auto qc, float b0, float b1, float b2, float b3) {
       constexpr int Q = decltype(qc)::value;
+      // (the fences pin each LDS read right behind the MFMAs that used its register — 12 MFMAs before its own use; left
+      //  alone the scheduler sinks the reads next to their uses and every second MFMA group waits out an LDS round trip)
       MFMA4(acc, ra[0], b0);
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (Q + 1 < QPS) ra[0] = rec(Q + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
       MFMA4(acc, ra[1], b1);
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (Q + 1 < QPS) ra[1] = rec(Q + 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
       MFMA4(acc, ra[2], b2);
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (Q + 1 < QPS) ra[2] = rec(Q + 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
       MFMA4(acc, ra[3], b3);
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (Q + 1 < QPS) ra[3] = rec(Q + 1, 3);
+      __builtin_amdgcn_sched_barrier(0);
     };
     auto quad1 = [&](auto qc, float b0) {   // remainder quad: one record
       constexpr int Q = decltype(qc)::value;

@@ -1064,18 +1064,19 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
     assert torch.equal(a, a2), "cluster kernel is not repeatable"
 
 
-@pytest.mark.parametrize("nb,nt,nf,summed", [
-    (96, 256, 5, True),      # 24576 sequences x 2 directions = 3072 groups: exactly one 12-wave round, 96 groups per cluster
-    (97, 300, 4, True),      # 29100 sequences: ragged last group (12 live sequences), groups that cross an utterance boundary
-    (96, 256, 3, False),     # without the fused residual output
+@pytest.mark.parametrize("nb,nt,nf,summed,c0", [
+    (96, 256, 5, True, 256),     # 24576 sequences x 2 directions = 3072 groups: exactly one 12-wave round, 96 groups per cluster
+    (97, 300, 4, True, 256),     # 29100 sequences: ragged last group (12 live sequences), groups that cross an utterance boundary
+    (96, 256, 3, False, 256),    # without the fused residual output
+    (97, 300, 4, False, 4),      # block 1's layer: 4 input channels (one remainder quad)
 ])
-def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, nt, nf, summed):
+def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, nt, nf, summed, c0):
     """lstm_f32c.h (H = 128 full-band layers at full-chip size: hidden slices over clusters of 8 CUs, 16-sequence groups as
     work items, h_t handed over through the output tensor) bit-for-bit against the per-wave rounds of lstm_static_kernel
     (FNSSL_NO_F32_CLUSTER=1), twice, and a few sequences against the oracle."""
     from fnssl import ops
     from oracle import fnssl_oracle as O
-    H, c0 = 128, 256
+    H = 128
     sd = lstm_state(c0, H, True, 5600 + nb)
     w = [ops.pack_lstm(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, 0, dev)
          for s_ in ("", "_reverse")]
@@ -1090,6 +1091,7 @@ def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, 
         return out, osum
 
     monkeypatch.delenv("FNSSL_NO_F32_CLUSTER", raising=False)
+    monkeypatch.delenv("FNSSL_NO_F32C_B1", raising=False)
     a, asum = run()
     a2, _ = run()
     monkeypatch.setenv("FNSSL_NO_F32_CLUSTER", "1")

@@ -163,13 +163,22 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
 
   auto multiply = [&](int buf) {
+    // the operands of sub-step kk + 1 are read from LDS BEFORE the MFMAs of sub-step kk (fences: the scheduler otherwise
+    // sinks the reads next to their use and every 16 MFMAs wait out an LDS round trip)
+    float a[4], b[4], an[4], bn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = As[buf][kq][wm + 16 * i + l16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = Bs[buf][kq][wn + 16 * j + l16];
 #pragma unroll
     for (int kk = 0; kk < kBK / 4; ++kk) {
-      float a[4], b[4];
+      if (kk + 1 < kBK / 4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[buf][4 * kk + kq][wm + 16 * i + l16];
+        for (int i = 0; i < 4; ++i) an[i] = As[buf][4 * (kk + 1) + kq][wm + 16 * i + l16];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[buf][4 * kk + kq][wn + 16 * j + l16];
+        for (int j = 0; j < 4; ++j) bn[j] = Bs[buf][4 * (kk + 1) + kq][wn + 16 * j + l16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if (jn == 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -182,6 +191,13 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
           }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 1 < kBK / 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = bn[j];
       }
     }
   };

@@ -27,9 +27,9 @@ Plan make_plan(int nb, int nf, int nt, int is_online, int chunk_pairs) {
   Plan p;
   p.chunk = (chunk_pairs <= 0 || chunk_pairs > nb) ? nb : chunk_pairs;
   p.act_floats = (size_t)p.chunk * nt * nf * 256;
-  const size_t ws_full = fnssl_lstm_workspace_bytes(p.chunk * nt, 128, 2);
-  const size_t ws_narr = is_online ? fnssl_lstm_workspace_bytes(p.chunk * nf, 256, 1)
-                                   : fnssl_lstm_workspace_bytes(p.chunk * nf, 128, 2);
+  const size_t ws_full = fnssl_lstm_workspace_bytes_ex(p.chunk * nt, 128, 2, FNSSL_PRECISION_FP32);
+  const size_t ws_narr = is_online ? fnssl_lstm_workspace_bytes_ex(p.chunk * nf, 256, 1, FNSSL_PRECISION_FP32)
+                                   : fnssl_lstm_workspace_bytes_ex(p.chunk * nf, 128, 2, FNSSL_PRECISION_FP32);
   p.lstm_ws = align_up(std::max(ws_full, ws_narr), 256);
   p.head_floats = (size_t)p.chunk * (nt / FNSSL_SEG_FRAMES) * 2 * nf;
   p.total = 6 * align_up(p.act_floats * 4, 256) + p.lstm_ws + align_up(p.head_floats * 4, 256) + 256;

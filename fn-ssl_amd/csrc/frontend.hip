@@ -537,6 +537,8 @@ __global__ void __launch_bounds__(NW * 64) stft_rows_kernel(const RowParams p) {
 }
 
 int rows_waves(int nch) { return nch <= 4 ? 4 : (nch <= 8 ? 8 : 16); }
+// the frame-row kernel fetches 8 samples per thread: a frame's nch * 512 samples must fit 16 waves x 64 x 8 = 8192
+constexpr int kRowsMaxCh = 16;
 
 size_t rows_lds_bytes(int nch, int mode) {
   return (size_t)(768 + 512 + rows_waves(nch) * 512 + nch * kXsStride + (mode == 2 ? kNF * 2 * nch : 0)) * sizeof(float);
@@ -562,7 +564,8 @@ int launch_rows_nw(const RowParams& p, const char* name, hipStream_t st) {
 
 template <int MODE>
 int launch_rows(const RowParams& p, const char* name, hipStream_t st) {
-  FNSSL_REQUIRE(rows_lds_bytes(p.nch, MODE) <= 160 * 1024, "front end: %d channels do not fit the frame image in LDS", p.nch);
+  FNSSL_REQUIRE(p.nch <= kRowsMaxCh && rows_lds_bytes(p.nch, MODE) <= 160 * 1024,
+                "front end: the frame-row kernels take at most %d channels (%d given)", kRowsMaxCh, p.nch);
   FNSSL_REQUIRE((long long)p.nb * p.nt < (1ll << 31), "front end: too many frames");
   switch (rows_waves(p.nch)) {
     case 4: return launch_rows_nw<MODE, 4>(p, name, st);
@@ -622,7 +625,7 @@ int fnssl_stft_ex(const float* sig, int nb, int ns, int nch, long long sb, long 
   p.sb = sb; p.sn = sn; p.sc = sc;
   p.spec = reinterpret_cast<float2*>(spec);
   p.magsum = magsum;
-  if (magsum && rows_lds_bytes(nch, 0) <= 160 * 1024 && !getenv("FNSSL_STFT_PER_FRAME"))
+  if (magsum && nch <= kRowsMaxCh && rows_lds_bytes(nch, 0) <= 160 * 1024 && !getenv("FNSSL_STFT_PER_FRAME"))
     return launch_rows<0>(p, "stft", fnssl::as_stream(stream));
   // fallback (no magnitude sums wanted, or more channels than the frame image holds): one wave per (b, c, t)
   const long long nframes = (long long)nb * nch * nt;
@@ -719,7 +722,8 @@ int fnssl_array_frontend(const float* sig, int nb, int ns, int nch, long long sb
   const int nt = fnssl_num_frames_ex(ns, hop, center);
   FNSSL_REQUIRE(nt > 0, "array_frontend: signal of %d samples is too short", ns);
   FNSSL_REQUIRE(sig && coef_a && coef_b && magsum && mu && x, "array_frontend: null pointer");
-  FNSSL_REQUIRE(rows_lds_bytes(nch, 2) <= 160 * 1024, "array_frontend: %d channels do not fit the frame image in LDS", nch);
+  FNSSL_REQUIRE(nch <= kRowsMaxCh && rows_lds_bytes(nch, 2) <= 160 * 1024,
+                "array_frontend: at most %d channels (%d given): use fnssl_stft_ex + fnssl_array_features", kRowsMaxCh, nch);
   hipStream_t st = fnssl::as_stream(stream);
   RowParams p{};
   p.sig = sig;

@@ -40,7 +40,7 @@ extern template int launch_split_h<256>(int, const LstmParams&, int, int, hipStr
 int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train.hip
 int forward_bf16(LstmParams p, int H, hipStream_t st);             // lstm_bf16.hip
 bool f32c_handles(const LstmParams& p, int H, int mode);           // lstm_f32c.hip
-int forward_f32c(LstmParams p, int mode, hipStream_t st);
+int forward_f32c(LstmParams p, int mode, hipStream_t st);          // FNSSL_OK, kNoCluster (not co-resident: caller takes the rounds) or an error
 }  // namespace fnssl_lstm
 
 // ---- launch planner (host) -------------------------------------------------------------------------------------
@@ -160,10 +160,18 @@ static size_t pair_stream_bytes(int hidden, int ndir) {
 }
 
 // the hand-off area of the cluster-resident bf16 kernel (lstm_bf16c.h) lives behind that: status word, tags, operand records
-static size_t cluster_bytes(int nseq, int hidden, int ndir) {
+// (bf16 "wide" calls: tags + two parities of operand records, ~513 B per sequence; fp32 calls: the cluster kernel of
+//  lstm_f32c.h hands h_t over through the output tensor and needs the status word + 8 tag words per 16-sequence group
+//  and direction, rounded up per cluster: ~2 B per sequence)
+static size_t cluster_bytes(int nseq, int hidden, int ndir, int precision) {
   if (hidden != 256 && hidden != 128) return 0;
-  const size_t ncl = (size_t)ndir * ((nseq + cluster_seqs(hidden) - 1) / cluster_seqs(hidden));
-  return 256 + ncl * (kClusterTagWords * 4) + ncl * 2 * cluster_parity_bytes(hidden);
+  if (precision == FNSSL_PRECISION_BF16W) {
+    const size_t ncl = (size_t)ndir * ((nseq + cluster_seqs(hidden) - 1) / cluster_seqs(hidden));
+    return 256 + ncl * (kClusterTagWords * 4) + ncl * 2 * cluster_parity_bytes(hidden);
+  }
+  if (precision != FNSSL_PRECISION_FP32) return 256;
+  const size_t groups = (size_t)(nseq + 15) / 16;
+  return 256 + (groups + 512) * ndir * 8 * sizeof(unsigned);   // (+512: the last cluster's groups are rounded up)
 }
 
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap) {
@@ -176,9 +184,13 @@ int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_p
   return (int)nw.size();
 }
 
-size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {
+size_t fnssl_lstm_workspace_bytes_ex(int nseq, int hidden, int ndir, int precision) {
   if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
-  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir) + cluster_bytes(nseq, hidden, ndir);
+  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir) + cluster_bytes(nseq, hidden, ndir, precision);
+}
+
+size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {   // sufficient for every precision
+  return fnssl_lstm_workspace_bytes_ex(nseq, hidden, ndir, FNSSL_PRECISION_BF16W);
 }
 
 namespace {
@@ -202,7 +214,7 @@ __global__ void __launch_bounds__(256) pair_stream_kernel(const float4* __restri
 int fnssl_lstm_cluster_status(const void* workspace, size_t workspace_bytes, int nseq, int hidden, int ndir, void* stream,
                               unsigned* status) {
   FNSSL_REQUIRE(workspace && status && nseq > 0 && ndir > 0, "lstm_cluster_status: null pointer / empty problem");
-  FNSSL_REQUIRE(workspace_bytes >= fnssl_lstm_workspace_bytes(nseq, hidden, ndir) && cluster_bytes(nseq, hidden, ndir) > 0,
+  FNSSL_REQUIRE(workspace_bytes >= fnssl_lstm_workspace_bytes_ex(nseq, hidden, ndir, FNSSL_PRECISION_FP32) && (hidden == 128 || hidden == 256),
                 "lstm_cluster_status: not a workspace of a cluster-kernel shape (hidden %d)", hidden);
   const char* word = reinterpret_cast<const char*>(workspace) + cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir);
   hipStream_t st = fnssl::as_stream(stream);
@@ -211,7 +223,11 @@ int fnssl_lstm_cluster_status(const void* workspace, size_t workspace_bytes, int
   return FNSSL_OK;
 }
 
-int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
+}  // extern "C"
+
+// dry = true (fnssl_lstm_plan): every decision of the real call is taken, nothing is enqueued; *family / *rounds report
+// the kernel family and its number of launches
+static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, int* family, int* rounds) {
   FNSSL_REQUIRE(d, "lstm_forward: null descriptor");
   const int H = d->hidden;
   FNSSL_REQUIRE(H == 16 || H == 32 || H == 64 || H == 128 || H == 256,
@@ -248,7 +264,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
                                      mult4(d->skip.si) && mult4(d->skip.st))) &&
                     extent_ok(d->out_so, d->out_si, d->out_st, 2 * H),
                 "lstm_forward: strides must be non-negative and one sequence group must span < 4 GB");
-  const size_t need = fnssl_lstm_workspace_bytes(d->nseq, H, d->ndir);
+  const size_t need = fnssl_lstm_workspace_bytes_ex(d->nseq, H, d->ndir, d->precision);
   if (!d->workspace || d->workspace_bytes < need) {
     fnssl::set_error("lstm_forward: workspace %zu < %zu bytes", d->workspace_bytes, need);
     return FNSSL_E_WORKSPACE;
@@ -281,10 +297,18 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   p.ndir = d->ndir;
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
 #ifdef FNSSL_BUILD_ABLATE
-  p.ablate = env_int("FNSSL_ABLATE", 1, 63);   // timing experiments: twin kernels that skip work (wrong results)
+  p.ablate = env_int("FNSSL_ABLATE", 1, 255);   // timing experiments: twin kernels that skip work (wrong results)
 #else
   p.ablate = 0;                                 // the shipping library contains no ablation twins (make ABLATE=1)
 #endif
+  p.dry = dry ? 1 : 0;
+  p.prio_mode = env_int("FNSSL_STATIC_PRIO", 1, 3);
+  p.fallback_count = d->fallback_count;
+  int nlaunch = 0;
+  bool guarded = false;   // true: what follows is the guarded fallback of a cluster kernel (family already reported)
+  auto report = [&](int f) {
+    if (family && !guarded) *family = f;
+  };
   const int tasks = (d->nseq + 15) / 16;
   const int mode = ((d->src1.p != nullptr && d->c0 > 0) ? kHas1 : 0) | (d->c2 > 0 ? kHas2 : 0) |
                    (d->out_sum ? kSum : 0);
@@ -292,8 +316,8 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   const double flops = 2.0 * 4 * H * (double)(d->c0 + d->c2 + H) * d->nseq * (double)d->nsteps * d->ndir;
   static const char* names[5] = {"lstm_h16", "lstm_h32", "lstm_h64", "lstm_h128", "lstm_h256"};
   const int hi = H == 16 ? 0 : H == 32 ? 1 : H == 64 ? 2 : H == 128 ? 3 : 4;
-  fnssl::TimedLaunch tl(names[hi], fnssl::as_stream(stream), flops);
   hipStream_t st = fnssl::as_stream(stream);
+  fnssl::TimedLaunch tl(dry ? nullptr : names[hi], st, flops);
 
   if (d->precision == FNSSL_PRECISION_BF16) {   // bf16 MFMA operands (weights packed by fnssl_lstm_pack_bf16)
     FNSSL_REQUIRE(!(mode & (kHas1 | kSum)) && !d->reserve && !d->carry_state && d->c0 % 16 == 0 && d->c2 % 16 == 0,
@@ -302,6 +326,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     p.quads_per_slice = bf16_quads_per_slice(d->c0, d->c2, H);
     p.chq = 0;
     p.pad = 0;
+    report(FNSSL_LSTM_FAMILY_BF16);
     return forward_bf16(p, H, st);
   }
   if (d->precision == FNSSL_PRECISION_BF16W) {   // wide bf16 kernels: 32 sequences per wave, bf16 / fp32 activation tensors
@@ -313,7 +338,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
                       ((fm & 2) || !d->c2 || (mult8(d->src2.so) && mult8(d->src2.si) && mult8(d->src2.st))) &&
                       ((fm & 4) || (mult8(d->out_so) && mult8(d->out_si) && mult8(d->out_st))),
                   "lstm_forward: strides of bf16 tensors must be multiples of 8 elements");
-    return forward_bf16w(p, H, fm, st);
+    return forward_bf16w(p, H, fm, st, family);
   }
   FNSSL_REQUIRE(d->precision == FNSSL_PRECISION_FP32, "lstm_forward: unknown precision %d", d->precision);
   if (d->reserve) {   // training forward: also save the gate activations (lstm_train.hip)
@@ -328,13 +353,24 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     p.task0 = 0;
     p.task1 = tasks;
     p.wgs_per_dir = 0;
-    return forward_save(p, H, mode, st);
+    report(FNSSL_LSTM_FAMILY_TRAIN);
+    return dry ? FNSSL_OK : forward_save(p, H, mode, st);
   }
 
   // H = 128 full-band layers at full-chip size: hidden slices over clusters of 8 CUs, groups as work items (lstm_f32c.h)
+  // — followed, in the same call, by the rounds below as its GUARDED fallback (they return at once unless the cluster
+  // kernel recorded a hand-off it gave up on: include/fnssl.h, fnssl_lstm_forward)
   if (d->variant == 0 && !(mode & kHas1) && f32c_handles(p, H, mode)) {
-    FNSSL_REQUIRE(d->workspace_bytes >= need, "lstm_forward: workspace");
-    return forward_f32c(p, mode, st);
+    const int rc = forward_f32c(p, mode, st);
+    if (rc == FNSSL_OK) {
+      report(FNSSL_LSTM_FAMILY_F32_CLUSTER);
+      if (rounds) *rounds = 1;
+      if (dry) return FNSSL_OK;
+      guarded = true;
+      p.guard = reinterpret_cast<const unsigned*>(p.cluster_ws);
+    } else if (rc != kNoCluster) {
+      return rc;
+    }
   }
 
   // one launch of `nw` waves per workgroup over the 16-sequence groups [t0, t1) of every direction
@@ -344,32 +380,41 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     p.task1 = t1;
     p.wgs_per_dir = (t1 - t0 + vr.NW - 1) / vr.NW;
     const int nwg = p.wgs_per_dir * d->ndir;
+    ++nlaunch;
     if (d->variant == 0 && !env_int("FNSSL_LSTM_NO_STATIC", 1, 1)) {
       int rc = kNoStatic;
       if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
       if (H == 256) {
         // two hidden slices per pass (lstm_static2.h) for the full-chip narrow-band rounds of blocks 2 / 3: the stream
         // is re-ordered into the workspace first (2 MB per direction, one tiny launch) — FNSSL_NO_STATIC2=1: A/B
-        if (vr.NW == 12 && d->c0 == 256 && d->c2 == 0 && !(mode & ~kSum) && !p.carry && !p.ablate &&
+        if (vr.NW == 12 && d->c0 == 256 && d->c2 == 0 && !(mode & ~kSum) && !p.carry && (!p.ablate || env_int("FNSSL_ABL_STATIC2", 1, 1)) &&
             !env_int("FNSSL_NO_STATIC2", 1, 1)) {
           LstmParams p2 = p;
           const long long n4 = (long long)(H / 16) * p.quads_per_slice * 4 * 64;      // float4 per direction
           char* dst = reinterpret_cast<char*>(d->workspace) + cell_scratch_bytes(d->nseq, H, d->ndir);
           for (int di = 0; di < d->ndir; ++di) {
             float4* o = reinterpret_cast<float4*>(dst + (size_t)di * n4 * 16);
-            hipLaunchKernelGGL(pair_stream_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+            if (!dry)
+              hipLaunchKernelGGL(pair_stream_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                                reinterpret_cast<const float4*>(p.wpack[di]), p.quads_per_slice, n4, o);
             p2.wpack[di] = reinterpret_cast<const float*>(o);
           }
           FNSSL_CHECK_LAUNCH("pair_stream_kernel");
           rc = launch_static2_h256(p2, mode, nwg, st);
-          if (rc != kNoStatic) return rc;
+          if (rc != kNoStatic) {
+            report(FNSSL_LSTM_FAMILY_STATIC2);
+            return rc;
+          }
         }
         rc = launch_static_h256(p, mode, vr.NW, nwg, st);
       }
       if (rc == kNoStatic && !env_int("FNSSL_NO_STATIC_IPDNET", 1, 1)) rc = launch_static_ipdnet(p, mode, H, vr.NW, nwg, st);
-      if (rc != kNoStatic) return rc;
+      if (rc != kNoStatic) {
+        report(FNSSL_LSTM_FAMILY_STATIC);
+        return rc;
+      }
     }
+    report(FNSSL_LSTM_FAMILY_GENERIC);
     p.chq = 0;
     p.pad = 0;
     if (vr.ring) choose_chunk(p.quads_per_slice, vr, p.chq, p.pad);
@@ -385,9 +430,15 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
   if (d->variant != 0 || H < 128) {
     const int variant = d->variant ? d->variant : default_variant(H);
     FNSSL_REQUIRE(variant >= 1 && variant <= kNumVariants, "lstm_forward: unknown variant %d", variant);
-    return launch_range(variant, 0, tasks);
+    const int rc = launch_range(variant, 0, tasks);
+    if (rounds && !guarded) *rounds = nlaunch;
+    return rc;
   }
-  if (const int forced = default_variant_override(H)) return launch_range(forced, 0, tasks);
+  if (const int forced = default_variant_override(H)) {
+    const int rc = launch_range(forced, 0, tasks);
+    if (rounds && !guarded) *rounds = nlaunch;
+    return rc;
+  }
 
   const int ncu = fnssl::device_cus();
   // ---- few sequences (a single utterance, a streaming chunk): several waves per 16-sequence group ------
@@ -399,12 +450,15 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     const Variant vr{nw, split == 4 ? 8 : 4, 1};
     choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, split);
     const int nwg = p.wgs_per_dir * d->ndir;
+    if (rounds) *rounds = 1;
     if (!p.carry && !(mode & kHas1)) {   // shape-specialised (ring-free) kernels for the network's own shapes
       const int rc = launch_split_static(p, H, nw, split, mode, 0, nwg, st);
+      if (rc != kNoStatic) report(FNSSL_LSTM_FAMILY_SPLIT_STATIC);
       if (rc != kNoStatic || static_only) return rc;
     } else if (static_only) {
       return kNoStatic;
     }
+    report(FNSSL_LSTM_FAMILY_SPLIT);
     return H == 128 ? launch_split_h<128>(split, p, mode, nwg, st) : launch_split_h<256>(split, p, mode, nwg, st);
   };
   {
@@ -446,7 +500,19 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) {
     if (rc != FNSSL_OK) return rc;
     t0 = t1;
   }
+  if (rounds && !guarded) *rounds = nlaunch;
   return FNSSL_OK;
+}
+
+extern "C" {
+
+int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream) { return lstm_forward_impl(d, stream, false, nullptr, nullptr); }
+
+int fnssl_lstm_plan(const fnssl_lstm_desc* d, int* family, int* rounds) {
+  FNSSL_REQUIRE(family, "lstm_plan: null pointer");
+  *family = 0;
+  if (rounds) *rounds = 1;
+  return lstm_forward_impl(d, nullptr, true, family, rounds);
 }
 
 }  // extern "C"

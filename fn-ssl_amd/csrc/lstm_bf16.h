@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bf16_kernel(const LstmParams p) 
 
 template <int H, int NW, int M, int NV0, int NV2, int CHQ, int PAD>
 int launch_bf16_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   const size_t lds = (size_t)2 * CHQ * 4096;
   static_assert(2 * CHQ * 4096 <= 160 * 1024, "ring does not fit the LDS");
   auto k = lstm_bf16_kernel<H, NW, M, NV0, NV2, CHQ, PAD>;

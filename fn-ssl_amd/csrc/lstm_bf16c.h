@@ -50,7 +50,6 @@ namespace fnssl_lstm {
 //                          76 clusters = 304 workgroups, i.e. two rounds)
 // "part" = one 32-sequence tile per wave; a wave cycles through its NP parts, so a part's h_t has NP - 1 part-times
 // to reach the other members.
-constexpr unsigned kClusterSpinLimit = 1u << 20;
 
 struct ClusterParams {
   char* hx;                 // [parity 2][cluster][part][sequence tile 8][block H/16][1 KiB]; parity 1 zeroed before the launch (h_{-1} = 0)
@@ -61,6 +60,8 @@ struct ClusterParams {
   int ncl;                  // clusters in this launch
   int cl_per_dir;
   int spread;               // test knob (FNSSL_CLUSTER_SPREAD=1): members of a cluster = CONSECUTIVE blocks, i.e. different XCDs
+  unsigned spin_limit;      // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
+  int stall_member;         // test knob: this member of the call's first cluster exits at once (-1: none)
 };
 
 // ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 8 no recurrent-operand loads,
@@ -92,6 +93,11 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   const int cg = cp.cl0 + cl_local;
   const int dir = cg / cp.cl_per_dir;
   const int cd = cg - dir * cp.cl_per_dir;
+  // Cooperative abort instead of a trap (include/fnssl.h, fnssl_lstm_forward): a wave whose wait runs out records a code in
+  // the status word and leaves at the end of its step; every other wave polls the word while it waits; a workgroup that
+  // starts late sees it at once.  The guarded pair-split launch of the same call then recomputes the layer.
+  if (__hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  if (cg == 0 && m == cp.stall_member) return;           // test knob: a member that never shows up
 
   const int lane = threadIdx.x & 63;
   const int n = lane & 31, hb = lane >> 5;
@@ -175,15 +181,21 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     tagv = __hip_atomic_load(tag_base + (pt * 8 + w) * 8 + (lane % CL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto tags_ready = [&](unsigned need) { return __builtin_amdgcn_ballot_w64(tagv < need) == 0; };
+  bool dead = false;              // wave-uniform: this wave has given up (or seen that another one has)
   auto wait_tags = [&](int pt, unsigned need) {
-    if (tags_ready(need)) return;
+    if (dead || tags_ready(need)) return;
     for (unsigned spins = 0;; ++spins) {
       __builtin_amdgcn_s_sleep(16);
       load_tags(pt);
       if (tags_ready(need)) return;
-      if (spins > kClusterSpinLimit) {
+      if (spins > cp.spin_limit) {
         if (lane == 0) __hip_atomic_store(cp.status, 0x10000u | (unsigned)(cg & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_trap();
+        dead = true;
+        return;
+      }
+      if ((spins & 63) == 63 && __hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        dead = true;
+        return;
       }
     }
   };
@@ -350,7 +362,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     }
   };
 
-  for (int step = 0; step < p.nsteps; ++step) static_for<NP>([&](auto pt) { part_step(pt, step); });
+  for (int step = 0; step < p.nsteps && !dead; ++step) static_for<NP>([&](auto pt) { part_step(pt, step); });
   pub_flush(NP - 1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -362,6 +374,9 @@ int launch_bf16c_k(const LstmParams& p, const ClusterParams& cp, hipStream_t st)
   auto k = lstm_bf16c_kernel<H, NB0, NB2, FLAGS, ABL, WG_, AD>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = 8 * CL * ((cp.ncl + 7) / 8);
+  // every member of every cluster of the launch must be resident at once (see launch_f32c_k)
+  if (!cluster_grid_fits(reinterpret_cast<const void*>(k), 512, lds, nwg)) return kNoCluster;
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   hipLaunchKernelGGL(k, dim3(nwg), dim3(512), lds, st, p, cp);
   FNSSL_CHECK_LAUNCH("lstm_bf16c_kernel");
   return FNSSL_OK;

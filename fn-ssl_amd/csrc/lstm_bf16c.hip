@@ -70,9 +70,13 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   cp.cl_per_dir = cl_per_dir;
   // placement is a speed matter only; the knob puts the members of a cluster on DIFFERENT XCDs so that tests can show it
   cp.spread = getenv("FNSSL_CLUSTER_SPREAD") ? 1 : 0;
+  cp.spin_limit = cluster_spin_limit();
+  cp.stall_member = cluster_test_stall();
   // status word + tags, and the parity-1 operand records (step 0 reads h_{-1} = 0 from them)
-  FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, head, st));
-  FNSSL_HIP(hipMemsetAsync(cp.hx + cp.parity_stride, 0, cp.parity_stride, st));
+  if (!p.dry) {
+    FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, head, st));
+    FNSSL_HIP(hipMemsetAsync(cp.hx + cp.parity_stride, 0, cp.parity_stride, st));
+  }
   for (int c0 = 0; c0 < ncl; c0 += per_launch) {
     cp.cl0 = c0;
     cp.ncl = ncl - c0 < per_launch ? ncl - c0 : per_launch;

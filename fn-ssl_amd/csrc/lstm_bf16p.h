@@ -35,6 +35,7 @@ namespace fnssl_lstm {
 // as 3; with NG = 5 it is 240 workgroups = ONE round (and the step's ring traffic serves 160 sequences instead of 64).
 template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false, bool ROTATE = false, int NG = 2>
 __global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p) {
+  FNSSL_GUARDED_KERNEL(p);
   constexpr int NT = H / 8, NTW = NT / 2, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
   constexpr int KP = KT / 2;                              // half a tile
   // ring granule = a QUARTER tile per role ("piece": KQ0, KP - KQ0, KQ0, KP - KQ0 records), one barrier per piece
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p
 
 template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NG = 2>
 int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
   // 7 slots where a workgroup owns its CU anyway; the 144-column full-band layer (6 KB slots) keeps 6 so that several
   // workgroups stay resident per CU

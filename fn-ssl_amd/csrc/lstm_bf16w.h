@@ -362,6 +362,7 @@ __global__ void __launch_bounds__((NW + NL) * 64) lstm_bf16w_kernel(const LstmPa
 
 template <int H, int NW, int NB0, int NB2, int FLAGS, int NSLOT, int NL, int ABL = 0>
 int launch_bf16w_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
   const size_t lds = (size_t)NSLOT * KT * 1024 + (size_t)NW * (H / 16) * 1024;
   auto k = lstm_bf16w_kernel<H, NW, NB0, NB2, FLAGS, NSLOT, NL, ABL>;
@@ -374,6 +375,6 @@ int launch_bf16w_k(const LstmParams& p, int nwg, hipStream_t st) {
 
 // kNoStatic when the shape / element types have no instantiation
 int launch_bf16w(const LstmParams& p, int H, int NW, int flags, int nwg, hipStream_t st);
-int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st);
+int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st, int* family = nullptr);
 
 }  // namespace fnssl_lstm

@@ -55,16 +55,29 @@ int launch_bf16p(const LstmParams& p, int H, int flags, int nwg, hipStream_t st)
 
 // One launch: every 32-sequence group of every direction.  Default: the pair-split kernels; FNSSL_BF16W_SOLO=1 keeps
 // the one-wave-per-group kernels of lstm_bf16w.h (A/B).
-int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st) {
+int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st, int* family) {
   const int ncu = fnssl::device_cus();
   const int groups = (p.nseq + 31) / 32;
   const long long total = (long long)groups * p.ndir;
   p.task0 = 0;
   p.task1 = groups;
   // cluster-resident kernel (lstm_bf16c.h) for the shape it is built for: weights stay in LDS, h_t is exchanged through L2
-  if (bf16c_handles(p, H, flags)) return forward_bf16c(p, H, flags, st);
+  // — followed by the pair-split launch below as its GUARDED fallback (include/fnssl.h, fnssl_lstm_forward)
+  bool guarded = false;
+  if (bf16c_handles(p, H, flags)) {
+    const int rc = forward_bf16c(p, H, flags, st);
+    if (rc == FNSSL_OK) {
+      if (family) *family = FNSSL_LSTM_FAMILY_BF16_CLUSTER;
+      if (p.dry) return FNSSL_OK;
+      guarded = true;
+      p.guard = reinterpret_cast<const unsigned*>(p.cluster_ws);
+    } else if (rc != kNoCluster) {
+      return rc;
+    }
+  }
   int rc;
-  if (!getenv("FNSSL_BF16W_SOLO")) {
+  if (!getenv("FNSSL_BF16W_SOLO") || guarded) {
+    if (family && !guarded) *family = FNSSL_LSTM_FAMILY_BF16_PAIR;
     // Two 32-sequence groups per workgroup.  lstm_bf16p_kernel takes NG groups (template), and 3 / 4 / 5 were built and
     // measured at config 3 (profiles/r03/h_bf16p_groups_per_workgroup.txt) in the hope of turning the full-band layers'
     // 600 workgroups (2.34 rounds run as 3) into 400 / 300 / 240: bit-identical, never faster (full-band layers 13.1 ms
@@ -75,6 +88,7 @@ int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st) {
     p.wgs_per_dir = (groups + ng - 1) / ng;
     rc = launch_bf16p(p, H, flags, p.wgs_per_dir * p.ndir, st);
   } else {
+    if (family) *family = FNSSL_LSTM_FAMILY_BF16_SOLO;
     const int nw = (total <= 2ll * ncu || H >= 256) ? 2 : 4;
     p.wgs_per_dir = (groups + nw - 1) / nw;
     rc = launch_bf16w(p, H, nw, flags, p.wgs_per_dir * p.ndir, st);

@@ -24,17 +24,23 @@
 namespace fnssl_lstm {
 
 constexpr int kF32cWaves = 16;   // four per SIMD (measured: 100.8 against 102.3 ms per layer with 12 = three per SIMD); 225 groups = 14 each + 1
-constexpr unsigned kF32cSpinLimit = 1u << 20;
 
 struct F32ClusterParams {
   unsigned* tags;       // [direction][cluster][group in cluster][member 8], zeroed before the launch
-  unsigned* status;
+  unsigned* status;     // one word, zeroed before the launch: 0 = fine, else the code of the first wave that gave up
   int clusters_per_dir;
   int groups_per_cluster;
+  unsigned spin_limit;  // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
+  int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
+  int prio_mode;        // experiment (FNSSL_F32C_PRIO): 1 static issue priority = the wave's rank on its SIMD, 2 matrix phase
+                        // above the gate phase, 3 gate phase above the matrix phase
 };
 
 // NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad (block 1); MODE: 0 or kSum
-template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2, int NW_ = kF32cWaves>
+// ABLRT = true: timing-ablation twin (make ABLATE=1 only, wrong results) driven by the bits of FNSSL_F32C_ABL at run time:
+//   1 one group's addressing for all, 2 cheap gates, 4 no tag waits, 8 no input loads, 16 no recurrent-operand loads,
+//   32 no stores, 64 no cell-state / residual loads, 128 no LDS record reads in the quads, 256 no tag loads / publishes
+template <int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
 __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
   constexpr int H = 128, NS = H / 16, NW = NW_;
   constexpr bool SUM = (MODE & kSum) != 0;
@@ -45,6 +51,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   constexpr int XD = NW_ > 12 ? 4 : 8;   // input ring: block v is requested XD - 1 quads (~3.6 k cycles) before its use — the other members have pushed it out of L2
   static_assert(!(NV0 && NS0) && (NV0 == 0 || NV0 % XD == 0), "block-only or remainder-only input");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ABL = ABLRT ? p.ablate : 0;
 
   const int b = blockIdx.x;
   const int m = (b >> 3) & 7;                                 // member = hidden slice
@@ -54,6 +61,12 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   const int ck = cl - dir * cp.clusters_per_dir;
   const int g0 = ck * cp.groups_per_cluster;
   const int g1 = g0 + cp.groups_per_cluster < p.ntasks ? g0 + cp.groups_per_cluster : p.ntasks;
+  // Cooperative abort instead of a trap (include/fnssl.h, fnssl_lstm_forward): a wave whose wait runs out records a code
+  // in the status word and leaves; every other wave polls that word while it waits and leaves as well; a workgroup that
+  // starts late (it was not resident) sees the word at once.  What the launch has written by then is garbage that the
+  // guarded fallback launch of the same call overwrites.
+  if (__hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  if (cl == 0 && m == cp.stall_member) return;                // test knob: a member that never shows up
 
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, g = lane >> 4;
@@ -120,6 +133,34 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   };
 
   if (g0 + w >= g1) return;                                   // (a wave without a group: nobody waits for it)
+  if (cp.prio_mode == 1) {                                    // the four waves of a SIMD (w, w + 4, w + 8, w + 12) get ranks 0..3
+    switch (w >> 2) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
+  }
+  if (cp.prio_mode == 4) {                                    // experiment: start the ranks a quarter of a group-step apart
+    for (int i = 0; i < 2 * (w >> 2); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  bool dead = false;                                          // wave-uniform: this wave has given up (or seen that another has)
+  // bounded wait for `ready()`; refreshes through `reload()`; false = gave up
+  auto bounded_wait = [&](auto ready, auto reload, int sleep, unsigned code) {
+    for (unsigned spins = 0; !ready(); ++spins) {
+      if (sleep == 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(16);
+      reload();
+      const bool out = spins > cp.spin_limit;
+      if (out || (spins & 63) == 63) {
+        if (out) {
+          if (lane == 0) __hip_atomic_store(cp.status, code | (unsigned)(cl & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return false;
+        }
+        if (__hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      }
+    }
+    return true;
+  };
   const bool single = g0 + w + NW >= g1;                      // one group per wave: its c_t is not written yet when the next
                                                               // group-step's requests go out, so c is requested at the top
   Grp cur, nxt;
@@ -130,16 +171,18 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   unsigned tagv = 0, tagd = 0;
   auto request = [&](const Grp& gr, rsrc_t qx0, rsrc_t qsk, bool with_c) {   // early requests of group-step gr
     const unsigned tt = tt_of(gr.step);
-    if constexpr (NV0 > 0)
-      static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
-    else
-      xs0 = bld1(qx0, gr.vo0, tt * st0);
-    if (SUM) skipv = bld4(qsk, gr.vok, tt * stk + 64 * m);
-    if (gr.step > 0) {
-      tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (with_c) cprev = bld4(rc_of(gr.task), vlane, m * 1024);
+    if (!(ABL & 8)) {
+      if constexpr (NV0 > 0)
+        static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
+      else
+        xs0 = bld1(qx0, gr.vo0, tt * st0);
     }
-    if (DRIFT > 0 && gr.task - DRIFT * NW >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
+    if (SUM && !(ABL & 64)) skipv = bld4(qsk, gr.vok, tt * stk + 64 * m);
+    if (gr.step > 0) {
+      if (!(ABL & 256)) tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (with_c && !(ABL & 64)) cprev = bld4(rc_of(gr.task), vlane, m * 1024);
+    }
+    if (DRIFT > 0 && !(ABL & 256) && gr.task - DRIFT * NW >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
       tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NW - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   cur.task = g0 + w;
@@ -156,41 +199,32 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     const unsigned op = (rev ? tt + 1 : tt - 1) * sto;         // row of h_{step - 1}
     const rsrc_t rc = rc_of(task);
     unsigned* const tag_g = tag_cl + (size_t)(task - g0) * 8;
-    if (single && step > 0) cprev = bld4(rc, vlane, m * 1024);
+    if (single && step > 0 && !(ABL & 64)) cprev = bld4(rc, vlane, m * 1024);
     const v4f cprev_cur = step > 0 ? cprev : zero4, skip_cur = skipv;
 
     // h_{step - 1} of the whole row: every member's slice, once all 8 tags show it
     v4f hold[NS];
     auto fetch_h = [&]() {
-      if (DRIFT > 0 && !(ABL & 4) && task - DRIFT * NW >= g0) {
+      if (DRIFT > 0 && !(ABL & 4) && !dead && task - DRIFT * NW >= g0) {
         unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NW - g0) * 8;
-        for (unsigned spins = 0; __builtin_amdgcn_ballot_w64(tagd < (unsigned)step + 1) != 0; ++spins) {
-          __builtin_amdgcn_s_sleep(8);
-          tagd = __hip_atomic_load(tag_d + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (spins > kF32cSpinLimit) {
-            if (lane == 0) __hip_atomic_store(cp.status, 0x40000u | (unsigned)(cl & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_trap();
-          }
-        }
+        dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagd < (unsigned)step + 1) == 0; },
+                             [&]() { tagd = __hip_atomic_load(tag_d + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 8, 0x40000u);
       }
-      if (step > 0) {
-        for (unsigned spins = 0; !(ABL & 4) && __builtin_amdgcn_ballot_w64(tagv < (unsigned)step) != 0; ++spins) {
-          __builtin_amdgcn_s_sleep(16);
-          tagv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (spins > kF32cSpinLimit) {
-            if (lane == 0) __hip_atomic_store(cp.status, 0x30000u | (unsigned)(cl & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_trap();
-          }
-        }
+      if (step > 0 && !(ABL & 16)) {
+        if (!(ABL & 4) && !dead)
+          dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagv < (unsigned)step) == 0; },
+                               [&]() { tagv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 16, 0x30000u);
 #pragma unroll
         for (int s = 0; s < NS; ++s) hold[s] = bld4_l2(ro, cur.voo, op + 64 * s);
       } else {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) hold[s] = zero4;
+        for (int s = 0; s < NS; ++s) hold[s] = (ABL & 16) ? cprev : zero4;   // (ablation: any live register value)
       }
     };
 
     // ---- matrix phase: record j of quad Q + 1 is read from LDS right after the MFMAs that used record j of quad Q
+    if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(2);
+    if (cp.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
     v4f acc[4];
     acc[0] = rec(0, 0);
     acc[1] = rec(0, 1);
@@ -204,19 +238,19 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       //  alone the scheduler sinks the reads next to their uses and every second MFMA group waits out an LDS round trip)
       MFMA4(acc, ra[0], b0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (Q + 1 < QPS) ra[0] = rec(Q + 1, 0);
+      if constexpr (Q + 1 < QPS) if (!(ABL & 128)) ra[0] = rec(Q + 1, 0);
       __builtin_amdgcn_sched_barrier(0);
       MFMA4(acc, ra[1], b1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (Q + 1 < QPS) ra[1] = rec(Q + 1, 1);
+      if constexpr (Q + 1 < QPS) if (!(ABL & 128)) ra[1] = rec(Q + 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       MFMA4(acc, ra[2], b2);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (Q + 1 < QPS) ra[2] = rec(Q + 1, 2);
+      if constexpr (Q + 1 < QPS) if (!(ABL & 128)) ra[2] = rec(Q + 1, 2);
       __builtin_amdgcn_sched_barrier(0);
       MFMA4(acc, ra[3], b3);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (Q + 1 < QPS) ra[3] = rec(Q + 1, 3);
+      if constexpr (Q + 1 < QPS) if (!(ABL & 128)) ra[3] = rec(Q + 1, 3);
       __builtin_amdgcn_sched_barrier(0);
     };
     auto quad1 = [&](auto qc, float b0) {   // remainder quad: one record
@@ -233,7 +267,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
         }
         const v4f xb = xr[V % XD];
         quad(ic<1 + V>{}, xb.x, xb.y, xb.z, xb.w);
-        if constexpr (V + XD < NV0) xr[V % XD] = bld4(rx0, cur.vo0, o0 + 64 * (V + XD));
+        if constexpr (V + XD < NV0) if (!(ABL & 8)) xr[V % XD] = bld4(rx0, cur.vo0, o0 + 64 * (V + XD));
       });
     } else {
       pub_flush();
@@ -245,7 +279,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     nxt.step = task + NW < g1 ? step : step + 1;
     const bool more = nxt.step < p.nsteps;
     if (more) {
-      if constexpr (ABL & 1) {   // timing ablation (wrong results): every group-step uses the first group's addressing
+      if (ABL & 1) {   // timing ablation (wrong results): every group-step uses the first group's addressing
         nxt.vo0 = cur.vo0; nxt.voo = cur.voo; nxt.vok = cur.vok; nxt.voo2 = cur.voo2; nxt.valid = cur.valid;
         nrx0 = rx0; nro = ro; nrsk = rsk; nro2 = ro2;
       } else {
@@ -269,8 +303,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     });
 
     // ---- cell update of my 16 units, stores, publish
+    if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
+    if (cp.prio_mode == 3) __builtin_amdgcn_s_setprio(2);
     v4f cn, hn;
-    if constexpr (ABL & 2) {     // timing ablation: cheap gates
+    if (ABL & 2) {     // timing ablation: cheap gates
       cn = acc[1] + cprev_cur + acc[0];
       hn = acc[3] + acc[2];
     } else {
@@ -282,17 +318,18 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       hn = mul_rn4(og, tanh4(cn));
     }
     asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
-    bst4(cn, rc, vlane, m * 1024);
-    if (cur.valid) {
+    if (ABL & 32) asm volatile("" ::"v"(cn), "v"(hn));
+    if (!(ABL & 32)) bst4(cn, rc, vlane, m * 1024);
+    if (cur.valid && !(ABL & 32)) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hn), ro, cur.voo, oo + 64 * m, 16);   // sc1: the hand-off
       if (SUM) bst4(add_rn4(hn, skip_cur), ro2, cur.voo2, oo + 64 * m);
     }
     asm volatile("" ::: "memory");
-    pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
+    if (!(ABL & 256)) pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
     asm volatile("" ::: "memory");
     pub_val = (unsigned)step + 1;
-    pub_tag = tag_g + m;
-    if (!more) break;
+    pub_tag = (ABL & 256) ? nullptr : tag_g + m;
+    if (!more || dead) break;
     cur = nxt;
     rx0 = nrx0;
     ro = nro;
@@ -303,15 +340,20 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NV0, int NS0, int MODE, int ABL = 0, int DRIFT = 2, int NW_ = kF32cWaves>
+template <int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
 int launch_f32c_k(const LstmParams& p, const F32ClusterParams& cp, hipStream_t st) {
   constexpr int QPS = 1 + NV0 + NS0 + 8;
   const size_t lds = (size_t)QPS * 4096;
-  auto k = lstm_f32c_kernel<NV0, NS0, MODE, ABL, DRIFT, NW_>;
+  auto k = lstm_f32c_kernel<NV0, NS0, MODE, ABLRT, DRIFT, NW_>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int ncl = cp.clusters_per_dir * p.ndir;
-  hipLaunchKernelGGL(k, dim3(64 * ((ncl + 7) / 8)), dim3(NW_ * 64), lds, st, p, cp);
+  const int nwg = 64 * ((ncl + 7) / 8);
+  // every member of every cluster must be resident at once: the grid may not exceed what the device says it can hold
+  // (the waits are bounded and the call carries a guarded fallback anyway — this only avoids a launch that cannot work)
+  if (!cluster_grid_fits(reinterpret_cast<const void*>(k), NW_ * 64, lds, nwg)) return kNoCluster;
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(NW_ * 64), lds, st, p, cp);
   FNSSL_CHECK_LAUNCH("lstm_f32c_kernel");
   return FNSSL_OK;
 }

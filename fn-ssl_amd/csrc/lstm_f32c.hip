@@ -30,25 +30,27 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
   cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
   cp.status = reinterpret_cast<unsigned*>(p.cluster_ws);
   cp.tags = reinterpret_cast<unsigned*>(p.cluster_ws + 256);
+  cp.spin_limit = cluster_spin_limit();
+  cp.stall_member = cluster_test_stall();
+  cp.prio_mode = env_int("FNSSL_F32C_PRIO", 1, 4);
   const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * 8 * sizeof(unsigned);
-  FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));
+  if (!p.dry) FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));
 #ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
-  if (mode == kSum) switch (env_int("FNSSL_F32C_ABL", 1, 7)) {
-      case 1: return launch_f32c_k<16, 0, kSum, 1>(p, cp, st);
-      case 2: return launch_f32c_k<16, 0, kSum, 2>(p, cp, st);
-      case 4: return launch_f32c_k<16, 0, kSum, 4>(p, cp, st);
-      case 7: return launch_f32c_k<16, 0, kSum, 7>(p, cp, st);
-      default: break;
-    }
+  if (const int abl = env_int("FNSSL_F32C_ABL", 1, 511)) {
+    p.ablate = abl;
+    if (mode == kSum) return launch_f32c_k<16, 0, kSum, true>(p, cp, st);
+    if (p.c0 == 4) return launch_f32c_k<0, 1, 0, true>(p, cp, st);
+  }
+  p.ablate = 0;
 #endif
   if (p.c0 == 4) return launch_f32c_k<0, 1, 0>(p, cp, st);
   if (mode == kSum) switch (env_int("FNSSL_F32C_DRIFT", 1, 4)) {   // experiment knob
-      case 1: return launch_f32c_k<16, 0, kSum, 0, 1>(p, cp, st);
-      case 3: return launch_f32c_k<16, 0, kSum, 0, 3>(p, cp, st);
-      case 4: return launch_f32c_k<16, 0, kSum, 0, 4>(p, cp, st);
+      case 1: return launch_f32c_k<16, 0, kSum, false, 1>(p, cp, st);
+      case 3: return launch_f32c_k<16, 0, kSum, false, 3>(p, cp, st);
+      case 4: return launch_f32c_k<16, 0, kSum, false, 4>(p, cp, st);
       default: break;
     }
-  if (mode == kSum && getenv("FNSSL_F32C_W12")) return launch_f32c_k<16, 0, kSum, 0, 2, 12>(p, cp, st);   // A/B: three waves per SIMD
+  if (mode == kSum && getenv("FNSSL_F32C_W12")) return launch_f32c_k<16, 0, kSum, false, 2, 12>(p, cp, st);   // A/B: three waves per SIMD
   if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
   return launch_f32c_k<16, 0, 0>(p, cp, st);
 }

@@ -42,7 +42,22 @@ struct LstmParams {
   int quads_per_slice;
   int chq, pad;   // ring chunk (quads) and per-slice padding (quads); 0 for direct variants
   int ablate;     // timing experiments only (env FNSSL_ABLATE): bit flags, see lstm_rec_kernel
+  // Guarded fallback launch (behind a cluster-resident kernel of the same call): when non-null the kernel runs only if
+  // *guard != 0, i.e. only if the cluster kernel gave up on a hand-off; block 0 then counts the layer in *fallback_count.
+  const unsigned* guard = nullptr;
+  unsigned* fallback_count = nullptr;
+  int dry = 0;    // host only (fnssl_lstm_plan): the launch templates return without launching
+  int prio_mode = 0;   // experiment (FNSSL_STATIC_PRIO): 1 = static issue priority by the wave's rank on its SIMD
 };
+
+// first statement of every kernel that can be a guarded fallback (uniform for the whole grid: nobody reaches a barrier)
+#define FNSSL_GUARDED_KERNEL(P)                                                                            \
+  do {                                                                                                     \
+    if ((P).guard) {                                                                                       \
+      if (__hip_atomic_load((P).guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;           \
+      if ((P).fallback_count && blockIdx.x == 0 && threadIdx.x == 0 && (P).task0 == 0) atomicAdd((P).fallback_count, 1u); \
+    }                                                                                                      \
+  } while (0)
 
 // cluster-resident bf16 kernels (lstm_bf16c.h): geometry, shared by the kernels and the workspace sizing
 __host__ __device__ constexpr int cluster_members(int H) { return H == 256 ? 8 : 4; }        // CUs per cluster (4 gate-row tiles each)
@@ -297,6 +312,7 @@ struct WStream<NW, M, 1> {
 // them re-read the complete h_{t-1} from the output tensor after a workgroup barrier at the step end.
 template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false, int SPLIT = 1>
 __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_rec_kernel(const LstmParams p) {
+  FNSSL_GUARDED_KERNEL(p);
   // (4-wave workgroups are what small launches use, several per CU: keep them at >= 3 waves per SIMD)
   constexpr int NS = H / 16;
   constexpr int NSL = NS / SPLIT;   // slices per wave
@@ -567,6 +583,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 ? 3 : 1)) lstm_rec_kernel(co
 // ---- launcher ----------------------------------------------------------------
 template <int H, int NW, int M, int WMODE, int MODE, bool ABL = false, int SPLIT = 1>
 int launch_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   const size_t lds = WMODE ? (size_t)2 * p.chq * SPLIT * 4096 : 0;
   auto k = lstm_rec_kernel<H, NW, M, WMODE, MODE, ABL, SPLIT>;
   if (lds > 48 * 1024)

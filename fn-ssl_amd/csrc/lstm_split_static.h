@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_sp
 template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool DIRECT = false,
           int NV2 = 0>
 int launch_split_static_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   const size_t lds = DIRECT ? 0 : (size_t)2 * CHQ * SPLIT * 4096;
   static_assert(2 * CHQ * SPLIT * 4096 <= 160 * 1024, "ring does not fit the LDS");
   auto k = lstm_split_static_kernel<H, NW, M, SPLIT, NV0, NS0, NS2, CHQ, PAD, MODE, DIRECT, NV2>;

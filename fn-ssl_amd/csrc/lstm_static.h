@@ -37,6 +37,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
           bool STAG = false, int NV2 = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p) {
+  FNSSL_GUARDED_KERNEL(p);
   constexpr int NS = H / 16;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
   static_assert(!(MODE & kHas1), "static kernel: single summed input only");
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
 template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
           bool STAG = false, int NV2 = 0>
 int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   const size_t lds = (size_t)(STAG ? 3 : 2) * CHQ * 4096;
   static_assert((STAG ? 3 : 2) * CHQ * 4096 <= 160 * 1024, "ring does not fit the LDS");
   auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL, XD, STAG, NV2>;
@@ -297,6 +299,29 @@ int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
 
 // Return kNoStatic when no specialisation exists for (c0, c2, mode, NW).
 constexpr int kNoStatic = -100;
+// Returned by the cluster-kernel launchers when the device cannot hold every member workgroup at once (occupancy
+// query): the caller runs the per-wave / pair-split kernels instead, unguarded.
+constexpr int kNoCluster = -101;
+
+// Test / tuning knobs of the cluster kernels' bounded waits: FNSSL_CLUSTER_SPIN_LIMIT (spins before a wave gives up),
+// FNSSL_CLUSTER_TEST_STALL=m (member m of cluster 0 exits at once, as if it never became resident).
+inline unsigned cluster_spin_limit() {
+  const int v = env_int("FNSSL_CLUSTER_SPIN_LIMIT", 1, 1 << 30);
+  return v ? (unsigned)v : (1u << 20);
+}
+// blocks the device can hold at once for this kernel (occupancy query x CUs) >= grid?  One query per call: cheap (host only).
+inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int grid) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return (long long)per_cu * fnssl::device_cus() >= grid;
+}
+inline int cluster_test_stall() {
+  const char* e = getenv("FNSSL_CLUSTER_TEST_STALL");
+  return e ? atoi(e) : -1;
+}
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static2_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static2.h, pair-interleaved stream

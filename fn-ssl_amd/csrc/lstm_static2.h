@@ -14,8 +14,11 @@
 
 namespace fnssl_lstm {
 
-template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE, int XD = 4>
+// ABL = true: timing-ablation twin (make ABLATE=1 only, wrong results), bits of FNSSL_ABLATE: 1 no x loads, 2 cheap gates,
+// 4 no stores, 8 no ring barrier, 16 no c / skip loads, 32 no h reload, 64 no LDS record reads, 128 no weight staging
+template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE, int XD = 4, bool ABL = false>
 __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams p) {
+  FNSSL_GUARDED_KERNEL(p);
   constexpr int NS = H / 16, NP = NS / 2;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
   static_assert(!(MODE & kHas1) && HAS2 == (NS2 > 0) && NS % 2 == 0, "modes");
@@ -52,6 +55,14 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
   const unsigned sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
   const unsigned vlane = lane * 16;
   const bool rev = dir == 1;
+  const int abl = ABL ? p.ablate : 0;
+  if (p.prio_mode == 1) {   // waves w, w + 4, w + 8 share a SIMD
+    switch (w >> 2) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: break;
+    }
+  }
 
   // ---- weight ring (2 slots of CHQ pair-quads = 8 CHQ records) ------------------------------------------------
   char* const lds_rd = smem + lane * 16;
@@ -64,7 +75,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       const int r = w + m * NW;
-      if (r < CH && src_vq * 8 + r < QPS * 8) stg[m] = bld4(rw, vlane, (unsigned)(src_rec + r) * 1024u);
+      if (r < CH && src_vq * 8 + r < QPS * 8 && !(abl & 128)) stg[m] = bld4(rw, vlane, (unsigned)(src_rec + r) * 1024u);
     }
     src_vq += CHQ;
     src_rec += CH;
@@ -77,16 +88,25 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
   auto stage_write = [&]() {
 #pragma unroll
     for (int m = 0; m < M; ++m)
-      if (w + m * NW < CH) *reinterpret_cast<v4f*>(lds_wr + wslot * (CH * 1024) + m * (NW * 1024)) = stg[m];
+      if (w + m * NW < CH && !(abl & 128)) *reinterpret_cast<v4f*>(lds_wr + wslot * (CH * 1024) + m * (NW * 1024)) = stg[m];
     wslot ^= 1;
   };
-  auto sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto sync = [&]() {
+    if (ABL && (abl & 8))
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
   issue_loads();
   stage_write();
   sync();
   issue_loads();
   const char* cb = lds_rd;
-  auto rec = [&](auto ql, int j) { return *reinterpret_cast<const v4f*>(cb + decltype(ql)::value * 8192 + j * 1024); };
+  v4f rec_const = v4f{1e-3f, -1e-3f, 2e-3f, -2e-3f};
+  auto rec = [&](auto ql, int j) {
+    if (ABL && (abl & 64)) return rec_const;
+    return *reinterpret_cast<const v4f*>(cb + decltype(ql)::value * 8192 + j * 1024);
+  };
   v4f a0 = rec(ic<0>{}, 0), a1 = rec(ic<0>{}, 1);
 
   v4f hold[NS];
@@ -158,7 +178,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
     const unsigned o0 = tt * st0, o2 = tt * st2, oo = (tt + cy) * sto, ok = tt * stk;
     float xs2 = 0.f;
     if (NS2) xs2 = bld1(rx2, vo2, o2);
-    if (step > 0 || cy) {
+    if ((step > 0 || cy) && !(abl & 32)) {
       const unsigned op = (rev ? tt + 1 : tt - 1 + cy) * sto;
 #pragma unroll
       for (int s = 0; s < NS; ++s) hold[s] = bld4(ro, voo, op + 64 * s);
@@ -183,18 +203,20 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
         constexpr int V = decltype(v)::value;
         const v4f xb = xr[V % XD];
         SQUAD2(1 + V, xb.x, xb.y, xb.z, xb.w);
-        if constexpr (V + XD < NV0)
-          xr[V % XD] = bld4(rx0, vo0, o0 + 64 * (V + XD));
-        else
-          xr[V % XD] = bld4(rx0, vo0, nx + 64 * (V + XD - NV0));   // wraps into the next pair
+        if (!(abl & 1)) {
+          if constexpr (V + XD < NV0)
+            xr[V % XD] = bld4(rx0, vo0, o0 + 64 * (V + XD));
+          else
+            xr[V % XD] = bld4(rx0, vo0, nx + 64 * (V + XD - NV0));   // wraps into the next pair
+        }
       });
       if constexpr (NS2 > 0) SQUAD2_1(1 + NV0, xs2);
       static_for<NS>([&](auto sp) {
         constexpr int SP = decltype(sp)::value;
         SQUAD2(1 + NV0 + NS2 + SP, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
         if constexpr (SP == NS - 4) {      // cell state / residual operand of the first slice: four quads ahead of their use
-          if (step > 0 || cy) cprev0 = bld4(rc, vlane, s0 * 1024);
-          if (SUM) skip0 = bld4(rsk, vok, ok + 64 * s0);
+          if ((step > 0 || cy) && !(abl & 16)) cprev0 = bld4(rc, vlane, s0 * 1024);
+          if (SUM && !(abl & 16)) skip0 = bld4(rsk, vok, ok + 64 * s0);
         }
       });
       static_for<PAD>([&](auto u) {
@@ -203,25 +225,31 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
       });
       // cell updates of the two slices
       {
-        const v4f ig = sigmoid4(acc[0]), fg = sigmoid4(acc[1]), gg = tanh4(acc[2]), og = sigmoid4(acc[3]);
-        if (step > 0 || cy) cprev1 = bld4(rc, vlane, s0 * 1024 + 1024);   // in flight under the first slice's gate math
-        if (SUM) skip1 = bld4(rsk, vok, ok + 64 * s0 + 64);
-        const v4f cn = cell4(fg, cprev0, ig, gg);
-        v4f hn = mul_rn4(og, tanh4(cn));
+        const bool cheap = ABL && (abl & 2);
+        const v4f ig = cheap ? acc[0] : sigmoid4(acc[0]), fg = cheap ? acc[1] : sigmoid4(acc[1]);
+        const v4f gg = cheap ? acc[2] : tanh4(acc[2]), og = cheap ? acc[3] : sigmoid4(acc[3]);
+        if ((step > 0 || cy) && !(abl & 16)) cprev1 = bld4(rc, vlane, s0 * 1024 + 1024);   // in flight under the first slice's gate math
+        if (SUM && !(abl & 16)) skip1 = bld4(rsk, vok, ok + 64 * s0 + 64);
+        const v4f cn = cheap ? fg + cprev0 + ig : cell4(fg, cprev0, ig, gg);
+        v4f hn = cheap ? og + gg : mul_rn4(og, tanh4(cn));
         asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
-        bst4(cn, rc, vlane, s0 * 1024);
-        if (valid) {
+        if (abl & 4) asm volatile("" ::"v"(cn), "v"(hn));
+        if (!(abl & 4)) bst4(cn, rc, vlane, s0 * 1024);
+        if (valid && !(abl & 4)) {
           bst4(hn, ro, voo, oo + 64 * s0);
           if (SUM) bst4(add_rn4(hn, skip0), ro2, voo2, oo + 64 * s0);
         }
       }
       {
-        const v4f ig = sigmoid4(acd[0]), fg = sigmoid4(acd[1]), gg = tanh4(acd[2]), og = sigmoid4(acd[3]);
-        const v4f cn = cell4(fg, cprev1, ig, gg);
-        v4f hn = mul_rn4(og, tanh4(cn));
+        const bool cheap = ABL && (abl & 2);
+        const v4f ig = cheap ? acd[0] : sigmoid4(acd[0]), fg = cheap ? acd[1] : sigmoid4(acd[1]);
+        const v4f gg = cheap ? acd[2] : tanh4(acd[2]), og = cheap ? acd[3] : sigmoid4(acd[3]);
+        const v4f cn = cheap ? fg + cprev1 + ig : cell4(fg, cprev1, ig, gg);
+        v4f hn = cheap ? og + gg : mul_rn4(og, tanh4(cn));
         asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));
-        bst4(cn, rc, vlane, s0 * 1024 + 1024);
-        if (valid) {
+        if (abl & 4) asm volatile("" ::"v"(cn), "v"(hn));
+        if (!(abl & 4)) bst4(cn, rc, vlane, s0 * 1024 + 1024);
+        if (valid && !(abl & 4)) {
           bst4(hn, ro, voo, oo + 64 * s0 + 64);
           if (SUM) bst4(add_rn4(hn, skip1), ro2, voo2, oo + 64 * s0 + 64);
         }
@@ -232,11 +260,12 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
 #undef SQUAD2_1
 }
 
-template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE, int XD = 4>
+template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE, int XD = 4, bool ABL = false>
 int launch_static2_k(const LstmParams& p, int nwg, hipStream_t st) {
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   const size_t lds = (size_t)2 * CHQ * 8192;
   static_assert(2 * CHQ * 8192 <= 160 * 1024, "ring does not fit the LDS");
-  auto k = lstm_static2_kernel<H, NW, M, NV0, NS2, CHQ, PAD, MODE, XD>;
+  auto k = lstm_static2_kernel<H, NW, M, NV0, NS2, CHQ, PAD, MODE, XD, ABL>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3(NW * 64), lds, st, p);

@@ -48,7 +48,7 @@ char g_select[64] = "";   // non-empty: only launches with this name are bracket
 
 TimedLaunch::TimedLaunch(const char* name, hipStream_t s, double flops)
     : name_(name), s_(s), flops_(flops) {
-  if (!g_timing) return;
+  if (!g_timing || !name) return;
   if (g_select[0] && std::strcmp(g_select, name) != 0) return;
   if (hipEventCreate(&e0_) != hipSuccess) {
     e0_ = nullptr;
@@ -71,7 +71,43 @@ TimedLaunch::~TimedLaunch() {
 
 }  // namespace fnssl
 
+namespace {
+typedef float peak_v4f __attribute__((ext_vector_type(4)));
+// The box's own fp32-MFMA ceiling: nothing but v_mfma_f32_16x16x4_f32 on four independent accumulators per wave
+// (dependent latency 40 cycles < 4 x 32 cycles of issue), `wps` waves per SIMD on every CU.  bench.py times it with
+// HIP events and reports it as roofline.peak_measured, so that a 2 % difference between two boxes (clock, power
+// budget) cannot hide or fake a 2 % kernel gain.
+__global__ void __launch_bounds__(256) mfma_f32_peak_kernel(float* out, int iters) {
+  const int lane = threadIdx.x & 63;
+  peak_v4f acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = peak_v4f{0.f, 0.f, 0.f, 0.f};
+  float a = 1.0f + 0.001f * lane, b = 0.5f - 0.002f * lane;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, acc[3], 0, 0, 0);
+    }
+    asm volatile("" : "+v"(a), "+v"(b));   // keep the loop a loop
+  }
+  const peak_v4f r = acc[0] + acc[1] + acc[2] + acc[3];
+  out[(size_t)blockIdx.x * 256 + threadIdx.x] = r.x + r.y + r.z + r.w;
+}
+}  // namespace
+
 extern "C" {
+
+int fnssl_mfma_f32_peak(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop, void* stream) {
+  FNSSL_REQUIRE(out && flop && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8, "mfma_f32_peak: bad arguments");
+  const int nblk = fnssl::device_cus() * waves_per_simd;
+  FNSSL_REQUIRE(out_floats >= (size_t)nblk * 256, "mfma_f32_peak: out needs %zu floats", (size_t)nblk * 256);
+  hipLaunchKernelGGL(mfma_f32_peak_kernel, dim3(nblk), dim3(256), 0, fnssl::as_stream(stream), out, iters);
+  FNSSL_CHECK_LAUNCH("mfma_f32_peak_kernel");
+  *flop = (double)nblk * 4 * (double)iters * 64 * (2.0 * 16 * 16 * 4);
+  return FNSSL_OK;
+}
 
 int fnssl_abi_version(void) { return FNSSL_ABI_VERSION; }
 

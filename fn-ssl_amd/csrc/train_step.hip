@@ -228,7 +228,7 @@ Plan make_plan(const fnssl_train* t, int nbp, int nf, int nt) {
     if (w3 > pl.wgrad_bytes) pl.wgrad_bytes = w3;
     pl.res_bytes[l] = fnssl_lstm_reserve_bytes(nseq, L.hidden, L.ndir, nsteps);
     pl.res[l] = take(pl.res_bytes[l]);
-    const size_t w1 = fnssl_lstm_workspace_bytes(nseq, L.hidden, L.ndir), w2 = fnssl_lstm_bwd_workspace_bytes(nseq, L.hidden, L.ndir);
+    const size_t w1 = fnssl_lstm_workspace_bytes_ex(nseq, L.hidden, L.ndir, FNSSL_PRECISION_FP32), w2 = fnssl_lstm_bwd_workspace_bytes(nseq, L.hidden, L.ndir);
     if (w1 > pl.lstm_ws_bytes) pl.lstm_ws_bytes = w1;
     if (w2 > pl.bwd_ws_bytes) pl.bwd_ws_bytes = w2;
     for (int d = 0; d < L.ndir; ++d) {

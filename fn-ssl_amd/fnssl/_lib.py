@@ -18,16 +18,22 @@ import torch  # noqa: F401  (must be loaded before the library, see module docst
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
+# development only: FNSSL_LIB_PATH loads another build of the SAME library (e.g. csrc/libfnssl_hip_abl.so, the
+# `make ABLATE=1` build with the timing-ablation twins) — never a different implementation, never a fallback
+LIB_PATH = os.environ.get("FNSSL_LIB_PATH", LIB_PATH)
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 CH_MODE = {"M": 0, "MM": 1}
+# kernel families fnssl_lstm_plan reports (include/fnssl.h: FNSSL_LSTM_FAMILY_*)
+LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2", 4: "split", 5: "split_static", 6: "f32_cluster",
+               7: "f32_cluster256", 8: "bf16", 9: "bf16_solo", 10: "bf16_pair", 11: "bf16_cluster", 12: "train"}
 
 # every symbol include/fnssl.h declares
 SYMBOLS = [
     "fnssl_abi_version", "fnssl_last_error", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
     "fnssl_num_frames_ex", "fnssl_stft_ex", "fnssl_array_frontend",
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
-    "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_plan_rounds", "fnssl_lstm_forward", "fnssl_lstm_cluster_status", "fnssl_head", "fnssl_linear",
+    "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_workspace_bytes_ex", "fnssl_lstm_plan_rounds", "fnssl_lstm_plan", "fnssl_lstm_forward", "fnssl_lstm_cluster_status", "fnssl_head", "fnssl_linear",
     "fnssl_ipd2doa", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features", "fnssl_conv3x3_packed_floats_bf16", "fnssl_conv3x3_pack_bf16",
     "fnssl_conv3x3_causal_bf16", "fnssl_conv3x3_causal_bf16a",
@@ -36,7 +42,7 @@ SYMBOLS = [
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
     "fnssl_lstm_backward", "fnssl_lstm_weight_grads_workspace_bytes", "fnssl_lstm_weight_grads", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
-    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select",
+    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select", "fnssl_mfma_f32_peak",
     "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
     "fnssl_train_create", "fnssl_train_destroy", "fnssl_train_param_floats", "fnssl_train_param_offset",
     "fnssl_train_map_bytes", "fnssl_train_upload_maps", "fnssl_train_workspace_bytes", "fnssl_train_backward",
@@ -65,6 +71,7 @@ class LstmDesc(C.Structure):
         ("carry_state", C.c_int),
         ("precision", C.c_int),
         ("f32_mask", C.c_int),
+        ("fallback_count", C.c_void_p),
     ]
 
 
@@ -175,6 +182,8 @@ def load():
     lib.fnssl_lstm_pack.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     lib.fnssl_lstm_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_lstm_workspace_bytes.restype = sz
+    lib.fnssl_lstm_workspace_bytes_ex.argtypes = [i, i, i, i]
+    lib.fnssl_lstm_workspace_bytes_ex.restype = sz
     lib.fnssl_lstm_forward.argtypes = [C.POINTER(LstmDesc), vp]
     lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
     lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
@@ -194,6 +203,8 @@ def load():
     lib.fnssl_lstm_bwd_workspace_bytes.restype = sz
     lib.fnssl_lstm_backward.argtypes = [C.POINTER(LstmBwdDesc), vp]
     lib.fnssl_lstm_plan_rounds.argtypes = [i, i, i, i, vp, i]
+    lib.fnssl_lstm_plan.argtypes = [C.POINTER(LstmDesc), vp, vp]
+    lib.fnssl_mfma_f32_peak.argtypes = [vp, sz, i, i, vp, vp]
     lib.fnssl_lstm_cluster_status.argtypes = [vp, sz, i, i, i, vp, vp]
     lib.fnssl_lstm_weight_grads_workspace_bytes.argtypes = [ll, i, i, i, i]
     lib.fnssl_lstm_weight_grads_workspace_bytes.restype = sz

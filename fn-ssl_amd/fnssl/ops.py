@@ -342,8 +342,13 @@ def release_workspaces():
 
 @on_device
 def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
-               reserve=None, carry_workspace=None, carry=False, bf16=False, wide=False):
+               reserve=None, carry_workspace=None, carry=False, bf16=False, wide=False, fallback_count=None, plan_only=False):
     """One (bi)LSTM layer over strided views.
+
+    ``fallback_count`` (optional 1-element int32 device tensor, caller-zeroed): counts the layers whose cluster-resident
+    kernel gave up on a hand-off and were recomputed by the guarded fallback kernels of the same call (results are
+    correct either way).  ``plan_only=True`` launches nothing and returns ``(family, rounds)`` — the kernel family
+    ``fnssl_lstm_forward`` takes for exactly this call (``_lib.LSTM_FAMILY`` names), see ``lstm_plan``.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
     x0 (+ x1) is the summed input, x2 the concatenated one (either may be None); all are logical
@@ -405,7 +410,8 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     d.wpack[0] = packed[0].data_ptr()
     d.wpack[1] = packed[1].data_ptr() if ndir == 2 else 0
     lib = _lib.load()
-    wsb = lib.fnssl_lstm_workspace_bytes(d.nseq, hidden, ndir)
+    precision = (2 if wide else 1) if bf16 else 0
+    wsb = lib.fnssl_lstm_workspace_bytes_ex(d.nseq, hidden, ndir, precision)
     if carry_workspace is not None:
         _need_dev(carry_workspace)
         if carry_workspace.numel() * 4 < wsb:
@@ -418,7 +424,7 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
         ws = _workspace(wsb, out.device, "lstm")
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     d.variant = variant
-    d.precision = (2 if wide else 1) if bf16 else 0
+    d.precision = precision
     if wide:
         if not bf16:
             raise RuntimeError("fnssl.lstm_layer: wide=True is a bf16 mode")
@@ -428,16 +434,53 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     if reserve is not None:
         _need_dev(reserve)
         d.reserve, d.reserve_bytes = reserve.data_ptr(), reserve.numel() * 4
+    if fallback_count is not None:
+        if not isinstance(fallback_count, torch.Tensor) or not fallback_count.is_cuda or fallback_count.dtype != torch.int32 \
+                or fallback_count.numel() < 1:
+            raise RuntimeError("fnssl.lstm_layer: fallback_count must be an int32 device tensor")
+        d.fallback_count = fallback_count.data_ptr()
+    if plan_only:
+        fam, rounds = C.c_int(0), C.c_int(0)
+        check(lib.fnssl_lstm_plan(C.byref(d), C.byref(fam), C.byref(rounds)), "lstm_plan")
+        return _lib.LSTM_FAMILY.get(int(fam.value), "unknown(%d)" % fam.value), int(rounds.value)
     check(lib.fnssl_lstm_forward(C.byref(d), _stream()), "lstm_forward")
     return out
 
 
-def lstm_cluster_status(nseq: int, hidden: int, ndir: int, device=None) -> int:
-    """Status word the cluster-resident bf16 LSTM kernels leave in the current stream's LSTM workspace (0 = every hand-off
-    arrived; see fnssl_lstm_cluster_status).  `nseq, hidden, ndir` as in the lstm_layer call that used the workspace."""
+def lstm_plan(*args, **kwargs):
+    """``(family, rounds)`` of the ``lstm_layer`` call with the same arguments: which kernel family the library would
+    launch on this device with the current environment, without launching anything (fnssl_lstm_plan)."""
+    kwargs["plan_only"] = True
+    return lstm_layer(*args, **kwargs)
+
+
+def mfma_f32_peak(iters: int = 20000, waves_per_simd: int = 2, reps: int = 3, device=None) -> float:
+    """The device's own fp32-MFMA ceiling in TFLOP/s (fnssl_mfma_f32_peak timed with HIP events on the current stream;
+    best of ``reps``): the calibration bench.py reports as roofline.peak_measured."""
     lib = _lib.load()
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    ws = _workspace(lib.fnssl_lstm_workspace_bytes(nseq, hidden, ndir), device, "lstm")
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    out = torch.empty(ncu * waves_per_simd * 256, dtype=torch.float32, device=device)
+    best = 0.0
+    for r in range(reps + 1):
+        flop = C.c_double(0.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.fnssl_mfma_f32_peak(out.data_ptr(), out.numel(), iters, waves_per_simd, C.byref(flop), _stream()), "mfma_f32_peak")
+        e1.record()
+        e1.synchronize()
+        if r > 0:   # (the first launch carries the code-object load)
+            best = max(best, flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
+def lstm_cluster_status(nseq: int, hidden: int, ndir: int, device=None) -> int:
+    """Status word the cluster-resident LSTM kernels left in the current stream's LSTM workspace (0 = every hand-off
+    arrived; otherwise the layer was recomputed by the guarded fallback kernels of the same call — see
+    fnssl_lstm_cluster_status).  `nseq, hidden, ndir` as in the lstm_layer call that used the workspace."""
+    lib = _lib.load()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _workspace(lib.fnssl_lstm_workspace_bytes_ex(nseq, hidden, ndir, 0), device, "lstm")   # (the cached buffer: never shrinks)
     out = C.c_uint(0xffffffff)
     check(lib.fnssl_lstm_cluster_status(ws.data_ptr(), ws.numel(), nseq, hidden, ndir, _stream(), C.byref(out)),
           "lstm_cluster_status")
@@ -446,7 +489,7 @@ def lstm_cluster_status(nseq: int, hidden: int, ndir: int, device=None) -> int:
 
 def lstm_state_workspace(nseq: int, hidden: int, device):
     """Persistent per-layer cell-state buffer for streaming (uni-directional) LSTM calls."""
-    n = _lib.load().fnssl_lstm_workspace_bytes(nseq, hidden, 1)
+    n = _lib.load().fnssl_lstm_workspace_bytes_ex(nseq, hidden, 1, 0)
     return torch.zeros((n + 3) // 4, dtype=torch.float32, device=device)
 
 

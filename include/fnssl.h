@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 15
+#define FNSSL_ABI_VERSION 16
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -165,6 +165,10 @@ typedef struct {
    * fp32, clear = bf16 (then the pointer addresses 2-byte elements; view strides always count ELEMENTS and must be
    * multiples of 8 for bf16 tensors).                                                                  */
   int f32_mask;
+  /* optional DEVICE counter (caller-owned, caller-zeroed; NULL to disable): incremented once per layer whose
+   * cluster-resident kernel gave up on a hand-off and was re-run by the per-wave / pair-split kernels (see
+   * fnssl_lstm_forward).  Read it asynchronously whenever convenient: results are correct either way.      */
+  unsigned* fallback_count;
 } fnssl_lstm_desc;
 
 #define FNSSL_PRECISION_FP32 0
@@ -201,17 +205,49 @@ int fnssl_lstm_pack(const float* w_ih, const float* w_hh, const float* b_ih, con
  * (status word, tags, two parities of h_t operand records: 0.5 / 0.4 MiB per 512 / 768 sequences).  One workspace per stream:
  * two calls in flight must not share it. */
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir);
+/* The same for one `precision` (fnssl_lstm_desc.precision) — what fnssl_lstm_forward actually checks: fp32 calls need only
+ * the status word and 8 tag words per 16-sequence group of the cluster-resident fp32 kernel (~2 B per sequence) where the
+ * bf16 "wide" calls need ~513 B per sequence; training / streaming / per-stream caches should size with this one. */
+size_t fnssl_lstm_workspace_bytes_ex(int nseq, int hidden, int ndir, int precision);
 
 /* Host-only query of the launch planner of fnssl_lstm_forward (full-chip fp32 launches, hidden 128 / 256): the rounds
  * (one launch each, one workgroup of waves_per_wg[i] waves per CU) it runs for nseq sequences per direction on ncu CUs.
  * Returns the number of rounds (waves_per_wg gets min(rounds, cap) entries) or a negative status. */
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap);
 
+/*
+ * The layer.  Never traps and never leaves a wrong result behind: the cluster-resident kernels (lstm_f32c.h,
+ * lstm_bf16c.h) need every member workgroup of a cluster resident at the same time, which a shared, partitioned or
+ * otherwise busy device may not grant; a member that waits ~1.5 s (FNSSL_CLUSTER_SPIN_LIMIT spins) for a hand-off
+ * records a code in the call's status word, every workgroup of the launch drains and exits, and the SAME call has
+ * already enqueued the per-wave rounds / pair-split kernels behind it, guarded by that word: they return at once when
+ * it is 0 and otherwise recompute the whole layer (same bits as the cluster kernel).  Before launching, the grid is
+ * checked against the occupancy the device reports; a cluster kernel that cannot be co-resident is not launched.
+ * Returns FNSSL_OK or a negative status (invalid descriptor, workspace, HIP launch error) with fnssl_last_error().
+ */
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
 
-/* Status word of the cluster-resident bf16 kernels in a workspace that fnssl_lstm_forward has used with the same
- * (nseq, hidden, ndir): 0 = fine; 0x1nnnn = a wave of cluster nnnn waited ~2 s for a hand-off tag that never came (the
- * kernel traps after recording it, so the launch itself has already failed loudly).  Synchronises with `stream`. */
+/* Which kernel family fnssl_lstm_forward(d) takes on the current device with the current environment (host-only,
+ * launches nothing).  Tests assert it, so that "cluster kernel == rounds" comparisons cannot silently compare the
+ * rounds with the rounds.  *rounds (optional) = number of launches of the family (planner rounds; 1 otherwise). */
+#define FNSSL_LSTM_FAMILY_GENERIC 1         /* lstm_rec_kernel rounds (any shape)                               */
+#define FNSSL_LSTM_FAMILY_STATIC 2          /* shape-specialised rounds (lstm_static.h)                         */
+#define FNSSL_LSTM_FAMILY_STATIC2 3         /* two-slices-per-pass rounds, hidden 256 (lstm_static2.h)          */
+#define FNSSL_LSTM_FAMILY_SPLIT 4           /* several waves per 16-sequence group, generic (small batches)     */
+#define FNSSL_LSTM_FAMILY_SPLIT_STATIC 5    /* the same, shape-specialised and ring-free                        */
+#define FNSSL_LSTM_FAMILY_F32_CLUSTER 6     /* cluster-resident fp32 kernel (lstm_f32c.h) + guarded fallback    */
+#define FNSSL_LSTM_FAMILY_F32_CLUSTER256 7  /* cluster-resident fp32 kernel, hidden 256 (lstm_f32c256.h)        */
+#define FNSSL_LSTM_FAMILY_BF16 8            /* 16-sequence bf16 kernels (lstm_bf16.h)                           */
+#define FNSSL_LSTM_FAMILY_BF16_SOLO 9       /* one-wave-per-group wide bf16 kernels (lstm_bf16w.h)              */
+#define FNSSL_LSTM_FAMILY_BF16_PAIR 10      /* pair-split wide bf16 kernels (lstm_bf16p.h)                      */
+#define FNSSL_LSTM_FAMILY_BF16_CLUSTER 11   /* cluster-resident bf16 kernels (lstm_bf16c.h) + guarded fallback  */
+#define FNSSL_LSTM_FAMILY_TRAIN 12          /* reserve-saving training forward (lstm_train.hip)                 */
+int fnssl_lstm_plan(const fnssl_lstm_desc* d, int* family, int* rounds);
+
+/* Status word the cluster-resident kernels left in a workspace that fnssl_lstm_forward has used with the same
+ * (nseq, hidden, ndir): 0 = every hand-off arrived; 0xKnnnn = a wave of cluster nnnn gave up after the spin limit
+ * (K = 1 bf16 tag, 3 fp32 tag, 4 fp32 drift bound, 5 aborted because another wave had) — the layer was then re-run by
+ * the guarded fallback kernels of the same call, so this is a diagnostic, not an error.  Synchronises with `stream`. */
 int fnssl_lstm_cluster_status(const void* workspace, size_t workspace_bytes, int nseq, int hidden, int ndir, void* stream,
                               unsigned* status);
 
@@ -678,6 +714,12 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
 /* ------------------------------------------------------------------------- */
 /* Measurement hooks (bench.py: per-kernel HIP-event timing on the launch stream) */
 /* ------------------------------------------------------------------------- */
+
+/* The device's own fp32-MFMA ceiling (calibration, not product): launches CUs x waves_per_simd workgroups of four
+ * waves that issue nothing but v_mfma_f32_16x16x4_f32 (iters x 64 per wave); *flop = floating-point operations of the
+ * launch.  The caller times it with events on `stream`; bench.py reports flop / time as roofline.peak_measured next to
+ * the datasheet peak.  out: >= CUs * waves_per_simd * 256 floats of scratch. */
+int fnssl_mfma_f32_peak(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop, void* stream);
 
 /* enable = 1: every kernel launch is bracketed by hipEvents on its stream. */
 int fnssl_timing_enable(int enable);

@@ -70,6 +70,32 @@ def test_stft_reads_permuted_batch_in_place(dev):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("nch,layout", [(16, "nsc"), (17, "nsc"), (17, "ncs"), (33, "nsc")])
+def test_stft_many_channels_matches_oracle(dev, nch, layout):
+    """More channels than the frame-row kernel's fetch covers (16 waves x 64 lanes x 8 samples = 16 x 512): from 17
+    channels on fnssl_stft_ex must take the one-wave-per-frame kernel — round 3's gate was the LDS size only, and the
+    samples beyond 8192 per frame were never fetched (silently wrong spectra).  Both waveform layouts, magsum included."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    sig = rs_randn(900 + nch, (2, 512 + 4 * 256, nch))
+    d = to_dev(sig, dev)
+    if layout == "ncs":
+        d = d.permute(0, 2, 1).contiguous().permute(0, 2, 1)             # [nb, nch, ns] memory, logical [nb, ns, nch]
+    spec, magsum = ops.stft(d)
+    got = torch.view_as_complex(spec).permute(0, 3, 2, 1).cpu().numpy()      # [nb, 257, nt, nch]
+    want = O.stft(sig)
+    scale = np.abs(want).max()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 5e-6 * scale, "vs oracle: %g" % (np.abs(got - want).max() / scale)
+    assert_close(magsum.cpu().numpy(), np.abs(want).sum(axis=1).transpose(0, 2, 1), 2e-6, 0, "magsum")
+
+
+def test_array_frontend_rejects_more_channels_than_it_fetches(dev):
+    from fnssl import ops
+    with pytest.raises(RuntimeError, match="at most 16 channels"):
+        ops.array_frontend(torch.zeros(1, 512 + 5 * 256, 17, device=dev))
+
+
 def test_stft_rejects_short_signal(dev):
     from fnssl import ops
     with pytest.raises(RuntimeError, match="shorter than one"):
@@ -1046,8 +1072,12 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
         ops.lstm_layer("narrow", x0, None, x2, w, H, out, bf16=True, wide=True)
         return out
 
+    def plan():
+        return ops.lstm_plan("narrow", x0, None, x2, w, H, torch.empty((nb, nt, nf, H), device=dev, dtype=torch.bfloat16), bf16=True, wide=True)
+
     monkeypatch.delenv("FNSSL_NO_CLUSTER", raising=False)
     monkeypatch.delenv("FNSSL_CLUSTER_SPREAD", raising=False)
+    assert plan()[0] == "bf16_cluster", "the comparison below would be pair-split against pair-split: %r" % (plan(),)
     a, a2 = run(), run()
     monkeypatch.setenv("FNSSL_CLUSTER_SPREAD", "1")        # members of a cluster on different XCDs: placement must not matter
     s1, s2 = run(), run()
@@ -1056,6 +1086,7 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
     with torch.cuda.device(dev):
         assert ops.lstm_cluster_status(nb * nf, H, 1, dev) == 0        # no bounded wait ran out
     monkeypatch.setenv("FNSSL_NO_CLUSTER", "1")
+    assert plan()[0] == "bf16_pair"
     b = run()
     got = a.float().cpu().numpy()
     assert np.isfinite(got).all()
@@ -1090,11 +1121,18 @@ def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, 
         ops.lstm_layer("full", x, None, None, w, H, out, skip=skip, out_sum=osum)
         return out, osum
 
+    def plan():
+        o = torch.empty((nb, nt, nf, 2 * H), device=dev)
+        return ops.lstm_plan("full", x, None, None, w, H, o, skip=skip, out_sum=torch.empty_like(o) if summed else None)
+
     monkeypatch.delenv("FNSSL_NO_F32_CLUSTER", raising=False)
     monkeypatch.delenv("FNSSL_NO_F32C_B1", raising=False)
+    assert plan() == ("f32_cluster", 1), "the comparison below would be rounds against rounds: %r" % (plan(),)
     a, asum = run()
     a2, _ = run()
     monkeypatch.setenv("FNSSL_NO_F32_CLUSTER", "1")
+    fam, rounds = plan()
+    assert fam in ("static", "generic") and rounds >= 1, (fam, rounds)
     b, bsum = run()
     assert torch.isfinite(a).all()
     assert torch.equal(a, b) and torch.equal(a, a2), "cluster kernel differs from the rounds / is not repeatable"
@@ -1108,6 +1146,70 @@ def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, 
     want = O.lstm(seq, sd, "L.", True)
     got = np.stack([a[b_, t_].cpu().numpy() for b_, t_ in rows])
     assert_close(got, want, RTOL, ATOL, "fp32 cluster kernel vs oracle")
+
+
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch, kind):
+    """A member workgroup that never shows up (FNSSL_CLUSTER_TEST_STALL: what a CU-masked, shared or busy device does to
+    a kernel that needs all its members resident) must cost time, not the process and not the result: the waiting waves
+    give up after the spin limit, record a code, every workgroup drains, and the guarded per-wave / pair-split launch of
+    the SAME fnssl_lstm_forward call recomputes the layer — output equal to the fallback kernels', the caller's counter
+    incremented, no exception, the device still usable."""
+    from fnssl import ops
+    if kind == "f32":
+        H, c0, nb, nt, nf, ndir = 128, 256, 96, 256, 3, 2
+        sd = lstm_state(c0, H, True, 5700)
+        w = [ops.pack_lstm(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, 0, dev)
+             for s_ in ("", "_reverse")]
+        x = (torch.randn((nb, nt, nf, c0), generator=torch.Generator(device="cpu").manual_seed(5701)) * 0.5).to(dev)
+        skip = (torch.randn((nb, nt, nf, 2 * H), generator=torch.Generator(device="cpu").manual_seed(5702)) * 0.5).to(dev)
+        off_env, fam, nseq = "FNSSL_NO_F32_CLUSTER", "f32_cluster", nb * nt
+
+        def run(counter=None, plan=False):
+            out = torch.full((nb, nt, nf, 2 * H), float("nan"), device=dev)
+            osum = torch.full_like(out, float("nan"))
+            r = ops.lstm_layer("full", x, None, None, w, H, out, skip=skip, out_sum=osum, fallback_count=counter, plan_only=plan)
+            return r if plan else torch.cat([out, osum], -1)
+    else:
+        H, c0, c2, nb, nt, nf, ndir = 256, 256, 16, 9, 4, 257
+        ndir = 1
+        sd = lstm_state(c0 + c2, H, False, 5710)
+        w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0, c2, dev)]
+        xd = (torch.randn((nb, nt, nf, c0 + c2), generator=torch.Generator(device="cpu").manual_seed(5711)) * 0.7).to(dev)
+        x0, x2 = xd[..., :c0].contiguous().bfloat16(), xd[..., c0:].contiguous()
+        off_env, fam, nseq = "FNSSL_NO_CLUSTER", "bf16_cluster", nb * nf
+
+        def run(counter=None, plan=False):
+            out = torch.full((nb, nt, nf, H), float("nan"), device=dev, dtype=torch.bfloat16)
+            r = ops.lstm_layer("narrow", x0, None, x2, w, H, out, bf16=True, wide=True, fallback_count=counter, plan_only=plan)
+            return r if plan else out
+
+    for k in (off_env, "FNSSL_CLUSTER_TEST_STALL", "FNSSL_CLUSTER_SPIN_LIMIT", "FNSSL_NO_F32C_B1", "FNSSL_CLUSTER_SPREAD"):
+        monkeypatch.delenv(k, raising=False)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert run(plan=True)[0] == fam
+    good = run(counter)
+    with torch.cuda.device(dev):
+        assert ops.lstm_cluster_status(nseq, H, ndir, dev) == 0 and int(counter.item()) == 0
+    monkeypatch.setenv(off_env, "1")
+    want = run()
+    assert torch.equal(good, want)
+    monkeypatch.delenv(off_env)
+    monkeypatch.setenv("FNSSL_CLUSTER_TEST_STALL", "3")         # member 3 of cluster 0 exits at once
+    monkeypatch.setenv("FNSSL_CLUSTER_SPIN_LIMIT", "20000")     # ~30 ms instead of ~1.5 s
+    got = run(counter)                                           # must not raise, must not kill the process
+    torch.cuda.synchronize(dev)
+    with torch.cuda.device(dev):
+        st = ops.lstm_cluster_status(nseq, H, ndir, dev)
+    assert st != 0 and (st >> 16) in (1, 3, 4), "the stalled cluster did not record a code: %#x" % st
+    assert int(counter.item()) == 1, "the guarded fallback did not run exactly once: %d" % int(counter.item())
+    assert torch.equal(got, want), "after a failed hand-off the layer was not recomputed by the fallback kernels"
+    monkeypatch.delenv("FNSSL_CLUSTER_TEST_STALL")
+    monkeypatch.delenv("FNSSL_CLUSTER_SPIN_LIMIT")
+    again = run(counter)                                         # and the next call is a normal cluster launch again
+    with torch.cuda.device(dev):
+        assert ops.lstm_cluster_status(nseq, H, ndir, dev) == 0 and int(counter.item()) == 1
+    assert torch.equal(again, want)
 
 
 def test_lstm_bf16_wide_rejects_unbuilt_shapes(dev):

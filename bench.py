@@ -42,7 +42,25 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only, by is_online
-TRAFFIC_JSON = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
+TRAFFIC_JSON = os.path.join("profiles", "r04", "hbm_traffic.json")     # per roofline kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_JSON_R03 = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
+# same-process A/B legs of the default run: (label, environment of the B leg).  A = the shipped default.
+AB_KNOBS = [("f32_cluster_vs_rounds", {"FNSSL_NO_F32_CLUSTER": "1"})]
+
+
+def traffic_of(key):
+    """(bytes per launch, source) of a roofline kernel from the committed PMC summaries, or (None, None): counter
+    passes cannot run inside the timed region (gpurun refuses --pmc next to traces, and they perturb the clock)."""
+    path = os.path.join(ROOT, TRAFFIC_JSON)
+    if os.path.exists(path):
+        with open(path) as f:
+            d = json.load(f).get(key)
+        if d and d.get("bytes_per_launch"):
+            return d["bytes_per_launch"], TRAFFIC_JSON + "[%s] (%s; not this run)" % (key, d.get("how", "rocprofv3 --pmc"))
+    if key == "c2_lstm_h256" and os.path.exists(os.path.join(ROOT, TRAFFIC_JSON_R03)):
+        with open(os.path.join(ROOT, TRAFFIC_JSON_R03)) as f:
+            return json.load(f).get("bytes_per_launch"), TRAFFIC_JSON_R03 + " (round-3 build; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
+    return None, None
 
 
 def log(msg):
@@ -104,6 +122,10 @@ class FnsslForward:
         self.args, self.dev, self.ops, self.world = args, dev, ops, world
         self.online = not args.offline
         self.nb = args.nb or 32
+        if args.scaling == "strong":                  # fixed global batch split over the ranks
+            if self.nb % world:
+                raise SystemExit("--scaling strong: the global batch of %d utterances does not split over %d ranks" % (self.nb, world))
+            self.global_nb, self.nb = self.nb, self.nb // world
         self.sd = W.make_fnssl_state(0, is_online=self.online)
         model = ps.MyModel(ch_mode=args.ch_mode, device=str(dev))
         if not self.online:
@@ -140,7 +162,8 @@ class FnsslForward:
                             "3x(full-band BiLSTM + narrow-band LSTM)->head; %d utterances/GPU x %d mics ('%s' = %d pairs) "
                             "x 257 bins x %d frames, fp32; frame = one STFT frame of one utterance"
                             % ("online" if self.online else "offline", self.nb, a.nch, a.ch_mode, self.n_pairs, self.nt),
-                "utterances_per_gpu": self.nb, "mics": a.nch, "pairs_per_utterance": self.n_pairs, "frames": self.nt,
+                "utterances_per_gpu": self.nb, "global_batch": self.nb * self.world, "mics": a.nch,
+                "pairs_per_utterance": self.n_pairs, "frames": self.nt,
                 "bins": 257, "parallelism": "dp%d (utterance shards, no collective)" % self.world,
                 "chunk_pairs": a.chunk_pairs, "gflop_per_frame": round(self.flop_per_utt_frame / 1e9, 3)}
 
@@ -164,14 +187,12 @@ class FnsslForward:
         if self.args.bf16:
             return kernel_roof(kern, "lstm_h256", "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
                                PEAK_BF16_MFMA_TFLOPS)
-        traffic, src = None, None
-        tpath = os.path.join(ROOT, TRAFFIC_JSON)
-        if os.path.exists(tpath):   # PMC passes cannot run inside the timed region: measured by rocprofv3, committed
-            with open(tpath) as f:
-                traffic = json.load(f).get("bytes_per_launch")
-            src = TRAFFIC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, not this run)"
+        traffic, src = traffic_of("c2_lstm_h256")
         return kernel_roof(kern, "lstm_h256", "lstm_static2_kernel<H=256> (narrow-band LSTM, two hidden slices per pass)",
                            PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
+
+    def ab_knobs(self):
+        return AB_KNOBS if (self.online and not self.args.bf16) else []
 
     def cpu_baseline(self):
         from oracle import torch_ref as R
@@ -256,8 +277,9 @@ class IpdnetForward:
     def roofline(self, kern):
         if self.fp32:
             return kernel_roof(kern, "lstm_h256", "narrow-band LSTM H=256 (fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS)
+        traffic, src = traffic_of("c3_lstm_h256")
         r = kernel_roof(kern, "lstm_h256", "lstm_bf16c_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands, weights resident "
-                        "in the LDS of an 8-CU cluster)", PEAK_BF16_MFMA_TFLOPS)
+                        "in the LDS of an 8-CU cluster)", PEAK_BF16_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
         if r is not None and self.multi_stream:
             r["note"] = ("part-batches run on several streams: in the timed region a launch shares the chip with the "
                          "other streams' kernels, so its duration there is not exclusive; `alone` = the same kernel in "
@@ -356,7 +378,9 @@ class FnsslTrain:
         return ex
 
     def roofline(self, kern):
-        return kernel_roof(kern, "lstm_bwd_h256", "lstm_bwd_kernel<H=256> (narrow-band BPTT)", PEAK_FP32_MFMA_TFLOPS)
+        traffic, src = traffic_of("c4_lstm_bwd_h256")
+        return kernel_roof(kern, "lstm_bwd_h256", "lstm_bwd_kernel<H=256> (narrow-band BPTT)", PEAK_FP32_MFMA_TFLOPS,
+                           traffic=traffic, traffic_source=src)
 
     def cpu_baseline(self):
         from oracle import train_ref as TR
@@ -464,10 +488,11 @@ class Ipdnet2Forward:
             clock = 2.4e9
             peak = 1024 * clock / 592.0                                    # wave-steps per second, all SIMDs issuing
             ach = wave_steps * (k["count"] / (2.0 * self.layers)) / (k["ms"] * 1e-3) if k["ms"] > 0 else 0.0
+            traffic, src = traffic_of("c5_sn_mamba_scan")
             return {"name": dom, "bound": "valu", "kernel": "sn_mamba_scan (selective scan: no matrix product; roof = VALU / "
                     "transcendental issue, 592 issue cycles per wave-step, DESIGN section 10)", "achieved": round(ach / 1e9, 3),
-                    "peak": round(peak / 1e9, 3), "unit": "G wave-steps/s", "frac": round(ach / peak, 4), "traffic": None,
-                    "traffic_source": None, "launches": k["count"], "avg_ms": round(k["ms"] / max(1, k["count"]), 4)}
+                    "peak": round(peak / 1e9, 3), "unit": "G wave-steps/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_source": src, "launches": k["count"], "avg_ms": round(k["ms"] / max(1, k["count"]), 4)}
         r = kernel_roof(kern, dom, "%s (dominant kernel of the step%s)" % (dom, ", bf16 MFMA operands" if on_bf16 else
                                                                            ", fp32 arithmetic"),
                         PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS)
@@ -606,6 +631,74 @@ def run_workload(args, cfg, dev, rank, world, dist, backend, steps, warmup):
                  for k, v in sorted(kern_all.items())}
     extra = wl.extra(value, kern_all, probe_steps)
 
+    # ---- evidence legs, after the timed region (never inside it) ---------------------------------------------
+    # (a) the box's own fp32-MFMA ceiling: a 2 % difference between two boxes must not hide or fake a 2 % kernel gain
+    if roof is not None and roof.get("unit") == "TFLOP/s" and roof.get("peak") == PEAK_FP32_MFMA_TFLOPS and rank == 0:
+        try:
+            pm = ops.mfma_f32_peak()
+            roof["peak_measured"] = round(pm, 1)
+            roof["frac_of_peak_measured"] = round(roof["achieved"] / pm, 4) if pm > 0 else None
+            roof["peak_measured_how"] = ("fnssl_mfma_f32_peak on this device in this process: v_mfma_f32_16x16x4_f32 only, 2 waves "
+                                         "per SIMD on every CU, HIP events, best of 3")
+        except Exception as e:            # calibration only
+            log("mfma_f32_peak failed: %r" % (e,))
+    # (b) same-process A/B of the kernels this and the previous round changed (A = the shipped default, B = the knob):
+    # alternating legs of a few steps each, so that box-to-box differences cancel
+    ab = None
+    if args.ab_steps > 0 and hasattr(wl, "ab_knobs") and world == 1:
+        ab = {}
+        for label, env in wl.ab_knobs():
+            legs = {"A": [], "B": []}
+            for _ in range(2):
+                for which in ("A", "B"):
+                    saved = {k: os.environ.get(k) for k in env}
+                    if which == "B":
+                        os.environ.update(env)
+                    wl.step()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _i in range(args.ab_steps):
+                        wl.step()
+                    e1.record()
+                    e1.synchronize()
+                    legs[which].append(round(e0.elapsed_time(e1) / args.ab_steps, 3))
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+            a_ms, b_ms = min(legs["A"]), min(legs["B"])
+            ab[label] = {"A_ms_per_step": legs["A"], "B_ms_per_step": legs["B"], "env_B": env, "steps_per_leg": args.ab_steps,
+                         "order": "A B A B (one untimed step after every switch)", "B_over_A": round(b_ms / a_ms, 4),
+                         "gain_of_default_pct": round((b_ms / a_ms - 1.0) * 100.0, 2)}
+            log("A/B %s: A %s ms, B %s ms" % (label, legs["A"], legs["B"]))
+    # (c) strong scaling: the same GLOBAL batch on one rank, same run, so that the line carries its own efficiency
+    strong = None
+    if args.scaling == "strong" and hasattr(wl, "global_nb"):
+        t1 = None
+        if world > 1:
+            if rank == 0:
+                one = argparse.Namespace(**vars(args))
+                one.scaling, one.nb = "weak", wl.global_nb
+                w1 = WORKLOADS[cfg](one, dev, 0, 1)
+                w1.step()
+                torch.cuda.synchronize()
+                p0 = time.perf_counter()
+                for _i in range(max(2, min(steps, 5))):
+                    w1.step()
+                torch.cuda.synchronize()
+                t1 = (time.perf_counter() - p0) / max(2, min(steps, 5))
+                del w1
+            sync_all()
+        else:
+            t1 = dt / steps
+        if rank == 0:
+            rate1 = wl.global_nb * wl.nt / t1
+            strong = {"global_batch": wl.global_nb, "utterances_per_rank": wl.nb, "one_rank_same_run_ms_per_step": round(t1 * 1e3, 3),
+                      "efficiency": round(value / (world * rate1), 4),
+                      "how": "value / (n_gpus x frames/s of ONE rank running the whole global batch in the same run)"}
+
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, parity = wl.cpu_baseline()
@@ -615,7 +708,7 @@ def run_workload(args, cfg, dev, rank, world, dist, backend, steps, warmup):
         line = {
             "metric": wl.metric, "value": None if failed else round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": wl.dtype, "data": "synthetic",
             "config": wl.config(), "roofline": roof, "cpu_baseline": cpu, "parity": parity,
             "ms_per_step_median_hip_events": round(step_ms[len(step_ms) // 2], 3), "ms_per_step_per_rank": per_rank,
             "rccl_world_size": (dist.get_world_size() if backend == "nccl" else 0) if dist is not None else 1,
@@ -623,6 +716,10 @@ def run_workload(args, cfg, dev, rank, world, dist, backend, steps, warmup):
             "kernels_source": "separate instrumented pass of %d steps (every launch bracketed); the timed region brackets only the roofline kernel" % probe_steps,
         }
         line.update(extra)
+        if ab:
+            line["ab"] = ab
+        if strong:
+            line["strong_scaling"] = strong
     # give the memory back before the next configuration (config 2 plans 90 GB, config 4 132 GB)
     del wl, out
     import gc
@@ -660,6 +757,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=1, help="utterances in the bounded CPU sample (config 2)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded sample (config 2)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank runs the configuration's batch (default); strong: the configuration's batch is the "
+                         "GLOBAL batch, split evenly over the ranks (config 2; the line then carries strong_scaling.efficiency)")
+    ap.add_argument("--ab-steps", type=int, default=-1,
+                    help="steps per leg of the same-process A/B legs run after the timed region (config 2; default 3 in the "
+                         "plain default run, else 0)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -701,29 +804,42 @@ def main():
     if others is None:
         plain = not (args.nb or args.offline or args.bf16 or args.frames != 300 or args.nch != 4 or args.ch_mode != "MM"
                      or args.chunk_pairs)
-        others = "3,4,5" if (args.config == 2 and plain) else ""
-    other_ids = [int(c) for c in others.split(",") if c.strip()]
+        others = "2M,2off,3,4,5" if (args.config == 2 and plain and args.scaling == "weak") else ""
+    if args.ab_steps < 0:
+        args.ab_steps = 3 if (args.config == 2 and others.startswith("2M")) else 0
+    if args.scaling == "strong" and args.config != 2:
+        raise SystemExit("--scaling strong is defined for config 2 (the fixed global batch of the headline)")
+    other_ids = [c.strip() for c in others.split(",") if c.strip()]
 
     line, failed = run_workload(args, args.config, dev, rank, world, dist, backend, args.steps, args.warmup)
     nested = {}
-    for c in other_ids:
-        if c == args.config or c not in WORKLOADS:
+    for key in other_ids:
+        # "2M" / "2off": SURVEY 8d's secondary reports of config 2 — 'M' pairing (np = 3) and is_online=False — as their
+        # own nested lines (5 steps each, bounded CPU sample); "3" / "4" / "5": the other BASELINE configurations
+        variant = key if key in ("2M", "2off") else None
+        c = 2 if variant else (int(key) if key.isdigit() else -1)
+        if (c == args.config and not variant) or c not in WORKLOADS:
             continue
         sub = argparse.Namespace(**vars(args))
         sub.nb, sub.frames, sub.nch, sub.ch_mode, sub.chunk_pairs = 0, 300, 4, "MM", 0
         sub.offline = sub.bf16 = sub.c_step = False
+        sub.ab_steps, sub.scaling = 0, "weak"
+        nsteps = max(1, min(args.steps, args.other_steps))
+        if variant:
+            sub.ch_mode, sub.offline = ("M", False) if variant == "2M" else ("MM", True)
+            sub.cpu_seconds = min(args.cpu_seconds, 6.0)
+            nsteps = max(1, min(args.steps, 5))
         try:
-            l2, f2 = run_workload(sub, c, dev, rank, world, dist, backend, max(1, min(args.steps, args.other_steps)),
-                                  max(1, min(args.warmup, 2)))
+            l2, f2 = run_workload(sub, c, dev, rank, world, dist, backend, nsteps, max(1, min(args.warmup, 2)))
         except Exception as e:                                     # a secondary configuration must not lose the headline
-            log("config %d failed: %r" % (c, e))
+            log("config %s failed: %r" % (key, e))
             l2, f2 = {"error": repr(e)}, False
             if dist is not None:
                 raise
         if l2 is not None:
-            nested[str(c)] = l2
+            nested[key] = l2
         if f2:
-            log("PARITY FAILED in config %d (its value is withheld; the headline stands)" % c)
+            log("PARITY FAILED in config %s (its value is withheld; the headline stands)" % key)
 
     if rank == 0:
         if nested:

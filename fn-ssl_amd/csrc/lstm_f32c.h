@@ -32,8 +32,10 @@ struct F32ClusterParams {
   int groups_per_cluster;
   unsigned spin_limit;  // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
-  int prio_mode;        // experiment (FNSSL_F32C_PRIO): 1 static issue priority = the wave's rank on its SIMD, 2 matrix phase
-                        // above the gate phase, 3 gate phase above the matrix phase
+  int prio_mode;        // issue priority (s_setprio) by phase: 2 matrix phase above the cell update, 3 cell update above the
+                        // matrix phase, 5 = 3 + the next group-step's addressing / requests as well; 0 none; 1 / 4 experiments
+                        // (rank on the SIMD / staggered start).  Measured (profiles/r04): 256-channel layers 88.9 -> 86.9 ms
+                        // with 2, block 1's layer 36.0 -> 34.4 ms with 3.  FNSSL_F32C_PRIO overrides (9 = none).
 };
 
 // NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad (block 1); MODE: 0 or kSum
@@ -133,6 +135,11 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   };
 
   if (g0 + w >= g1) return;                                   // (a wave without a group: nobody waits for it)
+  unsigned long long clk0 = 0, rt0 = 0;                       // ablation twin, bit 512: the shader clock this kernel really runs at
+  if (ABLRT && (ABL & 512)) {
+    clk0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   if (cp.prio_mode == 1) {                                    // the four waves of a SIMD (w, w + 4, w + 8, w + 12) get ranks 0..3
     switch (w >> 2) {
       case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -224,7 +231,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
 
     // ---- matrix phase: record j of quad Q + 1 is read from LDS right after the MFMAs that used record j of quad Q
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(2);
-    if (cp.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
+    if (cp.prio_mode == 3 || cp.prio_mode == 5) __builtin_amdgcn_s_setprio(0);
     v4f acc[4];
     acc[0] = rec(0, 0);
     acc[1] = rec(0, 1);
@@ -275,6 +282,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       quad1(ic<1>{}, xs0);
     }
     // ---- the next group-step: where it is, and its early requests (the input ring is free now)
+    if (cp.prio_mode == 5) __builtin_amdgcn_s_setprio(2);
     nxt.task = task + NW < g1 ? task + NW : g0 + w;
     nxt.step = task + NW < g1 ? step : step + 1;
     const bool more = nxt.step < p.nsteps;
@@ -297,6 +305,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       }
       request(nxt, nrx0, nrsk, !single);
     }
+    if (cp.prio_mode == 5) __builtin_amdgcn_s_setprio(0);
     static_for<NS>([&](auto sp) {
       constexpr int SP = decltype(sp)::value;
       quad(ic<1 + NV0 + NS0 + SP>{}, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
@@ -304,7 +313,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
 
     // ---- cell update of my 16 units, stores, publish
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
-    if (cp.prio_mode == 3) __builtin_amdgcn_s_setprio(2);
+    if (cp.prio_mode == 3 || cp.prio_mode == 5) __builtin_amdgcn_s_setprio(2);
     v4f cn, hn;
     if (ABL & 2) {     // timing ablation: cheap gates
       cn = acc[1] + cprev_cur + acc[0];
@@ -338,6 +347,11 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   }
   pub_flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ABLRT && (ABL & 512) && (w == 0 || w == 15) && lane == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    printf("f32c blk %d wave %d start %llu end %llu cycles %llu MHz %.1f\n", b, w, rt0, r1, c1 - clk0,
+           (double)(c1 - clk0) / (double)(r1 - rt0) * 100.0);
+  }
 }
 
 template <int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>

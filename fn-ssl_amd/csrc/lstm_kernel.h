@@ -97,22 +97,58 @@ __device__ __forceinline__ float tanh_f(float x) {
   // 1 - 2/(e^{2x}+1): saturates cleanly at +-1, abs error ~1e-7
   return __fmaf_rn(-2.0f, __builtin_amdgcn_rcpf(__fadd_rn(__expf(2.0f * x), 1.0f)), 1.0f);
 }
+// The 4-wide forms below compute EXACTLY what sigmoid_f / tanh_f / fmul / fadd / fma compute per element (same roundings,
+// same constants: __expf(-x) is v_exp_f32(x * -log2e), and exp(2x) is v_exp_f32(x * 2 log2e) — 2x is exact, so scaling
+// the constant instead gives the same product), but on packed fp32 instructions (v_pk_mul / v_pk_add / v_pk_fma: two
+// elements per issue).  Why it matters (tools/ubench/issue_model.hip, profiles/r04): beside v_mfma_f32_16x16x4_f32 an fp32
+// VALU instruction is NOT hidden by other waves' matrix instructions — with four waves per SIMD each v_fma / v_mul / v_add
+// costs ~3.5 cycles of matrix-pipe time, a v_pk_* the same for two elements, v_exp / v_rcp ~6.5 — so the cell update is
+// paid in full (~480 cycles per 16 x 16 slice) and its instruction COUNT is what there is to save.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f exp2_2(v2f a) { return v2f{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+__device__ __forceinline__ v2f rcp_2(v2f a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f sigmoid2(v2f a) {
+  const v2f nl2e = {-0x1.715476p+0f, -0x1.715476p+0f};       // -log2(e) as __expf's multiplier (0xbfb8aa3b)
+  const v2f one = {1.0f, 1.0f};
+  return rcp_2(exp2_2(a * nl2e) + one);
+}
+__device__ __forceinline__ v2f tanh2(v2f a) {
+  const v2f l2e2 = {0x1.715476p+1f, 0x1.715476p+1f};         // 2 log2(e): exp(2x) = exp2(x * 2 log2e)
+  const v2f one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
+  return __builtin_elementwise_fma(m2, rcp_2(exp2_2(a * l2e2) + one), one);
+}
+__device__ __forceinline__ v4f join4(v2f lo, v2f hi) { return v4f{lo.x, lo.y, hi.x, hi.y}; }
+// PK = false: the same values from one-element instructions — for a kernel at its register limit (packed operands are
+// even-aligned register PAIRS; lstm_static2_kernel's allocation went from 2 to 28 spilled registers with them).
+template <bool PK = true>
 __device__ __forceinline__ v4f sigmoid4(v4f a) {
+  if constexpr (PK) return join4(sigmoid2(v2f{a.x, a.y}), sigmoid2(v2f{a.z, a.w}));
   return v4f{sigmoid_f(a.x), sigmoid_f(a.y), sigmoid_f(a.z), sigmoid_f(a.w)};
 }
+template <bool PK = true>
 __device__ __forceinline__ v4f tanh4(v4f a) {
+  if constexpr (PK) return join4(tanh2(v2f{a.x, a.y}), tanh2(v2f{a.z, a.w}));
   return v4f{tanh_f(a.x), tanh_f(a.y), tanh_f(a.z), tanh_f(a.w)};
 }
-
+template <bool PK = true>
 __device__ __forceinline__ v4f cell4(v4f f, v4f c, v4f i, v4f g) {   // f*c + i*g, i*g rounded first
+  if constexpr (PK) {
+    const v2f lo = __builtin_elementwise_fma(v2f{f.x, f.y}, v2f{c.x, c.y}, v2f{i.x, i.y} * v2f{g.x, g.y});
+    const v2f hi = __builtin_elementwise_fma(v2f{f.z, f.w}, v2f{c.z, c.w}, v2f{i.z, i.w} * v2f{g.z, g.w});
+    return join4(lo, hi);
+  }
   return v4f{__fmaf_rn(f.x, c.x, __fmul_rn(i.x, g.x)), __fmaf_rn(f.y, c.y, __fmul_rn(i.y, g.y)),
              __fmaf_rn(f.z, c.z, __fmul_rn(i.z, g.z)), __fmaf_rn(f.w, c.w, __fmul_rn(i.w, g.w))};
 }
+template <bool PK = true>
 __device__ __forceinline__ v4f mul_rn4(v4f a, v4f b) {
+  if constexpr (PK) return join4(v2f{a.x, a.y} * v2f{b.x, b.y}, v2f{a.z, a.w} * v2f{b.z, b.w});
   return v4f{__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z), __fmul_rn(a.w, b.w)};
 }
 // h + skip with the reference's rounding (the rounded h is what gets added): no fma contraction
+template <bool PK = true>
 __device__ __forceinline__ v4f add_rn4(v4f a, v4f b) {
+  if constexpr (PK) return join4(v2f{a.x, a.y} + v2f{b.x, b.y}, v2f{a.z, a.w} + v2f{b.z, b.w});
   return v4f{__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w)};
 }
 

@@ -12,6 +12,13 @@
 
 #pragma clang fp contract(off)
 
+#ifndef FNSSL_STATIC2_GPK
+#define FNSSL_STATIC2_GPK true
+#endif
+#ifndef FNSSL_STATIC2_GPK2
+#define FNSSL_STATIC2_GPK2 false
+#endif
+
 namespace fnssl_lstm {
 
 // ABL = true: timing-ablation twin (make ABLATE=1 only, wrong results), bits of FNSSL_ABLATE: 1 no x loads, 2 cheap gates,
@@ -20,6 +27,8 @@ template <int H, int NW, int M, int NV0, int NS2, int CHQ, int PAD, int MODE, in
 __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams p) {
   FNSSL_GUARDED_KERNEL(p);
   constexpr int NS = H / 16, NP = NS / 2;
+  constexpr bool GPK2 = FNSSL_STATIC2_GPK2;
+  constexpr bool GPK = FNSSL_STATIC2_GPK;   // packed gate math (lstm_kernel.h): only if the register allocation takes it without spilling
   constexpr bool HAS2 = (MODE & kHas2) != 0, SUM = (MODE & kSum) != 0;
   static_assert(!(MODE & kHas1) && HAS2 == (NS2 > 0) && NS % 2 == 0, "modes");
   constexpr int QPS = 1 + NV0 + NS2 + NS;               // real (pair-)quads per slice pair
@@ -226,32 +235,32 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
       // cell updates of the two slices
       {
         const bool cheap = ABL && (abl & 2);
-        const v4f ig = cheap ? acc[0] : sigmoid4(acc[0]), fg = cheap ? acc[1] : sigmoid4(acc[1]);
-        const v4f gg = cheap ? acc[2] : tanh4(acc[2]), og = cheap ? acc[3] : sigmoid4(acc[3]);
+        const v4f ig = cheap ? acc[0] : sigmoid4<GPK>(acc[0]), fg = cheap ? acc[1] : sigmoid4<GPK>(acc[1]);
+        const v4f gg = cheap ? acc[2] : tanh4<GPK>(acc[2]), og = cheap ? acc[3] : sigmoid4<GPK>(acc[3]);
         if ((step > 0 || cy) && !(abl & 16)) cprev1 = bld4(rc, vlane, s0 * 1024 + 1024);   // in flight under the first slice's gate math
         if (SUM && !(abl & 16)) skip1 = bld4(rsk, vok, ok + 64 * s0 + 64);
-        const v4f cn = cheap ? fg + cprev0 + ig : cell4(fg, cprev0, ig, gg);
-        v4f hn = cheap ? og + gg : mul_rn4(og, tanh4(cn));
+        const v4f cn = cheap ? fg + cprev0 + ig : cell4<GPK2>(fg, cprev0, ig, gg);
+        v4f hn = cheap ? og + gg : mul_rn4<GPK2>(og, tanh4<GPK>(cn));
         asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
         if (abl & 4) asm volatile("" ::"v"(cn), "v"(hn));
         if (!(abl & 4)) bst4(cn, rc, vlane, s0 * 1024);
         if (valid && !(abl & 4)) {
           bst4(hn, ro, voo, oo + 64 * s0);
-          if (SUM) bst4(add_rn4(hn, skip0), ro2, voo2, oo + 64 * s0);
+          if (SUM) bst4(add_rn4<GPK2>(hn, skip0), ro2, voo2, oo + 64 * s0);
         }
       }
       {
         const bool cheap = ABL && (abl & 2);
-        const v4f ig = cheap ? acd[0] : sigmoid4(acd[0]), fg = cheap ? acd[1] : sigmoid4(acd[1]);
-        const v4f gg = cheap ? acd[2] : tanh4(acd[2]), og = cheap ? acd[3] : sigmoid4(acd[3]);
-        const v4f cn = cheap ? fg + cprev1 + ig : cell4(fg, cprev1, ig, gg);
-        v4f hn = cheap ? og + gg : mul_rn4(og, tanh4(cn));
+        const v4f ig = cheap ? acd[0] : sigmoid4<GPK>(acd[0]), fg = cheap ? acd[1] : sigmoid4<GPK>(acd[1]);
+        const v4f gg = cheap ? acd[2] : tanh4<GPK>(acd[2]), og = cheap ? acd[3] : sigmoid4<GPK>(acd[3]);
+        const v4f cn = cheap ? fg + cprev1 + ig : cell4<GPK2>(fg, cprev1, ig, gg);
+        v4f hn = cheap ? og + gg : mul_rn4<GPK2>(og, tanh4<GPK>(cn));
         asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));
         if (abl & 4) asm volatile("" ::"v"(cn), "v"(hn));
         if (!(abl & 4)) bst4(cn, rc, vlane, s0 * 1024 + 1024);
         if (valid && !(abl & 4)) {
           bst4(hn, ro, voo, oo + 64 * s0 + 64);
-          if (SUM) bst4(add_rn4(hn, skip1), ro2, voo2, oo + 64 * s0 + 64);
+          if (SUM) bst4(add_rn4<GPK2>(hn, skip1), ro2, voo2, oo + 64 * s0 + 64);
         }
       }
     }

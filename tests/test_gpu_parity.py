@@ -1171,8 +1171,7 @@ def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(
             r = ops.lstm_layer("full", x, None, None, w, H, out, skip=skip, out_sum=osum, fallback_count=counter, plan_only=plan)
             return r if plan else torch.cat([out, osum], -1)
     else:
-        H, c0, c2, nb, nt, nf, ndir = 256, 256, 16, 9, 4, 257
-        ndir = 1
+        H, c0, c2, nb, nt, nf, ndir = 256, 256, 16, 9, 4, 257, 1
         sd = lstm_state(c0 + c2, H, False, 5710)
         w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0, c2, dev)]
         xd = (torch.randn((nb, nt, nf, c0 + c2), generator=torch.Generator(device="cpu").manual_seed(5711)) * 0.7).to(dev)

@@ -73,14 +73,10 @@ if "f32c" in which:
     w = packed(256, 0, 128, True)
     fl = 2.0 * 4 * 128 * (256 + 128) * nb * nt * nf * 2
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out, skip=x, out_sum=osum)
-    prio_sweep("f32c", "FNSSL_F32C_PRIO", [0, 1, 2, 3, 4, 0], fn, fl)
+    prio_sweep("f32c", "FNSSL_F32C_PRIO", [0, 9, 3, 5, 2, 0], fn, fl)
     if ABL_LIB:
         M = 8 | 16 | 64                  # every load except the tags
-        sweep("f32c", "FNSSL_F32C_ABL", [0, 4 | 256, 8 | 16, M, M | 32, M | 32 | 4 | 256, M | 32 | 4 | 256 | 128, M | 32 | 4 | 256 | 2,
-                                         511 - 1, 511, 2 | 128, 0], fn, fl)
-        os.environ["FNSSL_F32C_PRIO"] = "1"
-        sweep("f32c/p1", "FNSSL_F32C_ABL", [511, M | 32 | 4 | 256], fn, fl)
-        os.environ.pop("FNSSL_F32C_PRIO")
+        sweep("f32c", "FNSSL_F32C_ABL", [512, 512 | 511, 512 | M | 32 | 4 | 256, 1, 511 - 1, 0], fn, fl)
     os.environ["FNSSL_NO_F32_CLUSTER"] = "1"
     print("rounds   %8.2f ms" % timed(fn), flush=True)
     os.environ.pop("FNSSL_NO_F32_CLUSTER")
@@ -93,9 +89,9 @@ if "f32c_b1" in which:
     w = packed(4, 0, 128, True)
     fl = 2.0 * 4 * 128 * (4 + 128) * nb * nt * nf * 2
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out)
-    prio_sweep("f32c_b1", "FNSSL_F32C_PRIO", [0, 1, 2, 3, 4, 0], fn, fl)
+    prio_sweep("f32c_b1", "FNSSL_F32C_PRIO", [0, 9, 2, 5, 3, 0], fn, fl)
     if ABL_LIB:
-        sweep("f32c_b1", "FNSSL_F32C_ABL", [0, 2, 8 | 16 | 64, 8 | 16 | 64 | 32 | 4 | 256, 511 - 128, 511, 0], fn, fl)
+        sweep("f32c_b1", "FNSSL_F32C_ABL", [512, 1, 2, 511, 0], fn, fl)
     del x, out
     torch.cuda.empty_cache()
 
@@ -111,5 +107,4 @@ if "static2" in which:
     fn = lambda: ops.lstm_layer("narrow", F, None, None, w, 256, out, skip=F, out_sum=osum)
     prio_sweep("static2", "FNSSL_STATIC_PRIO", [0, 1, 0], fn, fl)
     if ABL_LIB:
-        sweep("static2", "FNSSL_ABLATE", [0, 1, 2, 4, 8, 16, 32, 64, 128, 1 | 32, 4 | 16, 1 | 4 | 16 | 32, 8 | 128, 8 | 64 | 128,
-                                          1 | 4 | 16 | 32 | 2, 255 - 64, 255 - 8, 255, 0], fn, fl)
+        pass

@@ -387,8 +387,12 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
       if (H == 256) {
         // two hidden slices per pass (lstm_static2.h) for the full-chip narrow-band rounds of blocks 2 / 3: the stream
         // is re-ordered into the workspace first (2 MB per direction, one tiny launch) — FNSSL_NO_STATIC2=1: A/B
-        if (vr.NW == 12 && d->c0 == 256 && d->c2 == 0 && !(mode & ~kSum) && !p.carry && (!p.ablate || env_int("FNSSL_ABL_STATIC2", 1, 1)) &&
-            !env_int("FNSSL_NO_STATIC2", 1, 1)) {
+        // — or, since round 4, the operand-ring kernel (lstm_static3.h: h_{t-1} streamed like x_t, no register spills, block
+        // 1's 260-channel layer included); FNSSL_NO_STATIC3=1 keeps lstm_static2_kernel / the one-slice kernel: A/B
+        const bool s3 = !p.ablate && !env_int("FNSSL_NO_STATIC3", 1, 1) && (mode == kSum || mode == 0 || mode == (kHas2 | kSum)) &&
+                        ((d->c2 == 0 && !(mode & kHas2)) || (d->c2 == 4 && (mode & kHas2)));
+        const bool s2 = d->c2 == 0 && !(mode & ~kSum) && (!p.ablate || env_int("FNSSL_ABL_STATIC2", 1, 1)) && !env_int("FNSSL_NO_STATIC2", 1, 1);
+        if (vr.NW == 12 && d->c0 == 256 && !p.carry && (s3 || s2)) {
           LstmParams p2 = p;
           const long long n4 = (long long)(H / 16) * p.quads_per_slice * 4 * 64;      // float4 per direction
           char* dst = reinterpret_cast<char*>(d->workspace) + cell_scratch_bytes(d->nseq, H, d->ndir);
@@ -400,7 +404,12 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
             p2.wpack[di] = reinterpret_cast<const float*>(o);
           }
           FNSSL_CHECK_LAUNCH("pair_stream_kernel");
-          rc = launch_static2_h256(p2, mode, nwg, st);
+          rc = s3 ? launch_static3_h256(p2, mode, nwg, st) : kNoStatic;
+          if (rc != kNoStatic) {
+            report(FNSSL_LSTM_FAMILY_STATIC3);
+            return rc;
+          }
+          rc = s2 ? launch_static2_h256(p2, mode, nwg, st) : kNoStatic;
           if (rc != kNoStatic) {
             report(FNSSL_LSTM_FAMILY_STATIC2);
             return rc;

@@ -62,6 +62,7 @@ struct ClusterParams {
   int spread;               // test knob (FNSSL_CLUSTER_SPREAD=1): members of a cluster = CONSECUTIVE blocks, i.e. different XCDs
   unsigned spin_limit;      // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;         // test knob: this member of the call's first cluster exits at once (-1: none)
+  int pub_fence;            // 1: s_waitcnt vmcnt(0) in front of every tag store (FNSSL_CLUSTER_PUB_FENCE, see pub_flush)
 };
 
 // ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 8 no recurrent-operand loads,
@@ -207,6 +208,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   const rsrc_t rtag_2 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (2 * 8 + w) * 8 + m, 0, 4, 0x00020000);
   unsigned pub_dep = 0, pub_val = 0;
   auto pub_flush = [&](int pt) {                       // pt: the part whose tag is pending
+    if (cp.pub_fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // explicit release: every earlier store of this wave has completed
     unsigned tval = pub_val;
     asm volatile("; tag store ordered behind %1" : "+v"(tval) : "v"(pub_dep));
     __builtin_amdgcn_raw_buffer_store_b32(tval, pt == 0 ? rtag_0 : pt == 1 ? rtag_1 : rtag_2, lane * 4, 0, 16);   // sc1: write-through

@@ -32,6 +32,7 @@ struct F32ClusterParams {
   int groups_per_cluster;
   unsigned spin_limit;  // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
+  int pub_fence;        // 1: s_waitcnt vmcnt(0) in front of every tag store (FNSSL_CLUSTER_PUB_FENCE, see pub_flush)
   int prio_mode;        // issue priority (s_setprio) by phase: 2 matrix phase above the cell update, 3 cell update above the
                         // matrix phase, 5 = 3 + the next group-step's addressing / requests as well; 0 none; 1 / 4 experiments
                         // (rank on the SIMD / staggered start).  Measured (profiles/r04): 256-channel layers 88.9 -> 86.9 ms
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   unsigned* pub_tag = nullptr;
   auto pub_flush = [&]() {
     if (pub_tag) {
+      if (cp.pub_fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // explicit release: every earlier store of this wave has completed
       unsigned tval = pub_val;
       asm volatile("; tag store ordered behind %1" : "+v"(tval) : "v"(pub_dep));
       if (lane == 0) __hip_atomic_store(pub_tag, tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

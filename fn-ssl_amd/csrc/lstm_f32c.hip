@@ -32,8 +32,9 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
   cp.tags = reinterpret_cast<unsigned*>(p.cluster_ws + 256);
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
+  cp.pub_fence = cluster_pub_fence();
   cp.prio_mode = env_int("FNSSL_F32C_PRIO", 1, 9);
-  if (cp.prio_mode == 0) cp.prio_mode = p.c0 == 4 ? 3 : 2;   // defaults by shape (see F32ClusterParams)
+  if (cp.prio_mode == 0) cp.prio_mode = 2;   // defaults by shape (see F32ClusterParams)
   if (cp.prio_mode == 9) cp.prio_mode = 0;
   const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * 8 * sizeof(unsigned);
   if (!p.dry) FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));

@@ -318,6 +318,10 @@ inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int g
   }
   return (long long)per_cu * fnssl::device_cus() >= grid;
 }
+inline int cluster_pub_fence() {   // default decided by measurement, see DESIGN.md (cluster kernels, hand-off ordering)
+  const char* e = getenv("FNSSL_CLUSTER_PUB_FENCE");
+  return e ? atoi(e) : 1;
+}
 inline int cluster_test_stall() {
   const char* e = getenv("FNSSL_CLUSTER_TEST_STALL");
   return e ? atoi(e) : -1;
@@ -325,6 +329,7 @@ inline int cluster_test_stall() {
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static2_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static2.h, pair-interleaved stream
+int launch_static3_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static3.h, pair-interleaved stream
 int launch_static_ipdnet(const LstmParams& p, int mode, int H, int NW, int nwg, hipStream_t st);
 
 }  // namespace fnssl_lstm

@@ -236,7 +236,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
 #define FNSSL_LSTM_FAMILY_SPLIT 4           /* several waves per 16-sequence group, generic (small batches)     */
 #define FNSSL_LSTM_FAMILY_SPLIT_STATIC 5    /* the same, shape-specialised and ring-free                        */
 #define FNSSL_LSTM_FAMILY_F32_CLUSTER 6     /* cluster-resident fp32 kernel (lstm_f32c.h) + guarded fallback    */
-#define FNSSL_LSTM_FAMILY_F32_CLUSTER256 7  /* cluster-resident fp32 kernel, hidden 256 (lstm_f32c256.h)        */
+#define FNSSL_LSTM_FAMILY_STATIC3 7         /* operand-ring rounds, hidden 256: x_t AND h_{t-1} streamed (lstm_static3.h) */
 #define FNSSL_LSTM_FAMILY_BF16 8            /* 16-sequence bf16 kernels (lstm_bf16.h)                           */
 #define FNSSL_LSTM_FAMILY_BF16_SOLO 9       /* one-wave-per-group wide bf16 kernels (lstm_bf16w.h)              */
 #define FNSSL_LSTM_FAMILY_BF16_PAIR 10      /* pair-split wide bf16 kernels (lstm_bf16p.h)                      */

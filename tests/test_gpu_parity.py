@@ -1211,6 +1211,48 @@ def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(
     assert torch.equal(again, want)
 
 
+@pytest.mark.parametrize("c2,summed", [(0, True), (0, False), (4, True)])
+def test_lstm_operand_ring_kernel_equals_two_slice_and_one_slice_kernels(dev, monkeypatch, c2, summed):
+    """lstm_static3.h (round 4: h_{t-1} streamed through the operand ring like x_t, no register spills) bit-for-bit against the kernels it replaces at the full-chip narrow-band size — lstm_static2_kernel
+    (blocks 2 / 3) and the one-slice lstm_static_kernel (block 1's 260 channels) — for the three layer variants of the
+    network, with a reversed-direction-free, ragged-free shape and steps 0..6 (step 0 reads h_{-1} = 0 through a
+    zero-record descriptor); a few sequences against the oracle."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    H, c0, nb, nt, nf = 256, 256, 192, 7, 256            # 49152 sequences = 256 CUs x 12 waves x 16: config 2's launch geometry
+    sd = lstm_state(c0 + c2, H, False, 5800 + c2)
+    w = [ops.pack_lstm(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0, c2, dev)]
+    g = torch.Generator(device="cpu").manual_seed(5801 + c2)
+    x0 = (torch.randn((nb, nt, nf, c0), generator=g) * 0.5).to(dev)
+    x2 = (torch.randn((nb, nt, nf, c2), generator=g) * 0.5).to(dev) if c2 else None
+    skip = (torch.randn((nb, nt, nf, H), generator=g) * 0.5).to(dev) if summed else None
+
+    def run(plan=False):
+        out = torch.full((nb, nf, nt, H), float("nan"), device=dev).permute(0, 2, 1, 3)
+        osum = torch.full((nb, nf, nt, H), float("nan"), device=dev).permute(0, 2, 1, 3) if summed else None
+        r = ops.lstm_layer("narrow", x0, None, x2, w, H, out, skip=skip, out_sum=osum, plan_only=plan)
+        return r if plan else (out, osum)
+
+    for k in ("FNSSL_NO_STATIC3", "FNSSL_NO_STATIC2"):
+        monkeypatch.delenv(k, raising=False)
+    assert run(plan=True) == ("static3", 1), run(plan=True)
+    a, asum = run()
+    a6, a6sum = run()                                    # (and again: repeatable)
+    monkeypatch.setenv("FNSSL_NO_STATIC3", "1")
+    assert run(plan=True)[0] == ("static2" if c2 == 0 else "static")
+    b, bsum = run()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, a6), "operand-ring kernel differs from the kernels it replaces"
+    if summed:
+        assert torch.equal(asum, bsum) and torch.equal(asum, a6sum) and torch.equal(asum, a + skip)
+    rows = [(0, 0), (77, 131), (nb - 1, nf - 1)]
+    xin = torch.cat([x0, x2], -1) if c2 else x0
+    seq = np.stack([xin[b_, :, f_].cpu().numpy() for b_, f_ in rows])           # [3, nt, c0 + c2]
+    want = O.lstm(seq, sd, "L.", False)
+    got = np.stack([a[b_, :, f_].cpu().numpy() for b_, f_ in rows])
+    assert_close(got, want, RTOL, ATOL, "operand-ring kernel vs oracle")
+
+
 def test_lstm_bf16_wide_rejects_unbuilt_shapes(dev):
     from fnssl import ops
     sd = lstm_state(128, 256, False, 5200)

@@ -56,6 +56,14 @@ def prio_sweep(name, env, modes, fn, flops):
     os.environ.pop(env, None)
 
 
+def env_sweep(name, env, values, fn, flops):
+    for v in values:
+        os.environ[env] = v
+        ms = [timed(fn) for _ in range(2)]
+        print("%-8s %s=%s  %s ms  %.3f of 157.3" % (name, env, v, " ".join("%.2f" % t for t in ms), flops / min(ms) / 1e9 / 157.3), flush=True)
+    os.environ.pop(env, None)
+
+
 which = sys.argv[1:] or ["peak", "f32c", "f32c_b1", "static2"]
 ABL_LIB = "abl" in os.environ.get("FNSSL_LIB_PATH", "")
 if "peak" in which:
@@ -73,7 +81,8 @@ if "f32c" in which:
     w = packed(256, 0, 128, True)
     fl = 2.0 * 4 * 128 * (256 + 128) * nb * nt * nf * 2
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out, skip=x, out_sum=osum)
-    prio_sweep("f32c", "FNSSL_F32C_PRIO", [0, 9, 3, 5, 2, 0], fn, fl)
+    prio_sweep("f32c", "FNSSL_F32C_PRIO", [0, 9, 0], fn, fl)
+    env_sweep("f32c", "FNSSL_CLUSTER_PUB_FENCE", ["0", "1", "0", "1"], fn, fl)
     if ABL_LIB:
         M = 8 | 16 | 64                  # every load except the tags
         sweep("f32c", "FNSSL_F32C_ABL", [512, 512 | 511, 512 | M | 32 | 4 | 256, 1, 511 - 1, 0], fn, fl)
@@ -89,7 +98,8 @@ if "f32c_b1" in which:
     w = packed(4, 0, 128, True)
     fl = 2.0 * 4 * 128 * (4 + 128) * nb * nt * nf * 2
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out)
-    prio_sweep("f32c_b1", "FNSSL_F32C_PRIO", [0, 9, 2, 5, 3, 0], fn, fl)
+    prio_sweep("f32c_b1", "FNSSL_F32C_PRIO", [0, 9, 0], fn, fl)
+    env_sweep("f32c_b1", "FNSSL_CLUSTER_PUB_FENCE", ["0", "1", "0", "1"], fn, fl)
     if ABL_LIB:
         sweep("f32c_b1", "FNSSL_F32C_ABL", [512, 1, 2, 511, 0], fn, fl)
     del x, out
@@ -105,6 +115,16 @@ if "static2" in which:
     w = packed(256, 0, 256, False)
     fl = 2.0 * 4 * 256 * (256 + 256) * nb * nt * nf
     fn = lambda: ops.lstm_layer("narrow", F, None, None, w, 256, out, skip=F, out_sum=osum)
-    prio_sweep("static2", "FNSSL_STATIC_PRIO", [0, 1, 0], fn, fl)
+    env_sweep("narrow/sum", "FNSSL_NO_STATIC3", ["0", "1", "0", "1"], fn, fl)
+    env_sweep("narrow/sum", "FNSSL_STATIC3_CHQ", ["9", "6", "9", "6"], fn, fl)
+    fn0 = lambda: ops.lstm_layer("narrow", F, None, None, w, 256, out)
+    env_sweep("narrow/plain", "FNSSL_NO_STATIC3", ["0", "1", "0", "1"], fn0, fl)
+    env_sweep("narrow/plain", "FNSSL_STATIC3_CHQ", ["9", "6"], fn0, fl)
+    X2 = torch.randn((nb, nt, nf, 4), generator=g, device=dev)
+    w1 = packed(256, 4, 256, False)
+    fl1 = 2.0 * 4 * 256 * (260 + 256) * nb * nt * nf
+    fn1 = lambda: ops.lstm_layer("narrow", F, None, X2, w1, 256, out, skip=F, out_sum=osum)
+    env_sweep("narrow/b1", "FNSSL_NO_STATIC3", ["0", "1", "0", "1"], fn1, fl1)
+    env_sweep("narrow/b1", "FNSSL_STATIC3_CHQ", ["9", "6"], fn1, fl1)
     if ABL_LIB:
         pass

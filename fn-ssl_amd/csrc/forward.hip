@@ -121,6 +121,7 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
       d.wpack[1] = net->wpack[blk][0][1];
       d.workspace = lws;
       d.workspace_bytes = pl.lstm_ws;
+      d.fallback_count = net->fallback_count;
       int rc = fnssl_lstm_forward(&d, stream);
       if (rc != FNSSL_OK) return rc;
       // ---- narrow-band LSTM over time, one sequence per (pair, bin) ------------
@@ -150,6 +151,7 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
       e.wpack[1] = net->wpack[blk][1][1];
       e.workspace = lws;
       e.workspace_bytes = pl.lstm_ws;
+      e.fallback_count = net->fallback_count;
       rc = fnssl_lstm_forward(&e, stream);
       if (rc != FNSSL_OK) return rc;
     }

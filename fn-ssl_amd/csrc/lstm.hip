@@ -302,7 +302,6 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   p.ablate = 0;                                 // the shipping library contains no ablation twins (make ABLATE=1)
 #endif
   p.dry = dry ? 1 : 0;
-  p.prio_mode = env_int("FNSSL_STATIC_PRIO", 1, 3);
   p.fallback_count = d->fallback_count;
   int nlaunch = 0;
   bool guarded = false;   // true: what follows is the guarded fallback of a cluster kernel (family already reported)

@@ -33,7 +33,7 @@ namespace fnssl_lstm {
 // are per WORKGROUP and step, so more groups per workgroup amortise them: the 400-column full-band layer of IPDnet has
 // 1200 groups (64 utterances x 300 frames / 32, two directions) = 600 two-group workgroups = 2.34 rounds on 256 CUs run
 // as 3; with NG = 5 it is 240 workgroups = ONE round (and the step's ring traffic serves 160 sequences instead of 64).
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false, bool ROTATE = false, int NG = 2>
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NSLOT_ = 7, bool DRAIN = false, int NG = 2>
 __global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p) {
   FNSSL_GUARDED_KERNEL(p);
   constexpr int NT = H / 8, NTW = NT / 2, NKH = H / 16, NKX = NB0 + NB2, KT = 1 + NKX + NKH;
@@ -101,18 +101,11 @@ __global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p
   // pull the same piece at once — with one piece in flight the ring alone took 41 k cycles per step.
   const int fpar = grp;                                    // my index among the NG waves that fetch for this role
   const unsigned src_role = (unsigned)(role * NTW * KT) * 1024u;
-  // Tile rotation (EXPERIMENT, off: FNSSL_BF16P_ROTATE=1): within a step the gate-row tiles only depend on h_{t-1}, so
-  // their ORDER is free; with ROTATE the workgroups of one XCD (blockIdx & 7) start their walk through the role's NTW
-  // tiles at different tiles, so that the CUs of an XCD pull DIFFERENT records from their shared L2 at any moment
-  // instead of the same one.  Measured at config 3 (profiles/r03/h_*): no gain — narrow-band layers 14.92 ms per step
-  // rotated against 14.50 in lock-step (same-line requests are evidently served together; spreading them loses that).
-  // Static tile index I <-> stream tile (I + rot) & (NTW - 1): the cell state of that tile lives in creg[I].
-  static_assert((NTW & (NTW - 1)) == 0, "tile rotation assumes a power-of-two tile count per role");
-  const int rot = ROTATE ? (int)((blockIdx.x >> 3) & (NTW - 1)) : 0;
+  // (per-XCD tile rotation — the CUs of an XCD pulling DIFFERENT records at any moment — was measured in round 3: no gain)
   auto fetch_piece = [&](int j, int slot) {
     const int qt = j & 3;
     const int start = (qt >> 1) * KP + (qt & 1) * KQ0, size = (qt & 1) ? KQ1 : KQ0;
-    const unsigned sb = src_role + (unsigned)((((j >> 2) + rot) & (NTW - 1)) * KT + start + fpar) * 1024u;
+    const unsigned sb = src_role + (unsigned)((j >> 2) * KT + start + fpar) * 1024u;
     const unsigned lb = lds0 + (unsigned)(slot * SLOTB + (role * KQ0 + fpar) * 1024);
     // records fpar + 2 m: the first KPW - 1 always exist (2 (KPW - 2) + 1 < KQ1), the last one may run past a short
     // piece and then repeats the piece's last record
@@ -215,7 +208,7 @@ __global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p
     const v4bfw hb4 = __builtin_convertvector(hn, v4bfw);
     pend_f = hn;
     pend_b = hb4;
-    const int ta = (I + rot) & (NTW - 1);                 // the stream tile this static index stands for
+    const int ta = I;                                     // the stream tile of this static index
     pend_off = oo_t + (OUTF ? 32 : 16) * ta;
     pend_live = true;
     // global tile G = role * NTW + ta -> operand block G / 2, elements 4 (G & 1) .. + 3
@@ -331,10 +324,7 @@ int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
   // — bit-stable with one workgroup per CU (same kernel, LDS padded) and with drained barriers; the cause could not
   // be pinned from here, so the shape runs the canonical "vmcnt(0) + barrier" protocol: 3.99 -> 4.37 ms per launch
   // (three resident workgroups hide each other's waits).  The other shapes own their CU (114-158 KB of LDS).
-  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), false, NG>;
-  if constexpr (NG == 2) {
-    if (getenv("FNSSL_BF16P_ROTATE")) k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), true, NG>;   // A/B
-  }
+  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), NG>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3(NG * 128), lds, st, p);

@@ -33,10 +33,10 @@ struct F32ClusterParams {
   unsigned spin_limit;  // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
   int pub_fence;        // 1: s_waitcnt vmcnt(0) in front of every tag store (FNSSL_CLUSTER_PUB_FENCE, see pub_flush)
-  int prio_mode;        // issue priority (s_setprio) by phase: 2 matrix phase above the cell update, 3 cell update above the
-                        // matrix phase, 5 = 3 + the next group-step's addressing / requests as well; 0 none; 1 / 4 experiments
-                        // (rank on the SIMD / staggered start).  Measured (profiles/r04): 256-channel layers 88.9 -> 86.9 ms
-                        // with 2, block 1's layer 36.0 -> 34.4 ms with 3.  FNSSL_F32C_PRIO overrides (9 = none).
+  int prio_mode;        // 2 (default): s_setprio 2 during the matrix phase, 0 during the cell update — a wave in its matrix
+                        // phase outranks its SIMD neighbours' cell updates at issue; 0: none (FNSSL_F32C_PRIO=9).  Measured
+                        // (profiles/r04): 256-channel layers 88.9 -> 86.5 ms, block 1's layer 36.1 -> 35.3 ms; the reverse
+                        // order, a static rank per wave and a staggered start were measured as well: equal or worse.
 };
 
 // NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad (block 1); MODE: 0 or kSum
@@ -142,17 +142,6 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     clk0 = __builtin_amdgcn_s_memtime();
     rt0 = __builtin_amdgcn_s_memrealtime();
   }
-  if (cp.prio_mode == 1) {                                    // the four waves of a SIMD (w, w + 4, w + 8, w + 12) get ranks 0..3
-    switch (w >> 2) {
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      case 3: __builtin_amdgcn_s_setprio(3); break;
-      default: break;
-    }
-  }
-  if (cp.prio_mode == 4) {                                    // experiment: start the ranks a quarter of a group-step apart
-    for (int i = 0; i < 2 * (w >> 2); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   bool dead = false;                                          // wave-uniform: this wave has given up (or seen that another has)
   // bounded wait for `ready()`; refreshes through `reload()`; false = gave up
   auto bounded_wait = [&](auto ready, auto reload, int sleep, unsigned code) {
@@ -233,7 +222,6 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
 
     // ---- matrix phase: record j of quad Q + 1 is read from LDS right after the MFMAs that used record j of quad Q
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(2);
-    if (cp.prio_mode == 3 || cp.prio_mode == 5) __builtin_amdgcn_s_setprio(0);
     v4f acc[4];
     acc[0] = rec(0, 0);
     acc[1] = rec(0, 1);
@@ -284,7 +272,6 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       quad1(ic<1>{}, xs0);
     }
     // ---- the next group-step: where it is, and its early requests (the input ring is free now)
-    if (cp.prio_mode == 5) __builtin_amdgcn_s_setprio(2);
     nxt.task = task + NW < g1 ? task + NW : g0 + w;
     nxt.step = task + NW < g1 ? step : step + 1;
     const bool more = nxt.step < p.nsteps;
@@ -307,7 +294,6 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       }
       request(nxt, nrx0, nrsk, !single);
     }
-    if (cp.prio_mode == 5) __builtin_amdgcn_s_setprio(0);
     static_for<NS>([&](auto sp) {
       constexpr int SP = decltype(sp)::value;
       quad(ic<1 + NV0 + NS0 + SP>{}, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
@@ -315,7 +301,6 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
 
     // ---- cell update of my 16 units, stores, publish
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
-    if (cp.prio_mode == 3 || cp.prio_mode == 5) __builtin_amdgcn_s_setprio(2);
     v4f cn, hn;
     if (ABL & 2) {     // timing ablation: cheap gates
       cn = acc[1] + cprev_cur + acc[0];

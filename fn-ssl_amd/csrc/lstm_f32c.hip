@@ -33,9 +33,7 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
   cp.pub_fence = cluster_pub_fence();
-  cp.prio_mode = env_int("FNSSL_F32C_PRIO", 1, 9);
-  if (cp.prio_mode == 0) cp.prio_mode = 2;   // defaults by shape (see F32ClusterParams)
-  if (cp.prio_mode == 9) cp.prio_mode = 0;
+  cp.prio_mode = env_int("FNSSL_F32C_PRIO", 9, 9) ? 0 : 2;   // see F32ClusterParams
   const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * 8 * sizeof(unsigned);
   if (!p.dry) FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));
 #ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
@@ -47,13 +45,7 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
   p.ablate = 0;
 #endif
   if (p.c0 == 4) return launch_f32c_k<0, 1, 0>(p, cp, st);
-  if (mode == kSum) switch (env_int("FNSSL_F32C_DRIFT", 1, 4)) {   // experiment knob
-      case 1: return launch_f32c_k<16, 0, kSum, false, 1>(p, cp, st);
-      case 3: return launch_f32c_k<16, 0, kSum, false, 3>(p, cp, st);
-      case 4: return launch_f32c_k<16, 0, kSum, false, 4>(p, cp, st);
-      default: break;
-    }
-  if (mode == kSum && getenv("FNSSL_F32C_W12")) return launch_f32c_k<16, 0, kSum, false, 2, 12>(p, cp, st);   // A/B: three waves per SIMD
+  // (drift bounds of 1 / 3 / 4 group-steps and 12 waves per member were measured in round 3: +0.5 / 0.0 / +1.2 ms, +1.5 ms)
   if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
   return launch_f32c_k<16, 0, 0>(p, cp, st);
 }

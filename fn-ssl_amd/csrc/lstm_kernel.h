@@ -47,7 +47,6 @@ struct LstmParams {
   const unsigned* guard = nullptr;
   unsigned* fallback_count = nullptr;
   int dry = 0;    // host only (fnssl_lstm_plan): the launch templates return without launching
-  int prio_mode = 0;   // experiment (FNSSL_STATIC_PRIO): 1 = static issue priority by the wave's rank on its SIMD
 };
 
 // first statement of every kernel that can be a guarded fallback (uniform for the whole grid: nobody reaches a barrier)

@@ -31,11 +31,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // ABL = true: timing-ablation twin driven by FNSSL_ABLATE (bits as in lstm_rec_kernel); wrong results.
-// STAG = true: the waves of a workgroup form two groups that run ONE CHUNK apart on a 3-slot ring,
-// so the slice-end work of one group (cell update, stores, accumulator re-init, first x loads)
-// overlaps with the other group's MFMAs instead of idling the matrix pipe for everybody at once.
 template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
-          bool STAG = false, int NV2 = 0>
+          int NV2 = 0>
 __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p) {
   FNSSL_GUARDED_KERNEL(p);
   constexpr int NS = H / 16;
@@ -83,8 +80,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   // ---- weight ring ---------------------------------------------------------------
   char* const lds_rd = smem + lane * 16;
   char* const lds_wr = smem + w * 1024 + lane * 16;
-  constexpr int NSLOT = STAG ? 3 : 2;
-  const bool late = STAG && ((w >> 2) & 1);   // group 1 runs one chunk behind group 0
+  constexpr int NSLOT = 2;
   int wslot = 0;          // slot the staged chunk is committed to
   int rslot = 0;          // slot being read
   int src_rec = 0;        // real record index of the next chunk to stage
@@ -124,11 +120,6 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
   stage_write();
   sync();
   issue_loads();
-  if (late) {   // idle period: keep the ring protocol going while group 0 works on chunk 0
-    stage_write();
-    sync();
-    issue_loads();
-  }
   const char* cb = lds_rd;                      // base of the chunk being read
   auto rec = [&](auto ql, int j) {              // record j of quad ql (compile time) of the current chunk
     return *reinterpret_cast<const v4f*>(cb + decltype(ql)::value * 4096 + j * 1024);
@@ -274,21 +265,17 @@ __global__ void __launch_bounds__(NW * 64) lstm_static_kernel(const LstmParams p
       }
     }
   }
-  if (STAG && !late) {   // group 0 finishes one period early: stay in the protocol
-    stage_write();
-    sync();
-  }
 #undef SQUAD
 #undef SQUAD1
 }
 
 template <int H, int NW, int M, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool ABL = false, int XD = 4,
-          bool STAG = false, int NV2 = 0>
+          int NV2 = 0>
 int launch_static_k(const LstmParams& p, int nwg, hipStream_t st) {
   if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
-  const size_t lds = (size_t)(STAG ? 3 : 2) * CHQ * 4096;
-  static_assert((STAG ? 3 : 2) * CHQ * 4096 <= 160 * 1024, "ring does not fit the LDS");
-  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL, XD, STAG, NV2>;
+  const size_t lds = (size_t)2 * CHQ * 4096;
+  static_assert(2 * CHQ * 4096 <= 160 * 1024, "ring does not fit the LDS");
+  auto k = lstm_static_kernel<H, NW, M, NV0, NS0, NS2, CHQ, PAD, MODE, ABL, XD, NV2>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));

@@ -65,13 +65,6 @@ __global__ void __launch_bounds__(NW * 64) lstm_static2_kernel(const LstmParams 
   const unsigned vlane = lane * 16;
   const bool rev = dir == 1;
   const int abl = ABL ? p.ablate : 0;
-  if (p.prio_mode == 1) {   // waves w, w + 4, w + 8 share a SIMD
-    switch (w >> 2) {
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: break;
-    }
-  }
 
   // ---- weight ring (2 slots of CHQ pair-quads = 8 CHQ records) ------------------------------------------------
   char* const lds_rd = smem + lane * 16;

@@ -8,58 +8,24 @@ namespace fnssl_lstm {
   if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && NS2_ < 4 && mode == (MODE_))                  \
     return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_>(p, nwg, st);
 
-#define TRYS(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_)                                             \
-  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && NS2_ < 4 && mode == (MODE_))                \
-    return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, 4, true>(p, nwg, st);
-
-#define TRYX(NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, XD_)                                        \
-  if (NW == NW_ && p.c0 == 16 * NV0_ + 4 * NS0_ && p.c2 == 4 * NS2_ && NS2_ < 4 && mode == (MODE_))                \
-    return launch_static_k<128, NW_, M_, NV0_, NS0_, NS2_, CHQ_, PAD_, MODE_, false, XD_>(p, nwg, st);
-
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st) {
-  if (!p.ablate && env_int("FNSSL_STATIC_XD8", 1, 1)) {   // experiment: 8-deep x ring
-    TRYX(16, 2, 16, 0, 0, 7, 3, kSum, 8)
-    TRYX(15, 2, 16, 0, 0, 7, 3, kSum, 8)
-    TRYX(14, 2, 16, 0, 0, 7, 3, kSum, 8)
-  }
-  if (!p.ablate && env_int("FNSSL_STATIC_STAG", 1, 1)) {   // experiment (no gain, r01): two wave groups one chunk apart
-    TRYS(16, 2, 16, 0, 0, 7, 3, kSum)
-    TRYS(15, 2, 16, 0, 0, 7, 3, kSum)
-    TRYS(14, 2, 16, 0, 0, 7, 3, kSum)
-    TRYS(16, 2, 0, 1, 0, 5, 0, 0)
-    TRYS(15, 2, 0, 1, 0, 5, 0, 0)
-    TRYS(14, 2, 0, 1, 0, 5, 0, 0)
-  }
   // block 1 full-band: 4 input channels, 10 quads per slice
-  if (!env_int("FNSSL_STATIC_SMALLCHUNK", 1, 1)) {
-    TRY(16, 4, 0, 1, 0, 10, 0, 0)
-    TRY(15, 4, 0, 1, 0, 10, 0, 0)
-    TRY(14, 4, 0, 1, 0, 10, 0, 0)
-    TRY(13, 4, 0, 1, 0, 10, 0, 0)
-  }
-  TRY(16, 2, 0, 1, 0, 5, 0, 0)
-  TRY(15, 2, 0, 1, 0, 5, 0, 0)
-  TRY(14, 2, 0, 1, 0, 5, 0, 0)
-  TRY(13, 2, 0, 1, 0, 5, 0, 0)
+  TRY(16, 4, 0, 1, 0, 10, 0, 0)
+  TRY(15, 4, 0, 1, 0, 10, 0, 0)
+  TRY(14, 4, 0, 1, 0, 10, 0, 0)
+  TRY(13, 4, 0, 1, 0, 10, 0, 0)
   // blocks 2/3 full-band (and offline narrow-band 2/3): 256 channels, 25 quads (+3 pad = 4 x 7)
 #ifdef FNSSL_BUILD_ABLATE   // timing-ablation twin (wrong results by construction): only in `make ABLATE=1` builds
   if (p.ablate && NW == 16 && p.c0 == 256 && p.c2 == 0 && mode == kSum)
     return launch_static_k<128, 16, 2, 16, 0, 0, 7, 3, kSum, true>(p, nwg, st);
 #endif
-  if (!env_int("FNSSL_STATIC_SMALLCHUNK", 1, 1)) {   // 26 virtual quads = 2 chunks of 13
-    TRY(16, 4, 16, 0, 0, 13, 1, kSum)
-    TRY(15, 4, 16, 0, 0, 13, 1, kSum)
-    TRY(14, 4, 16, 0, 0, 13, 1, kSum)
-    TRY(16, 4, 16, 0, 0, 13, 1, 0)
-    TRY(15, 4, 16, 0, 0, 13, 1, 0)
-    TRY(14, 4, 16, 0, 0, 13, 1, 0)
-  }
-  TRY(16, 2, 16, 0, 0, 7, 3, kSum)
-  TRY(15, 2, 16, 0, 0, 7, 3, kSum)
-  TRY(14, 2, 16, 0, 0, 7, 3, kSum)
-  TRY(16, 2, 16, 0, 0, 7, 3, 0)
-  TRY(15, 2, 16, 0, 0, 7, 3, 0)
-  TRY(14, 2, 16, 0, 0, 7, 3, 0)
+  // 26 virtual quads = 2 chunks of 13
+  TRY(16, 4, 16, 0, 0, 13, 1, kSum)
+  TRY(15, 4, 16, 0, 0, 13, 1, kSum)
+  TRY(14, 4, 16, 0, 0, 13, 1, kSum)
+  TRY(16, 4, 16, 0, 0, 13, 1, 0)
+  TRY(15, 4, 16, 0, 0, 13, 1, 0)
+  TRY(14, 4, 16, 0, 0, 13, 1, 0)
   // offline narrow-band block 1: 256 + 4 channels, 26 quads (+2 pad = 4 x 7)
   TRY(16, 2, 16, 0, 1, 7, 2, kHas2 | kSum)
   TRY(12, 4, 16, 0, 1, 9, 1, kHas2 | kSum)

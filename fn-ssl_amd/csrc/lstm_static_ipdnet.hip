@@ -11,7 +11,7 @@ namespace fnssl_lstm {
 // c0 = 16 * NV0 (summed input), c2 = 16 * NV2 (concatenated input, packed as 16-channel blocks)
 #define TRYH(H_, NW_, M_, NV0_, NV2_, CHQ_, PAD_, XD_)                                                   \
   if (H == H_ && NW == NW_ && p.c0 == 16 * NV0_ && p.c2 == 16 * NV2_ && mode == kHas2)                   \
-    return launch_static_k<H_, NW_, M_, NV0_, 0, 0, CHQ_, PAD_, kHas2, false, XD_, false, NV2_>(p, nwg, st);
+    return launch_static_k<H_, NW_, M_, NV0_, 0, 0, CHQ_, PAD_, kHas2, false, XD_, NV2_>(p, nwg, st);
 
 int launch_static_ipdnet(const LstmParams& p, int mode, int H, int NW, int nwg, hipStream_t st) {
   if (p.ablate) return kNoStatic;

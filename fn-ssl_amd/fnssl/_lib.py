@@ -106,6 +106,7 @@ class Net(C.Structure):
         ("emb_w", C.c_void_p), ("emb_b", C.c_void_p),
         ("doa_wt", C.c_void_p), ("doa_b", C.c_void_p),
         ("input_size", C.c_int), ("is_online", C.c_int),
+        ("fallback_count", C.c_void_p),
     ]
 
 

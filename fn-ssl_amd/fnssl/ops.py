@@ -765,7 +765,31 @@ class DeviceNet:
             self.doa_b = self._dev(g("ipd2doa.bias"))
             net.doa_wt, net.doa_b = self.doa_wt.data_ptr(), self.doa_b.data_ptr()
         net.input_size, net.is_online = self.input_size, int(self.is_online)
+        # layers whose cluster-resident kernel gave up on a hand-off and were recomputed by the guarded fallback kernels of
+        # the same call (fnssl_lstm_forward): counted on the device, read back asynchronously (4 bytes per forward, no
+        # synchronisation) and reported one forward later as a RuntimeWarning — results are correct either way
+        self.fallbacks = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._fb_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else None
+        self._fb_event, self._fb_seen = None, 0
+        net.fallback_count = self.fallbacks.data_ptr()
         self.net = net
+
+    def _report_fallbacks(self):
+        if self._fb_event is not None and self._fb_event.query():
+            n = int(self._fb_host[0])
+            if n > self._fb_seen:
+                import warnings
+                warnings.warn("fnssl: %d LSTM layer launch(es) so far could not keep every member workgroup of a cluster-resident "
+                              "kernel resident (shared, partitioned or busy device?) and were recomputed by the per-wave kernels: "
+                              "results are unaffected, throughput is" % n, RuntimeWarning, stacklevel=3)
+                self._fb_seen = n
+            self._fb_event = None
+
+    def _poll_fallbacks(self):
+        if self._fb_host is not None and self._fb_event is None:
+            self._fb_host.copy_(self.fallbacks, non_blocking=True)
+            self._fb_event = torch.cuda.Event()
+            self._fb_event.record(torch.cuda.current_stream(self.device))
 
     def _dev(self, a):
         t = a.detach() if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a, dtype=np.float32))
@@ -780,16 +804,7 @@ class DeviceNet:
 
     @on_device
     def forward(self, x0: torch.Tensor, chunk_pairs: int = 0) -> torch.Tensor:
-        """x0 [nb', nt, nf, input_size] -> [nb', nt//12, 2*nf] (or [.., 180] with the DOA layer).
-
-        EXPERIMENT, off by default (FNSSL_TAIL_PAIRS=n / FNSSL_TAIL_AUTO=1): pairs are independent and a launch runs at
-        the pace of its fullest SIMD, so when the batch overflows a whole number of wave-times per SIMD in the
-        full-band layers by a few pairs (BASELINE config 2: 7200 wave tasks on 1024 SIMDs = 7.03) those pairs can be
-        peeled off onto a second stream — the main part then fits SIMD-balanced rounds (16 + 12 waves per CU instead
-        of 15 + 14, launch planner in csrc/lstm.hip).  Measured on MI355X (profiles/r03/e_*): the main part does get
-        faster, but the peeled pair's own six dependent launches find no free SIMD slots beside the persistent main
-        kernels (3 x 146 registers of the narrow-band rounds, 4 waves per SIMD of the 16-wave rounds) and finish after
-        them: 604.6 ms against 560.4 ms per step.  Results are identical either way (every launch path is bit-identical)."""
+        """x0 [nb', nt, nf, input_size] -> [nb', nt//12, 2*nf] (or [.., 180] with the DOA layer)."""
         _need_dev(x0)
         x0 = x0.contiguous()
         nb, nt, nf, cin = x0.shape
@@ -797,41 +812,10 @@ class DeviceNet:
             raise RuntimeError("fnssl.forward: expected %d input channels, got %d" % (self.input_size, cin))
         last = 180 if self.is_doa else 2 * nf
         out = torch.empty((nb, nt // SEG_FRAMES, last), dtype=torch.float32, device=x0.device)
-        tail = 0 if chunk_pairs else tail_pairs(nb, nt, torch.cuda.get_device_properties(x0.device).multi_processor_count)
-        if not tail:
-            self._run(x0, out, chunk_pairs)
-            return out
-        cur = torch.cuda.current_stream(x0.device)
-        side = getattr(self, "_side", None)
-        if side is None or side.device != x0.device:
-            side = self._side = torch.cuda.Stream(device=x0.device, priority=-1)
-        side.wait_stream(cur)                       # inputs and packed weights are ready on the caller's stream
-        with torch.cuda.stream(side):
-            self._run(x0[nb - tail:], out[nb - tail:], 0)
-        self._run(x0[:nb - tail], out[:nb - tail], 0)
-        cur.wait_stream(side)
+        self._report_fallbacks()
+        self._run(x0, out, chunk_pairs)
+        self._poll_fallbacks()
         return out
-
-
-def tail_pairs(nb: int, nt: int, ncu: int) -> int:
-    """How many trailing pairs ``DeviceNet.forward`` runs on its second stream: the fewest that bring the full-band
-    layers' wave tasks (2 directions x ceil(pairs * frames / 16)) down to a whole number of wave-times per SIMD
-    (4 waves per SIMD, 4 SIMDs per CU) — if that is a small fraction of a large batch, else 0."""
-    import os
-    forced = os.environ.get("FNSSL_TAIL_PAIRS")
-    if forced:
-        return max(0, min(int(forced), nb - 1))
-    if not os.environ.get("FNSSL_TAIL_AUTO") or nb < 2 or ncu <= 0:      # measured slower (see DeviceNet.forward): opt-in
-        return 0
-    units = lambda n: -(-(2 * -(-(n * nt) // 16)) // (4 * ncu))   # noqa: E731  ceil(tasks / SIMDs)
-    u = units(nb)
-    if u < 3:
-        return 0
-    n = nb
-    while n > 0 and units(n) >= u:
-        n -= 1
-    tail = nb - n
-    return tail if n > 0 and tail <= max(1, nb // 32) else 0
 
 
 # --------------------------------------------------------------------------- #

@@ -552,6 +552,7 @@ typedef struct {
   const float* doa_b;     /* [180] or NULL                          */
   int input_size;         /* 4                                      */
   int is_online;          /* narrow-band: 1 = uni-dir H=256, 0 = bi-dir H=128 */
+  unsigned* fallback_count;   /* optional DEVICE counter handed to every layer (fnssl_lstm_desc.fallback_count); NULL: none */
 } fnssl_net;
 
 size_t fnssl_forward_workspace_bytes(int nb, int nf, int nt, int is_online, int chunk_pairs);

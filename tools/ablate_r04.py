@@ -115,8 +115,7 @@ if "static2" in which:
     w = packed(256, 0, 256, False)
     fl = 2.0 * 4 * 256 * (256 + 256) * nb * nt * nf
     fn = lambda: ops.lstm_layer("narrow", F, None, None, w, 256, out, skip=F, out_sum=osum)
-    env_sweep("narrow/sum", "FNSSL_NO_STATIC3", ["0", "1", "0", "1"], fn, fl)
-    env_sweep("narrow/sum", "FNSSL_STATIC3_CHQ", ["9", "6", "9", "6"], fn, fl)
+    env_sweep("narrow/sum", "FNSSL_STATIC_PRIO", ["0", "7", "8", "0", "7", "8"], fn, fl)
     fn0 = lambda: ops.lstm_layer("narrow", F, None, None, w, 256, out)
     env_sweep("narrow/plain", "FNSSL_NO_STATIC3", ["0", "1", "0", "1"], fn0, fl)
     env_sweep("narrow/plain", "FNSSL_STATIC3_CHQ", ["9", "6"], fn0, fl)

@@ -14,8 +14,14 @@ reference's own CPU case and only a parity test):
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM.  Every rank runs the same
 per-GPU batch (weak scaling; utterances are independent: no data-path collective, config 4 has the one gradient
-all-reduce).  K steps are timed between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line whose
-`value` is utterance-frames per second over all ranks.  The line also carries
+all-reduce) — or, with --scaling strong (config 2), an even share of the configuration's GLOBAL batch, and the line
+then carries `strong_scaling.efficiency` against one rank running the whole batch in the same run.  K steps are timed
+between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line whose `value` is utterance-frames per second
+over all ranks.  The default run (no flags) nests config 2's 'M' pairing and is_online=False variants ("2M", "2off") and
+configs 3, 4, 5 under `other_configs`, each with its own roofline / cpu_baseline / parity.  The line also carries
+  ab           : same-process A/B legs run AFTER the timed region (A = the shipped default, B = an environment knob that
+                 restores the previous kernels; alternating, a few steps each) — a box-independent record of what a
+                 kernel change is worth; roofline.peak_measured = this device's own fp32-MFMA ceiling (fnssl_mfma_f32_peak);
   roofline     : the dominant kernel against its roof, timed with HIP events on the launch stream inside the timed
                  region — only that kernel is bracketed there (fnssl_timing_select); `kernels` and `frontend` (the STFT
                  + feature kernels against the HBM roof, config 2) come from an instrumented pass before it;
@@ -45,7 +51,12 @@ FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only (BASEL
 TRAFFIC_JSON = os.path.join("profiles", "r04", "hbm_traffic.json")     # per roofline kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 TRAFFIC_JSON_R03 = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
 # same-process A/B legs of the default run: (label, environment of the B leg).  A = the shipped default.
-AB_KNOBS = [("f32_cluster_vs_rounds", {"FNSSL_NO_F32_CLUSTER": "1"})]
+AB_KNOBS = [
+    # round 4: operand-ring narrow-band kernel (lstm_static3.h) + issue priorities in the cluster-resident full-band kernel
+    ("round4_kernels_vs_round3_kernels", {"FNSSL_NO_STATIC3": "1", "FNSSL_F32C_PRIO": "9"}),
+    # round 3: cluster-resident full-band kernel (lstm_f32c.h) against the per-wave rounds
+    ("f32_cluster_vs_rounds", {"FNSSL_NO_F32_CLUSTER": "1"}),
+]
 
 
 def traffic_of(key):
@@ -183,12 +194,13 @@ class FnsslForward:
 
     def roofline(self, kern):
         if not self.online:
-            return kernel_roof(kern, "lstm_h128", "lstm_rec_kernel<H=128> (offline: every layer)", PEAK_FP32_MFMA_TFLOPS)
+            return kernel_roof(kern, "lstm_h128", "H = 128 layers (offline: every layer; full-band on the cluster-resident lstm_f32c_kernel, "
+                               "narrow-band on lstm_static_kernel rounds)", PEAK_FP32_MFMA_TFLOPS)
         if self.args.bf16:
             return kernel_roof(kern, "lstm_h256", "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
                                PEAK_BF16_MFMA_TFLOPS)
         traffic, src = traffic_of("c2_lstm_h256")
-        return kernel_roof(kern, "lstm_h256", "lstm_static2_kernel<H=256> (narrow-band LSTM, two hidden slices per pass)",
+        return kernel_roof(kern, "lstm_h256", "lstm_static3_kernel<H=256> (narrow-band LSTM, two hidden slices per pass, x_t and h_{t-1} streamed)",
                            PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
 
     def ab_knobs(self):

@@ -33,6 +33,7 @@ struct F32ClusterParams {
   unsigned spin_limit;  // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
   int pub_fence;        // 1: s_waitcnt vmcnt(0) in front of every tag store (FNSSL_CLUSTER_PUB_FENCE, see pub_flush)
+  int rotate;           // 1: the groups a cluster has beyond a multiple of its waves change hands every step (see the schedule)
   int prio_mode;        // 2 (default): s_setprio 2 during the matrix phase, 0 during the cell update — a wave in its matrix
                         // phase outranks its SIMD neighbours' cell updates at issue; 0: none (FNSSL_F32C_PRIO=9).  Measured
                         // (profiles/r04): 256-channel layers 88.9 -> 86.5 ms, block 1's layer 36.1 -> 35.3 ms; the reverse
@@ -159,6 +160,14 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     }
     return true;
   };
+  // Schedule of a wave within a step: its regular groups g0 + w + i NW (i < FULL / NW), then — rotate — at most one LEFTOVER
+  // group g0 + FULL + j, j = (w - step) mod NW < LEFT: the groups beyond a multiple of the wave count change hands every
+  // step, so every wave (and SIMD) carries the same load over the launch — config 2: 225 groups = 14 per wave + 1, the
+  // fullest SIMD 56.25 group-steps per step instead of 57 (1.3 %).  A group's state lives in memory (h in the output tensor,
+  // c in the scratch area, both read past the L1), so which wave of the member takes it is free.
+  const int NGR = g1 - g0;
+  const bool rot = cp.rotate && NGR >= 2 * NW;
+  const int FULL = rot ? (NGR / NW) * NW : NGR, LEFT = NGR - FULL;
   const bool single = g0 + w + NW >= g1;                      // one group per wave: its c_t is not written yet when the next
                                                               // group-step's requests go out, so c is requested at the top
   Grp cur, nxt;
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     if (SUM && !(ABL & 64)) skipv = bld4(qsk, gr.vok, tt * stk + 64 * m);
     if (gr.step > 0) {
       if (!(ABL & 256)) tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (with_c && !(ABL & 64)) cprev = bld4(rc_of(gr.task), vlane, m * 1024);
+      if (with_c && !(ABL & 64)) cprev = bld4_l2(rc_of(gr.task), vlane, m * 1024);
     }
     if (DRIFT > 0 && !(ABL & 256) && gr.task - DRIFT * NW >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
       tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NW - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -197,8 +206,12 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     const unsigned op = (rev ? tt + 1 : tt - 1) * sto;         // row of h_{step - 1}
     const rsrc_t rc = rc_of(task);
     unsigned* const tag_g = tag_cl + (size_t)(task - g0) * 8;
-    if (single && step > 0 && !(ABL & 64)) cprev = bld4(rc, vlane, m * 1024);
-    const v4f cprev_cur = step > 0 ? cprev : zero4, skip_cur = skipv;
+    if (single && step > 0 && !(ABL & 64)) cprev = bld4_l2(rc, vlane, m * 1024);
+    // (a leftover group's c_{t-1} was written by ANOTHER wave of this member, which may be behind: it is loaded in fetch_h,
+    //  once the tags show that every member — this one included — has finished the group's previous step)
+    const bool late_c = task >= g0 + FULL;
+    v4f cprev_cur = step > 0 ? cprev : zero4;
+    const v4f skip_cur = skipv;
 
     // h_{step - 1} of the whole row: every member's slice, once all 8 tags show it
     v4f hold[NS];
@@ -212,6 +225,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
         if (!(ABL & 4) && !dead)
           dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagv < (unsigned)step) == 0; },
                                [&]() { tagv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 16, 0x30000u);
+        if (late_c && !(ABL & 64)) cprev_cur = bld4_l2(rc, vlane, m * 1024);
 #pragma unroll
         for (int s = 0; s < NS; ++s) hold[s] = bld4_l2(ro, cur.voo, op + 64 * s);
       } else {
@@ -272,27 +286,43 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       quad1(ic<1>{}, xs0);
     }
     // ---- the next group-step: where it is, and its early requests (the input ring is free now)
-    nxt.task = task + NW < g1 ? task + NW : g0 + w;
-    nxt.step = task + NW < g1 ? step : step + 1;
+    bool seq_next = false;                                      // the next group is this one + NW (incremental addressing)
+    if (task < g0 + FULL && task + NW < g0 + FULL) {
+      nxt.task = task + NW;
+      nxt.step = step;
+      seq_next = true;
+    } else {
+      const int j = (w - step) & (NW - 1);                      // (NW is a power of two when rot; LEFT = 0 otherwise)
+      if (task < g0 + FULL && j < LEFT) {
+        nxt.task = g0 + FULL + j;
+        nxt.step = step;
+      } else {
+        nxt.task = g0 + w;
+        nxt.step = step + 1;
+      }
+    }
     const bool more = nxt.step < p.nsteps;
     if (more) {
       if (ABL & 1) {   // timing ablation (wrong results): every group-step uses the first group's addressing
         nxt.vo0 = cur.vo0; nxt.voo = cur.voo; nxt.vok = cur.vok; nxt.voo2 = cur.voo2; nxt.valid = cur.valid;
         nrx0 = rx0; nro = ro; nrsk = rsk; nro2 = ro2;
       } else {
-        if (nxt.step == step) {                               // next group of this wave: 16 NW sequences further
+        if (seq_next) {                                       // next group of this wave: 16 NW sequences further
           qi0 += 16 * NW;
           while (qi0 >= p.q_inner) {
             qi0 -= p.q_inner;
             ++qo0;
           }
+        } else if (nxt.step == step) {                        // a leftover group: once per step at most
+          qo0 = (nxt.task * 16) / p.q_inner;
+          qi0 = nxt.task * 16 - qo0 * p.q_inner;
         } else {
           qo0 = qo_first;
           qi0 = qi_first;
         }
         locate(nxt.task, qo0, qi0, nxt, nrx0, nro, nrsk, nro2);
       }
-      request(nxt, nrx0, nrsk, !single);
+      request(nxt, nrx0, nrsk, !single && nxt.task < g0 + FULL);
     }
     static_for<NS>([&](auto sp) {
       constexpr int SP = decltype(sp)::value;

@@ -33,6 +33,7 @@ int forward_f32c(LstmParams p, int mode, hipStream_t st) {
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
   cp.pub_fence = cluster_pub_fence();
+  cp.rotate = (kF32cWaves & (kF32cWaves - 1)) == 0 && !getenv("FNSSL_F32C_NO_ROTATE");   // A/B knob, same bits
   cp.prio_mode = env_int("FNSSL_F32C_PRIO", 9, 9) ? 0 : 2;   // see F32ClusterParams
   const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * 8 * sizeof(unsigned);
   if (!p.dry) FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));

@@ -147,3 +147,14 @@ def test_bench_self_launches_n_ranks(tmp_path):
         assert line["value"] > 0 and line["scaling"] == "weak"
         # whole-job value = frames of BOTH ranks over the slowest rank's time
         assert abs(line["value"] - 2 * 2 * 24 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"] + 0.01
+    # strong scaling: the configuration's batch is the GLOBAL batch, split over the ranks; the line carries its
+    # own efficiency against one rank running the whole batch in the same run
+    res = subprocess.run([sys.executable, bench, "--gpus", "2", "--config", "2", "--scaling", "strong", "--steps", "2", "--warmup", "1",
+                          "--nb", "2", "--frames", "24"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and "other_configs" not in line
+    assert line["config"]["utterances_per_gpu"] == 1 and line["config"]["global_batch"] == 2
+    assert abs(line["value"] - 2 * 24 / (line["ms_per_step"] * 1e-3)) <= 1e-3 * line["value"] + 0.01
+    ss = line["strong_scaling"]
+    assert ss["global_batch"] == 2 and ss["utterances_per_rank"] == 1 and 0.0 < ss["efficiency"] < 4.0

@@ -81,8 +81,12 @@ if "f32c" in which:
     w = packed(256, 0, 128, True)
     fl = 2.0 * 4 * 128 * (256 + 128) * nb * nt * nf * 2
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out, skip=x, out_sum=osum)
-    prio_sweep("f32c", "FNSSL_F32C_PRIO", [0, 9, 0], fn, fl)
-    env_sweep("f32c", "FNSSL_CLUSTER_PUB_FENCE", ["0", "1", "0", "1"], fn, fl)
+    for _ in range(2):
+        os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
+        print("f32c rotate     %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
+        os.environ["FNSSL_F32C_NO_ROTATE"] = "1"
+        print("f32c no-rotate  %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
+    os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
     if ABL_LIB:
         M = 8 | 16 | 64                  # every load except the tags
         sweep("f32c", "FNSSL_F32C_ABL", [512, 512 | 511, 512 | M | 32 | 4 | 256, 1, 511 - 1, 0], fn, fl)
@@ -98,8 +102,12 @@ if "f32c_b1" in which:
     w = packed(4, 0, 128, True)
     fl = 2.0 * 4 * 128 * (4 + 128) * nb * nt * nf * 2
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out)
-    prio_sweep("f32c_b1", "FNSSL_F32C_PRIO", [0, 9, 0], fn, fl)
-    env_sweep("f32c_b1", "FNSSL_CLUSTER_PUB_FENCE", ["0", "1", "0", "1"], fn, fl)
+    for _ in range(2):
+        os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
+        print("b1 rotate     %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
+        os.environ["FNSSL_F32C_NO_ROTATE"] = "1"
+        print("b1 no-rotate  %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
+    os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
     if ABL_LIB:
         sweep("f32c_b1", "FNSSL_F32C_ABL", [512, 1, 2, 511, 0], fn, fl)
     del x, out

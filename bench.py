@@ -52,8 +52,9 @@ TRAFFIC_JSON = os.path.join("profiles", "r04", "hbm_traffic.json")     # per roo
 TRAFFIC_JSON_R03 = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
 # same-process A/B legs of the default run: (label, environment of the B leg).  A = the shipped default.
 AB_KNOBS = [
-    # round 4: operand-ring narrow-band kernel (lstm_static3.h) + issue priorities in the cluster-resident full-band kernel
-    ("round4_kernels_vs_round3_kernels", {"FNSSL_NO_STATIC3": "1", "FNSSL_F32C_PRIO": "9"}),
+    # round 4: operand-ring narrow-band kernel (lstm_static3.h); issue priorities by phase and leftover-group rotation in the
+    # cluster-resident full-band kernel (lstm_f32c.h)
+    ("round4_kernels_vs_round3_kernels", {"FNSSL_NO_STATIC3": "1", "FNSSL_F32C_PRIO": "9", "FNSSL_F32C_NO_ROTATE": "1"}),
     # round 3: cluster-resident full-band kernel (lstm_f32c.h) against the per-wave rounds
     ("f32_cluster_vs_rounds", {"FNSSL_NO_F32_CLUSTER": "1"}),
 ]
@@ -813,12 +814,12 @@ def main():
                                                              dist.get_world_size()))
 
     others = args.other_configs
+    plain = not (args.nb or args.offline or args.bf16 or args.frames != 300 or args.nch != 4 or args.ch_mode != "MM"
+                 or args.chunk_pairs) and args.scaling == "weak" and args.config == 2
     if others is None:
-        plain = not (args.nb or args.offline or args.bf16 or args.frames != 300 or args.nch != 4 or args.ch_mode != "MM"
-                     or args.chunk_pairs)
-        others = "2M,2off,3,4,5" if (args.config == 2 and plain and args.scaling == "weak") else ""
+        others = "2M,2off,3,4,5" if plain else ""
     if args.ab_steps < 0:
-        args.ab_steps = 3 if (args.config == 2 and others.startswith("2M")) else 0
+        args.ab_steps = 3 if plain else 0
     if args.scaling == "strong" and args.config != 2:
         raise SystemExit("--scaling strong is defined for config 2 (the fixed global batch of the headline)")
     other_ids = [c.strip() for c in others.split(",") if c.strip()]

@@ -528,7 +528,9 @@ class Ipdnet2Forward:
                          "algorithm with a python scan over frames, parity unpinned), fp32, %d threads, %.1f s"
                          % (frames, cores, cdt)}
         got = self.net(self.ops.preprocess_ipdnet2(sig)).cpu()
-        rt, at = (1e-4, 5e-5) if self.fp32 else (2e-2, 1.5e-2)          # bf16: SURVEY 8c, fp32 reference at a looser tolerance
+        # bf16: no reference exists — the fp32 CPU forward at a tolerance set from what bf16 operand rounding through
+        # 8 layers measures (1.2e-2 max, 2.2e-3 rms on outputs of rms 0.45; the fp32 kernels sit at 9e-7) plus ~8 % margin
+        rt, at = (1e-4, 5e-5) if self.fp32 else (2e-2, 1.3e-2)
         return cpu, parity_of(got, want, rt, at, "%d frames vs the fp32 PyTorch CPU forward" % frames)
 
 

@@ -994,6 +994,17 @@ def test_config2_full_batch_independence_and_oracle(dev):
     gen = torch.Generator(device=dev)
     gen.manual_seed(77)
     batch = torch.randn((32, 4, 77056), generator=gen, device=dev)
+    # the kernels this test is about: at this size the library must pick the operand-ring kernel for the narrow-band layers
+    # and the cluster-resident kernel for the full-band ones (descriptors only: nothing is launched, nothing dereferenced)
+    from fnssl import ops as _ops
+    big = torch.empty((192, 300, 256, 256), device=dev)                  # (never touched: one buffer stands in for every operand)
+    bign = torch.empty((192, 256, 300, 256), device=dev).permute(0, 2, 1, 3)
+    wf = [torch.empty(int(_ops._lib.load().fnssl_lstm_packed_floats(256, 0, 128)), device=dev)] * 2
+    wn = [torch.empty(int(_ops._lib.load().fnssl_lstm_packed_floats(256, 0, 256)), device=dev)]
+    assert _ops.lstm_plan("full", big, None, None, wf, 128, big, skip=big, out_sum=big) == ("f32_cluster", 1)
+    assert _ops.lstm_plan("narrow", big, None, None, wn, 256, bign, skip=big, out_sum=bign) == ("static3", 1)
+    del big, bign
+    torch.cuda.empty_cache()
     out = model.predict_step(batch, 0)
     assert tuple(out.shape) == (192, 25, 512) and bool(torch.isfinite(out).all())
     for u in (0, 13, 31):

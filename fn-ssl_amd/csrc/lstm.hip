@@ -352,6 +352,19 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
     p.task0 = 0;
     p.task1 = tasks;
     p.wgs_per_dir = 0;
+    // the full-band layers of a large enough shard: the cluster-resident kernel with the reserve stores (lstm_f32c.h), its
+    // guarded fallback = the split kernels below
+    if (d->variant == 0 && f32c_handles(p, H, mode)) {
+      const int rc = forward_f32c(p, mode, st);
+      if (rc == FNSSL_OK) {
+        report(FNSSL_LSTM_FAMILY_F32_CLUSTER);
+        if (dry) return FNSSL_OK;
+        guarded = true;
+        p.guard = reinterpret_cast<const unsigned*>(p.cluster_ws);
+      } else if (rc != kNoCluster) {
+        return rc;
+      }
+    }
     report(FNSSL_LSTM_FAMILY_TRAIN);
     return dry ? FNSSL_OK : forward_save(p, H, mode, st);
   }

@@ -19,9 +19,8 @@
 // FNSSL_CLUSTER_SPREAD=1 places them on different XCDs: same bits, 14 % slower):
 //   * producer wave: its two 1-KiB operand records (blocks 2m, 2m + 1 of its sequence tile: exactly the units this
 //     member computes) are stored write-through (16-byte sc1 stores); the TAG word of (part, wave, member) is stored
-//     (sc1) only after a load issued BEHIND those stores has returned: vector memory operations of a wave complete in
-//     order on gfx9, so the stores have been acknowledged by then — without draining the wave's prefetch window the way
-//     s_waitcnt vmcnt(0) would;
+//     (sc1) behind an s_waitcnt vmcnt(0), five K-steps into the next part (round 3 ordered it behind a dependent load
+//     instead; the explicit drain costs nothing measurable: profiles/r04/);
 //   * consumer wave: loads the tags of its (part, wave) at the end of the previous part (relaxed agent loads), looks at
 //     them a few K-steps later, and only after all members show the step it waits for does it issue the sc1 loads of
 //     the operand records (sc1 loads bypass the CU's L1, which other CUs' stores never refresh).  Tags are monotonic
@@ -62,7 +61,6 @@ struct ClusterParams {
   int spread;               // test knob (FNSSL_CLUSTER_SPREAD=1): members of a cluster = CONSECUTIVE blocks, i.e. different XCDs
   unsigned spin_limit;      // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;         // test knob: this member of the call's first cluster exits at once (-1: none)
-  int pub_fence;            // 1: s_waitcnt vmcnt(0) in front of every tag store (FNSSL_CLUSTER_PUB_FENCE, see pub_flush)
 };
 
 // ABL (make ABLATE=1 builds only; wrong results): 1 no tag waits, 2 cheap gate math, 8 no recurrent-operand loads,
@@ -138,7 +136,6 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   auto RO = [&](int pt) { return pt == 0 ? ro_0 : pt == 1 ? ro_1 : ro_2; };
   const unsigned st0 = (unsigned)(p.src0.st * 2), st2 = (unsigned)(p.src2.st * 4), sto = (unsigned)(p.out_st * 2);
   const rsrc_t rhx = make_rsrc(cp.hx + (size_t)cg * cluster_parity_bytes(H));
-  const rsrc_t rw = make_rsrc(p.wpack[dir]);
   const unsigned vlane = lane * 16;
   unsigned* const tag_base = cp.tags + (size_t)cg * kClusterTagWords;
   // operand records of (parity, part): sequence tile w, block s
@@ -206,11 +203,10 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   const rsrc_t rtag_0 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (0 * 8 + w) * 8 + m, 0, 4, 0x00020000);
   const rsrc_t rtag_1 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (1 * 8 + w) * 8 + m, 0, 4, 0x00020000);
   const rsrc_t rtag_2 = __builtin_amdgcn_make_buffer_rsrc(tag_base + (2 * 8 + w) * 8 + m, 0, 4, 0x00020000);
-  unsigned pub_dep = 0, pub_val = 0;
+  unsigned pub_val = 0;
   auto pub_flush = [&](int pt) {                       // pt: the part whose tag is pending
-    if (cp.pub_fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // explicit release: every earlier store of this wave has completed
-    unsigned tval = pub_val;
-    asm volatile("; tag store ordered behind %1" : "+v"(tval) : "v"(pub_dep));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // release: every earlier vector memory operation of this wave has completed
+    const unsigned tval = pub_val;
     __builtin_amdgcn_raw_buffer_store_b32(tval, pt == 0 ? rtag_0 : pt == 1 ? rtag_1 : rtag_2, lane * 4, 0, 16);   // sc1: write-through
   };
 
@@ -354,12 +350,8 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     if constexpr (!(ABL & 64)) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[0], hq[1])), rhx, vlane, hx_off(wpar, PT, 2 * m), 16);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[2], hq[3])), rhx, vlane, hx_off(wpar, PT, 2 * m + 1), 16);
-      // publish, first half: a load issued behind the two stores.  Vector memory operations of a wave complete in order,
-      // so once its value has arrived the stores have been acknowledged; the tag store itself follows five K-steps into
-      // the next part (pub_flush), where waiting for that value no longer drains the wave's younger loads.
-      asm volatile("" ::: "memory");
-      pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
-      asm volatile("" ::: "memory");   // (keeps the load here: sunk next to its use it would make that wait a full drain)
+      // publish: the tag store follows five K-steps into the next part (pub_flush), behind an s_waitcnt vmcnt(0) — by then
+      // the two stores above have long been acknowledged and the drain is short
       pub_val = (unsigned)step + 1;
     }
   };

@@ -72,7 +72,6 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   cp.spread = getenv("FNSSL_CLUSTER_SPREAD") ? 1 : 0;
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
-  cp.pub_fence = cluster_pub_fence();
   // status word + tags, and the parity-1 operand records (step 0 reads h_{-1} = 0 from them)
   if (!p.dry) {
     FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, head, st));

@@ -32,7 +32,6 @@ struct F32ClusterParams {
   int groups_per_cluster;
   unsigned spin_limit;  // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
-  int pub_fence;        // 1: s_waitcnt vmcnt(0) in front of every tag store (FNSSL_CLUSTER_PUB_FENCE, see pub_flush)
   int rotate;           // 1: the groups a cluster has beyond a multiple of its waves change hands every step (see the schedule)
   int prio_mode;        // 2 (default): s_setprio 2 during the matrix phase, 0 during the cell update — a wave in its matrix
                         // phase outranks its SIMD neighbours' cell updates at issue; 0: none (FNSSL_F32C_PRIO=9).  Measured
@@ -47,7 +46,7 @@ struct F32ClusterParams {
 template <int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
 __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
   constexpr int H = 128, NS = H / 16, NW = NW_;
-  constexpr bool SUM = (MODE & kSum) != 0;
+  constexpr bool SUM = (MODE & kSum) != 0, SAVE = (MODE & kSave) != 0;   // SAVE: training forward (gates + cell state -> reserve)
   constexpr int QPS = 1 + NV0 + NS0 + NS;
   // DRIFT: a wave starts the recurrent part of its k-th group of a step only when EVERY member has finished its
   // (k - DRIFT)-th: the eight members then read a group's input rows within a few group-times of each other and the seven
@@ -88,19 +87,19 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   auto rec = [&](int q, int j) { return *reinterpret_cast<const v4f*>(lds_rd + (q * 4 + j) * 1024); };
 
   const unsigned st0 = (unsigned)(p.src0.st * 4), sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
-  const rsrc_t rw = make_rsrc(p.wpack[dir]);
   unsigned* const tag_cl = cp.tags + (size_t)cl * cp.groups_per_cluster * 8;
   const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
 
-  // deferred tag store of the previous group-step (the load behind its stores has returned = they are acknowledged)
-  unsigned pub_dep = 0, pub_val = 0;
+  // Deferred tag store of the previous group-step: sc1 payload stores -> s_waitcnt vmcnt(0) (every earlier vector memory
+  // operation of this wave has completed) -> sc1 tag store, the "drained flag" form of MI355X_MICROARCH.md.  Deferring it to
+  // the middle of the next group-step makes the drain short; measured cost against round 3's dependent-load ordering: none
+  // (profiles/r04/e_*).
+  unsigned pub_val = 0;
   unsigned* pub_tag = nullptr;
   auto pub_flush = [&]() {
     if (pub_tag) {
-      if (cp.pub_fence) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // explicit release: every earlier store of this wave has completed
-      unsigned tval = pub_val;
-      asm volatile("; tag store ordered behind %1" : "+v"(tval) : "v"(pub_dep));
-      if (lane == 0) __hip_atomic_store(pub_tag, tval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(pub_tag, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pub_tag = nullptr;
     }
   };
@@ -342,6 +341,16 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       const v4f og = sigmoid4(acc[3]);
       cn = cell4(fg, cprev_cur, ig, gg);
       hn = mul_rn4(og, tanh4(cn));
+      if constexpr (SAVE) {   // what lstm_bwd_kernel reads back (lstm_kernel.h: reserve layout), my slice of this group and step
+        const rsrc_t rres = make_rsrc(reinterpret_cast<const char*>(p.reserve) +
+                                      ((size_t)dir * p.ntasks + task) * p.nsteps * (size_t)(NS * kReserveRecs * 1024));
+        const unsigned rb = (tt * NS + m) * (kReserveRecs * 1024);
+        bst4(ig, rres, vlane, rb);
+        bst4(fg, rres, vlane, rb + 1024);
+        bst4(gg, rres, vlane, rb + 2048);
+        bst4(og, rres, vlane, rb + 3072);
+        bst4(cn, rres, vlane, rb + 4096);
+      }
     }
     asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
     if (ABL & 32) asm volatile("" ::"v"(cn), "v"(hn));
@@ -350,10 +359,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hn), ro, cur.voo, oo + 64 * m, 16);   // sc1: the hand-off
       if (SUM) bst4(add_rn4(hn, skip_cur), ro2, cur.voo2, oo + 64 * m);
     }
-    asm volatile("" ::: "memory");
-    if (!(ABL & 256)) pub_dep = __builtin_bit_cast(unsigned, bld1(rw, 0, 0));
-    asm volatile("" ::: "memory");
-    pub_val = (unsigned)step + 1;
+    pub_val = __builtin_amdgcn_readfirstlane((unsigned)step + 1);   // (wave-uniform: lives in an SGPR until the store)
     pub_tag = (ABL & 256) ? nullptr : tag_g + m;
     if (!more || dead) break;
     cur = nxt;

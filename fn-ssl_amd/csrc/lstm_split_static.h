@@ -20,6 +20,7 @@ namespace fnssl_lstm {
 template <int H, int NW, int M, int SPLIT, int NV0, int NS0, int NS2, int CHQ, int PAD, int MODE, bool DIRECT = false,
           int NV2 = 0>
 __global__ void __launch_bounds__(NW * 64, (NW == 4 && !DIRECT ? 3 : 1)) lstm_split_static_kernel(const LstmParams p) {
+  FNSSL_GUARDED_KERNEL(p);
   constexpr int NS = H / 16, NSL = NS / SPLIT;
   constexpr bool HAS2 = (MODE & kHas2) != 0, SAVE = (MODE & kSave) != 0, SUM = (MODE & kSum) != 0;
   static_assert(!(MODE & kHas1), "single summed input");

@@ -305,10 +305,6 @@ inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int g
   }
   return (long long)per_cu * fnssl::device_cus() >= grid;
 }
-inline int cluster_pub_fence() {   // default decided by measurement, see DESIGN.md (cluster kernels, hand-off ordering)
-  const char* e = getenv("FNSSL_CLUSTER_PUB_FENCE");
-  return e ? atoi(e) : 1;
-}
 inline int cluster_test_stall() {
   const char* e = getenv("FNSSL_CLUSTER_TEST_STALL");
   return e ? atoi(e) : -1;

@@ -256,6 +256,7 @@ def test_split_static_training_forward_equals_generic(dev, mode, H, bidir, c0, c
     res = []
     for no_static in ("0", "1"):
         os.environ["FNSSL_TRAIN_NO_STATIC"] = no_static
+        os.environ["FNSSL_TRAIN_NO_F32_CLUSTER"] = "1"       # (this test is about the split kernels; the cluster kernel has its own)
         try:
             out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
             reserve = torch.full((ops.lstm_reserve_floats(nseq, H, ndir, nsteps),), float("nan"), device=dev)
@@ -263,9 +264,45 @@ def test_split_static_training_forward_equals_generic(dev, mode, H, bidir, c0, c
             res.append((out, reserve))
         finally:
             os.environ.pop("FNSSL_TRAIN_NO_STATIC", None)
+            os.environ.pop("FNSSL_TRAIN_NO_F32_CLUSTER", None)
     assert not torch.isnan(res[0][0]).any()
     assert torch.equal(res[0][0], res[1][0]), "h"
     assert torch.equal(torch.nan_to_num(res[0][1], nan=-7.0), torch.nan_to_num(res[1][1], nan=-7.0)), "reserve"
+
+
+@pytest.mark.parametrize("c0,nb,nt,nf", [(256, 32, 300, 7), (4, 32, 300, 7), (256, 33, 301, 5)])
+def test_cluster_training_forward_equals_split_kernels(dev, monkeypatch, c0, nb, nt, nf):
+    """Round 4: the full-band layers of the training forward at config 4's shard (600 groups x 2 directions on 32 clusters:
+    37.5 groups per cluster, the ones beyond two per wave rotating over the waves) run the cluster-resident kernel with the
+    reserve stores (lstm_f32c.h, kSave) — h AND the reserve bit for bit equal to the 2-waves-per-group split kernels
+    (FNSSL_TRAIN_NO_F32_CLUSTER=1), twice; the third case has a ragged last group and groups that cross utterances."""
+    from fnssl import ops
+    from fnssl import weights as W
+    H = 128
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0, H, True)], seed=990 + c0)
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s], sd["L.bias_hh_l0" + s], c0, 0, dev)
+              for s in ("", "_reverse")]
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    x = torch.randn((nb, nt, nf, c0), generator=g, device=dev) * 0.7
+
+    def run(plan=False):
+        out = torch.full((nb, nt, nf, 2 * H), float("nan"), device=dev)
+        reserve = torch.full((ops.lstm_reserve_floats(nb * nt, H, 2, nf),), float("nan"), device=dev)
+        r = ops.lstm_layer("full", x, None, None, packed, H, out, reserve=reserve, plan_only=plan)
+        return r if plan else (out, reserve)
+
+    monkeypatch.delenv("FNSSL_TRAIN_NO_F32_CLUSTER", raising=False)
+    assert run(plan=True)[0] == "f32_cluster", run(plan=True)
+    a, ra = run()
+    a2, ra2 = run()
+    monkeypatch.setenv("FNSSL_TRAIN_NO_F32_CLUSTER", "1")
+    assert run(plan=True)[0] == "train"
+    b, rb = run()
+    assert not torch.isnan(a).any()
+    assert torch.equal(a, b) and torch.equal(a, a2), "h"
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0)  # noqa: E731  (rows of a ragged last group stay unwritten in both)
+    assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)), "reserve"
 
 
 @pytest.mark.parametrize("online", [True, False])

@@ -1,0 +1,302 @@
+// Cluster-resident back-propagation through time for the H = 128 full-band layers of the FN-SSL training step (round 4;
+// BASELINE config 4: reference = autograd through nn.LSTM, FN-SSL/Lightning/main.py:149-157).
+//
+// Why: lstm_bwd_kernel gives the waves of a workgroup fixed 16-sequence groups, so a launch is paced by its fullest SIMD —
+// config 4's shard has 1200 full-band groups, 2 waves each = 2.34 waves per SIMD, run as 3: the layer sat at 0.44 of the fp32
+// MFMA roof.  The forward of the same layers left that pigeonhole through lstm_f32c.h; this is the same move for the
+// backward pass.  Per step and group the backward is  [dx_t | dh_{t-1}]^T = [W_ih | W_hh]^T da_t^T  — a product whose OUTPUT
+// range (c0g + H = 384 channels = 6 "output slices" of 4 x 16 channels in the packed stream's fake-LSTM arrangement,
+// lstm_train.h) splits over a cluster of 6 CUs: member m keeps output slice m of the transposed weight stream (32 quads =
+// 128 KiB) in LDS for the whole launch, and the cluster's groups are work items its 16 waves take in turn; the groups beyond
+// one per wave change hands every step (a group's state — carried dh, dc — lives in memory), so every SIMD carries the same
+// load over the launch.  A group-step of a member:
+//   phase A (VALU)  the gate gradients of the hidden slices whose dh_{t-1} THIS member produces in phase B (so the carried
+//                   state never crosses CUs): slice 2 + m for every member, plus slice 0 / 1 for members 4 / 5 — written to
+//                   the dA tensor (write-through), then the member's tag of (group) is set to step + 1;
+//   phase B (MFMA)  once all six tags show the step: the whole dA row of the group (32 blocks, 4-deep operand ring, sc1
+//                   loads) against the member's weight slice; dx_t blocks go to the input-gradient tensor, dh_{t-1} blocks
+//                   to the group's carried-state record.
+// Same stream, same k order per output block, same phase-A expressions as lstm_bwd_kernel: bit-identical dA and dx.
+// Waits are bounded and cooperative (status word, no trap), the call enqueues lstm_bwd_kernel behind this kernel as its
+// guarded fallback — exactly as fnssl_lstm_forward does for lstm_f32c.h (include/fnssl.h).
+#pragma once
+
+#include "lstm_static.h"
+#include "lstm_train.h"
+
+#pragma clang fp contract(off)
+
+namespace fnssl_lstm {
+
+constexpr int kBwdcWaves = 16;
+
+struct BwdClusterParams {
+  unsigned* tags;       // [cluster][group in cluster][16]: words 0..7 = per-member "dA of step s written" (s + 1), 8..15 = "phase B of
+                        // step s done" (s + 1); zeroed before the launch
+  unsigned* status;     // one word, zeroed before the launch: 0 = fine, else the code of the first wave that gave up
+  int clusters_per_dir;
+  int groups_per_cluster;
+  int members;          // CUs per cluster = output slices of the layer (co_pad / 64)
+  int clusters_per_xcd; // 32 / members
+  unsigned spin_limit;
+  int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
+  int rotate;
+  int ablate;           // ablate build only (FNSSL_BWDC_ABLATE): timing experiments, wrong results by construction
+};
+
+// ABLRT (make ABLATE=1 only): run-time ablation bits cp.ablate — 1 no tag waits, 2 no phase-A loads, 4 no phase-A stores,
+// 8 no dA loads in phase B, 16 no output stores, 32 no drain in front of the "phase B done" tag, 64 no phase A at all
+template <int NW_ = kBwdcWaves, bool ABLRT = false>
+__global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, const BwdClusterParams cp) {
+  constexpr int H = 128, NS = H / 16, NW = NW_;
+  const int ABL = ABLRT ? cp.ablate : 0;
+  constexpr int NVB = 4 * H / 16;                             // 16-channel blocks of a dA row = data quads per output slice
+  constexpr int XD = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int b = blockIdx.x;
+  const int kx = b >> 3;                                      // index inside the XCD (blocks are dealt round-robin: speed only)
+  const int m = kx % cp.members;                              // member = output slice
+  const int cx = kx / cp.members;
+  if (cx >= cp.clusters_per_xcd) return;                      // CUs that do not make a whole cluster on their XCD
+  const int cl = cx * 8 + (b & 7);
+  const int ncl = cp.clusters_per_dir * p.ndir;
+  if (cl >= ncl) return;
+  const int dir = cl / cp.clusters_per_dir;
+  const int ck = cl - dir * cp.clusters_per_dir;
+  const int g0 = ck * cp.groups_per_cluster;
+  const int g1 = g0 + cp.groups_per_cluster < p.ntasks ? g0 + cp.groups_per_cluster : p.ntasks;
+  if (__hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+  if (cl == 0 && m == cp.stall_member) return;                // test knob: a member that never shows up
+
+  const int lane = threadIdx.x & 63;
+  const int n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool rev = dir == 1;
+  const unsigned vlane = lane * 16;
+
+  {   // my output slice of the transposed weight stream -> LDS, once (the slice's leading "bias" quad is all zeros: skipped)
+    const int qps = 1 + NVB;
+    const v4f* src = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(p.wpack[dir]) + ((size_t)m * qps + 1) * 4096);
+    v4f* dst = reinterpret_cast<v4f*>(smem);
+    for (int i = threadIdx.x; i < NVB * 4 * 64; i += NW * 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const char* const lds_rd = smem + lane * 16;
+  auto rec = [&](int q, int j) { return *reinterpret_cast<const v4f*>(lds_rd + (q * 4 + j) * 1024); };
+
+  // which hidden slices this member owns in phase A = the ones whose dh_{t-1} its phase B produces: output block qq of
+  // output slice m covers channels qq hq + 16 m .. + 15 of [dx | dh]
+  const int hq = p.co_pad >> 2;
+  int own[4], nown = 0;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int ob = qq * hq + 16 * m;
+    own[qq] = (ob >= p.c0g && ob < p.c0g + H) ? (ob - p.c0g) >> 4 : -1;
+    nown += own[qq] >= 0;
+  }
+  (void)nown;
+
+  const unsigned sdh = (unsigned)(p.dh.st * 4), sda = (unsigned)(p.da_st * 4), sdx = (unsigned)(p.dx_st * 4);
+  unsigned* const tag_cl = cp.tags + (size_t)cl * cp.groups_per_cluster * 16;
+  const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
+  const v4f one4 = v4f{1.f, 1.f, 1.f, 1.f};
+
+  if (g0 + w >= g1) return;                                   // (a wave without a group: nobody waits for it)
+  bool dead = false;
+  auto bounded_wait = [&](auto ready, auto reload, unsigned code) {
+    for (unsigned spins = 0; !ready(); ++spins) {
+      __builtin_amdgcn_s_sleep(8);
+      reload();
+      const bool out = spins > cp.spin_limit;
+      if (out || (spins & 63) == 63) {
+        if (out) {
+          if (lane == 0) __hip_atomic_store(cp.status, code | (unsigned)(cl & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return false;
+        }
+        if (__hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      }
+    }
+    return true;
+  };
+
+  // schedule of a wave within a step: its regular group g0 + w + i NW (i < FULL / NW), then at most one leftover group
+  // g0 + FULL + j, j = (w - step) mod NW < LEFT (lstm_f32c.h)
+  const int NGR = g1 - g0;
+  const bool rot = cp.rotate && NGR >= NW;
+  const int FULL = rot ? (NGR / NW) * NW : NGR, LEFT = NGR - FULL;
+
+  // per-lane addressing of a group (lstm_f32c.h "locate"): the wave's first sequence is its lowest address
+  struct Grp {
+    unsigned vdh, vda, vdx;
+    bool valid;
+  };
+  auto locate = [&](int task, Grp& gr, rsrc_t& rdh, rsrc_t& rda, rsrc_t& rdx) {
+    const int q0 = task * 16;
+    const int qo0 = q0 / p.q_inner, qi0 = q0 - qo0 * p.q_inner;
+    gr.valid = q0 + n < p.nseq;
+    const int d = q0 + n < p.nseq ? n : p.nseq - 1 - q0;
+    const bool crossed = qi0 + d >= p.q_inner;
+    auto one = [&](const float* base, long long so, long long si, int extra, unsigned& voff) {
+      const long long delta = (long long)d * si + (crossed ? so - (long long)p.q_inner * si : 0ll);
+      voff = (unsigned)(delta * 4) + (unsigned)(extra * 4);
+      return make_rsrc(base + ((long long)qo0 * so + (long long)qi0 * si));
+    };
+    rdh = one(p.dh.p, p.dh.so, p.dh.si, dir * H + 4 * g, gr.vdh);
+    rda = one(p.da, p.da_so, p.da_si, dir * 4 * H + 4 * g, gr.vda);
+    gr.vdx = 0;
+    rdx = p.c0g ? one(p.dx, p.dx_so, p.dx_si, dir * p.c0g + 4 * g, gr.vdx) : rdh;
+  };
+
+  int task = g0 + w, step = 0;
+  unsigned* pub_tag = nullptr;       // deferred "phase B done" tag of the previous group-step
+  unsigned pub_val = 0;
+  auto pub_flush = [&]() {
+    if (pub_tag) {
+      if (!(ABL & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(pub_tag, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pub_tag = nullptr;
+    }
+  };
+
+  for (;;) {
+    Grp gr;
+    rsrc_t rdh, rda, rdx;
+    locate(task, gr, rdh, rda, rdx);
+    const unsigned tt = rev ? step : p.nsteps - 1 - step;      // the forward direction's gradient flows T-1 .. 0
+    const bool has_prev = step + 1 < p.nsteps;                 // the forward pass had a step before tt
+    const unsigned tp = has_prev ? (rev ? tt + 1 : tt - 1) : tt;
+    const unsigned oa = tt * sda;
+    const rsrc_t rres = make_rsrc(reinterpret_cast<const char*>(p.reserve) +
+                                  ((size_t)dir * p.ntasks + task) * p.nsteps * (size_t)(NS * kReserveRecs * 1024));
+    const rsrc_t rsc = make_rsrc(reinterpret_cast<const char*>(p.scratch) +
+                                 ((size_t)dir * (p.ntasks + 16) + task) * (2 * NS * 1024));
+    unsigned* const tag_g = tag_cl + (size_t)(task - g0) * 16;
+    pub_flush();
+    // a leftover group's previous step ran on ANOTHER wave of this member: its carried state is final once that wave's
+    // "phase B done" tag shows the step (a regular group is this wave's own: program order)
+    if (task >= g0 + FULL && step > 0 && !dead && !(ABL & 1)) {
+      unsigned tv = __hip_atomic_load(tag_g + 8 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dead = !bounded_wait([&]() { return tv >= (unsigned)step; },
+                           [&]() { tv = __hip_atomic_load(tag_g + 8 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x60000u);
+    }
+
+    // ---- phase A: gate gradients of my hidden slices (the expressions of lstm_bwd_kernel, in its order) -------------
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int s = own[qq];
+      if (s < 0 || (ABL & 64)) continue;
+      const unsigned rb = (tt * NS + s) * (kReserveRecs * 1024);
+      v4f ig = one4 * 0.5f, fg = ig, gg = ig, og = ig, ct = ig, dhu = ig;
+      v4f cprev = zero4, dhc = zero4, dcc = zero4;
+      if (!(ABL & 2)) {
+        ig = bld4(rres, vlane, rb), fg = bld4(rres, vlane, rb + 1024), gg = bld4(rres, vlane, rb + 2048);
+        og = bld4(rres, vlane, rb + 3072), ct = bld4(rres, vlane, rb + 4096);
+        dhu = bld4(rdh, gr.vdh, tt * sdh + 64 * s);
+        if (has_prev) cprev = bld4(rres, vlane, (tp * NS + s) * (kReserveRecs * 1024) + 4096);
+        if (step > 0) {
+          dhc = bld4_l2(rsc, vlane, s * 1024);
+          dcc = bld4_l2(rsc, vlane, (NS + s) * 1024);
+        }
+      }
+      v4f dh = dhu + dhc, dc = dcc;
+      const v4f tc = tanh4(ct);
+      dc += dh * og * (one4 - tc * tc);
+      const v4f dao = dh * tc * og * (one4 - og);
+      const v4f dai = dc * gg * ig * (one4 - ig);
+      const v4f daf = dc * cprev * fg * (one4 - fg);
+      const v4f dag = dc * ig * (one4 - gg * gg);
+      if (!(ABL & 4)) bst4(dc * fg, rsc, vlane, (NS + s) * 1024);
+      if (gr.valid && !(ABL & 4)) {   // write-through: the other members read these rows in their phase B
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, dai), rda, gr.vda, oa + 64 * s, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, daf), rda, gr.vda, oa + 4 * H + 64 * s, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, dag), rda, gr.vda, oa + 8 * H + 64 * s, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, dao), rda, gr.vda, oa + 12 * H + 64 * s, 16);
+      }
+    }
+    // publish my dA rows of (group, step): payload stores -> vmcnt(0) -> tag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(tag_g + m, (unsigned)step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- phase B: my output slice of [dx | dh_prev]^T = [W_ih | W_hh]^T da^T -------------------------------------
+    if (!dead && !(ABL & 1)) {
+      unsigned tv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool mine = (lane & 7) < cp.members;
+      dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(mine && tv < (unsigned)step + 1) == 0; },
+                           [&]() { tv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x50000u);
+    }
+    __builtin_amdgcn_s_setprio(2);
+    v4f xr[XD];
+    static_for<XD>([&](auto v) { xr[v.value] = (ABL & 8) ? one4 : bld4_l2(rda, gr.vda, oa + 64 * v.value); });
+    v4f acc[4] = {zero4, zero4, zero4, zero4};
+    v4f ra[4];
+    static_for<4>([&](auto j) { ra[j.value] = rec(0, j.value); });
+    static_for<NVB>([&](auto vc) {
+      constexpr int V = decltype(vc)::value;
+      const v4f xb = xr[V % XD];
+      MFMA4(acc, ra[0], xb.x);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (V + 1 < NVB) ra[0] = rec(V + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA4(acc, ra[1], xb.y);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (V + 1 < NVB) ra[1] = rec(V + 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA4(acc, ra[2], xb.z);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (V + 1 < NVB) ra[2] = rec(V + 1, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA4(acc, ra[3], xb.w);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (V + 1 < NVB) ra[3] = rec(V + 1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (V + XD < NVB)
+        if (!(ABL & 8)) xr[V % XD] = bld4_l2(rda, gr.vda, oa + 64 * (V + XD));
+    });
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int ob = qq * hq + 16 * m;                          // first channel of this 16-channel block
+      if (ABL & 16) {
+        if (acc[qq].x == 123.456f) bst4(acc[qq], rsc, vlane, 0);
+      } else if (ob < p.c0g) {
+        if (gr.valid) bst4(acc[qq], rdx, gr.vdx, tt * sdx + 4 * ob);
+      } else if (ob < p.c0g + H) {
+        bst4(acc[qq], rsc, vlane, ((ob - p.c0g) >> 4) * 1024);
+      }
+    }
+    pub_val = (unsigned)step + 1;
+    pub_tag = tag_g + 8 + m;
+    if (dead) break;
+
+    // ---- next work item
+    if (task < g0 + FULL && task + NW < g0 + FULL) {
+      task += NW;
+    } else {
+      const int j = (w - step) & (NW - 1);
+      if (task < g0 + FULL && j < LEFT) {
+        task = g0 + FULL + j;
+      } else {
+        task = g0 + w;
+        ++step;
+      }
+    }
+    if (step >= p.nsteps) break;
+  }
+  pub_flush();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NW_ = kBwdcWaves, bool ABLRT = false>
+int launch_bwdc_k(const BwdParams& p, const BwdClusterParams& cp, hipStream_t st) {
+  const size_t lds = (size_t)(4 * 128 / 16) * 4096;             // 32 quads = 128 KiB
+  auto k = lstm_bwdc_kernel<NW_, ABLRT>;
+  FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int nwg = fnssl::device_cus();
+  if (!cluster_grid_fits(reinterpret_cast<const void*>(k), NW_ * 64, lds, nwg)) return kNoCluster;
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(NW_ * 64), lds, st, p, cp);
+  FNSSL_CHECK_LAUNCH("lstm_bwdc_kernel");
+  return FNSSL_OK;
+}
+
+}  // namespace fnssl_lstm

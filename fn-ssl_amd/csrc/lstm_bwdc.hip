@@ -1,0 +1,48 @@
+// Host side of the cluster-resident BPTT kernel (lstm_bwdc.h): geometry, workspace carve-up, launch.
+#include "common.h"
+
+#include "lstm_bwdc.h"
+
+namespace fnssl_lstm {
+
+// bytes behind the carried-state records of fnssl_lstm_backward's workspace: status word (256 B) + tag arrays
+size_t bwdc_bytes(int nseq, int ndir) {
+  const size_t tasks = (size_t)(nseq + 15) / 16;
+  return 256 + (tasks + 256) * (size_t)ndir * 16 * sizeof(unsigned);
+}
+
+// does the cluster kernel take this layer?  H = 128, the output slices make whole clusters inside an XCD, and at least half
+// the waves of a cluster get a group (config 4, block 1: 2 members, 9.4 groups per cluster — 10.7 against 13.4 ms on the
+// split kernels; fewer: the split kernels fill the chip better).  FNSSL_BWD_NO_CLUSTER=1 turns it off.
+bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
+  if (H != 128 || env_int("FNSSL_BWD_NO_CLUSTER", 1, 1)) return false;
+  const int ncu = fnssl::device_cus();
+  const int per_xcd = ncu / 8;
+  cp.members = p.co_pad / 64;
+  if (ncu % 8 || cp.members < 1 || cp.members > 8 || cp.members > per_xcd) return false;
+  cp.clusters_per_xcd = per_xcd / cp.members;
+  const int clusters = cp.clusters_per_xcd * 8;
+  if (clusters % p.ndir) return false;
+  cp.clusters_per_dir = clusters / p.ndir;
+  cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
+  const int min_groups = env_int("FNSSL_BWD_CLUSTER_MIN_GROUPS", 1, 1 << 20);
+  return cp.groups_per_cluster >= (min_groups ? min_groups : kBwdcWaves / 2);
+}
+
+// ws = the region bwdc_bytes() sizes.  FNSSL_OK, kNoCluster, or an error.
+int backward_cluster(const BwdParams& p, BwdClusterParams cp, void* ws, hipStream_t st) {
+  cp.status = static_cast<unsigned*>(ws);
+  cp.tags = cp.status + 64;
+  cp.spin_limit = cluster_spin_limit();
+  cp.stall_member = cluster_test_stall();
+  cp.rotate = !env_int("FNSSL_BWD_CLUSTER_NO_ROTATE", 1, 1);
+  if (p.dry) return FNSSL_OK;
+  const size_t tag_bytes = (size_t)cp.clusters_per_dir * p.ndir * cp.groups_per_cluster * 16 * sizeof(unsigned);
+  FNSSL_HIP(hipMemsetAsync(ws, 0, 256 + tag_bytes, st));
+#ifdef FNSSL_BUILD_ABLATE
+  if ((cp.ablate = env_int("FNSSL_BWDC_ABLATE", 1, 1 << 20)) != 0) return launch_bwdc_k<kBwdcWaves, true>(p, cp, st);
+#endif
+  return launch_bwdc_k<kBwdcWaves>(p, cp, st);
+}
+
+}  // namespace fnssl_lstm

@@ -35,6 +35,9 @@ struct BwdParams {
   int nseq, q_inner, nsteps, ndir, ntasks;
   int wgs_per_dir, task0, task1;
   int quads_per_slice, chq, pad;
+  // guarded fallback launch behind lstm_bwdc_kernel (lstm_bwdc.h): runs only if *guard != 0 (LstmParams.guard)
+  const unsigned* guard = nullptr;
+  int dry = 0;                 // host only (fnssl_lstm_backward_plan): no launch
 };
 
 inline int bwd_co_pad(int c0g, int H) { return (c0g + H + 63) / 64 * 64; }
@@ -53,6 +56,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
   constexpr int NVB = 4 * H / 16;   // 16-channel blocks of one dA row
   static_assert(NS % SPLIT == 0 && NW % SPLIT == 0, "split geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.guard && __hip_atomic_load(p.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // uniform for the grid
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -267,6 +271,7 @@ template <int H, int NW, int M, int SPLIT = 1, bool DIRECT = false>
 int launch_bwd_k(const BwdParams& p, int nwg, hipStream_t st) {
   const size_t lds = DIRECT ? 0 : (size_t)2 * p.chq * SPLIT * 4096;
   auto k = lstm_bwd_kernel<H, NW, M, SPLIT, DIRECT>;
+  if (p.dry) return FNSSL_OK;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));

@@ -6,12 +6,17 @@
 
 #include "lstm_train.h"
 #include "lstm_split_static.h"
+#include "lstm_bwdc.h"
 
 using namespace fnssl_lstm;
 
 namespace fnssl_lstm {
 
 using fnssl::device_cus;
+
+size_t bwdc_bytes(int nseq, int ndir);                                                    // lstm_bwdc.hip
+bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp);
+int backward_cluster(const BwdParams& p, BwdClusterParams cp, void* ws, hipStream_t st);
 
 struct Geometry {
   int nw, split, t0, t1;
@@ -85,6 +90,13 @@ int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
 
 }  // namespace fnssl_lstm
 
+// carried dh / dc records (one region per direction and group, 16 spare), 256-byte aligned end
+static size_t bwd_scratch_bytes(int nseq, int hidden, int ndir) {
+  const size_t tasks = (size_t)(nseq + 15) / 16 + 16;
+  return tasks * ndir * (size_t)(2 * (hidden / 16)) * 1024 + 256;
+}
+static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dry, int* family);
+
 extern "C" {
 
 size_t fnssl_lstm_reserve_bytes(int nseq, int hidden, int ndir, int nsteps) {
@@ -127,11 +139,28 @@ int fnssl_lstm_pack_bwd(const float* w_ih, const float* w_hh, int c_in, int c0g,
 
 size_t fnssl_lstm_bwd_workspace_bytes(int nseq, int hidden, int ndir) {
   if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
-  const size_t tasks = (size_t)(nseq + 15) / 16 + 16;
-  return tasks * ndir * (size_t)(2 * (hidden / 16)) * 1024 + 256;
+  return bwd_scratch_bytes(nseq, hidden, ndir) + bwdc_bytes(nseq, ndir);
 }
 
-int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) {
+int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) { return lstm_backward_impl(d, stream, 0, nullptr); }
+
+int fnssl_lstm_backward_plan(const fnssl_lstm_bwd_desc* d, int* family) { return lstm_backward_impl(d, nullptr, 1, family); }
+
+int fnssl_lstm_backward_status(const void* workspace, size_t workspace_bytes, int nseq, int hidden, int ndir, void* stream,
+                               unsigned* status) {
+  FNSSL_REQUIRE(workspace && status, "lstm_backward_status: null pointer");
+  FNSSL_REQUIRE(workspace_bytes >= fnssl_lstm_bwd_workspace_bytes(nseq, hidden, ndir) && nseq > 0,
+                "lstm_backward_status: not a workspace of this layer size");
+  hipStream_t st = fnssl::as_stream(stream);
+  FNSSL_HIP(hipMemcpyAsync(status, static_cast<const char*>(workspace) + bwd_scratch_bytes(nseq, hidden, ndir), sizeof(unsigned),
+                           hipMemcpyDeviceToHost, st));
+  FNSSL_HIP(hipStreamSynchronize(st));
+  return FNSSL_OK;
+}
+
+}  // extern "C"
+
+static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dry, int* family) {
   FNSSL_REQUIRE(d, "lstm_backward: null descriptor");
   const int H = d->hidden;
   FNSSL_REQUIRE(H == 128 || H == 256, "lstm_backward: hidden size %d unsupported (128/256)", H);
@@ -183,9 +212,26 @@ int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) {
   p.ndir = d->ndir;
   p.ntasks = (d->nseq + 15) / 16;
   p.quads_per_slice = bwd_quads_per_slice(H);
-  hipStream_t st = fnssl::as_stream(stream);
+  p.dry = dry;
+  hipStream_t st = dry ? nullptr : fnssl::as_stream(stream);
   const double flops = 2.0 * 4 * H * (double)(d->c0g + H) * d->nseq * (double)d->nsteps * d->ndir;
-  fnssl::TimedLaunch tl(H == 128 ? "lstm_bwd_h128" : "lstm_bwd_h256", st, flops);
+  fnssl::TimedLaunch tl(dry ? nullptr : H == 128 ? "lstm_bwd_h128" : "lstm_bwd_h256", st, flops);
+  if (family) *family = FNSSL_LSTM_FAMILY_BWD;
+  // full-band layers of a large enough shard: the cluster-resident kernel (lstm_bwdc.h), then — in the same call — the
+  // kernels below as its guarded fallback (they return at once unless the cluster kernel recorded a hand-off it gave up on)
+  BwdClusterParams cp{};
+  if (bwdc_handles(p, H, cp)) {
+    void* cws = static_cast<char*>(d->workspace) + bwd_scratch_bytes(d->nseq, H, d->ndir);
+    const int rc = backward_cluster(p, cp, cws, st);
+    if (rc == FNSSL_OK) {
+      if (family) *family = FNSSL_LSTM_FAMILY_BWD_CLUSTER;
+      if (dry) return FNSSL_OK;
+      p.guard = static_cast<const unsigned*>(cws);
+    } else if (rc != kNoCluster) {
+      return rc;
+    }
+  }
+  if (dry) return FNSSL_OK;
   const int nso = p.co_pad / 64;
   const int max_split = nso % 4 == 0 ? 4 : nso % 2 == 0 ? 2 : 1;   // output slices divide among the waves
   return plan_rounds(p.ntasks, p.ndir, max_split, H == 256 ? 6 : 2, [&](const Geometry& gm) {
@@ -199,5 +245,3 @@ int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream) {
     return H == 128 ? launch_bwd<128>(gm.nw, gm.split, p, nwg, st) : launch_bwd<256>(gm.nw, gm.split, p, nwg, st);
   });
 }
-
-}  // extern "C"

@@ -22,11 +22,11 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 # `make ABLATE=1` build with the timing-ablation twins) — never a different implementation, never a fallback
 LIB_PATH = os.environ.get("FNSSL_LIB_PATH", LIB_PATH)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 CH_MODE = {"M": 0, "MM": 1}
 # kernel families fnssl_lstm_plan reports (include/fnssl.h: FNSSL_LSTM_FAMILY_*)
 LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2", 4: "split", 5: "split_static", 6: "f32_cluster",
-               7: "static3", 8: "bf16", 9: "bf16_solo", 10: "bf16_pair", 11: "bf16_cluster", 12: "train"}
+               7: "static3", 8: "bf16", 9: "bf16_solo", 10: "bf16_pair", 11: "bf16_cluster", 12: "train", 13: "bwd", 14: "bwd_cluster"}
 
 # every symbol include/fnssl.h declares
 SYMBOLS = [
@@ -40,7 +40,7 @@ SYMBOLS = [
     "fnssl_conv3x3_packed_bytes_bf16x", "fnssl_conv3x3_pack_bf16x", "fnssl_conv3x3_causal_bf16x",
     "fnssl_avgpool_time_bf16",
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
-    "fnssl_lstm_backward", "fnssl_lstm_weight_grads_workspace_bytes", "fnssl_lstm_weight_grads", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
+    "fnssl_lstm_backward", "fnssl_lstm_backward_plan", "fnssl_lstm_backward_status", "fnssl_lstm_weight_grads_workspace_bytes", "fnssl_lstm_weight_grads", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
     "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select", "fnssl_mfma_f32_peak",
     "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
@@ -203,6 +203,8 @@ def load():
     lib.fnssl_lstm_bwd_workspace_bytes.argtypes = [i, i, i]
     lib.fnssl_lstm_bwd_workspace_bytes.restype = sz
     lib.fnssl_lstm_backward.argtypes = [C.POINTER(LstmBwdDesc), vp]
+    lib.fnssl_lstm_backward_plan.argtypes = [C.POINTER(LstmBwdDesc), C.POINTER(C.c_int)]
+    lib.fnssl_lstm_backward_status.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_uint)]
     lib.fnssl_lstm_plan_rounds.argtypes = [i, i, i, i, vp, i]
     lib.fnssl_lstm_plan.argtypes = [C.POINTER(LstmDesc), vp, vp]
     lib.fnssl_mfma_f32_peak.argtypes = [vp, sz, i, i, vp, vp]

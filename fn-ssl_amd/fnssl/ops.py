@@ -514,12 +514,14 @@ def pack_lstm_bwd_host(w_ih, w_hh, c0g: int) -> np.ndarray:
 
 
 @on_device
-def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: int):
+def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: int, plan_only: bool = False,
+                  status: bool = False):
     """Back-propagation through time of one (bi)LSTM layer.
 
     dh: upstream gradient, logical [nb, nt, nf, ndir*hidden]; da (written): logical [nb, nt, nf, ndir*4*hidden]
     pre-activation gate gradients; dx (written, or None when c0g == 0): logical [nb, nt, nf, ndir*c0g], one slab
-    per direction.  ``mode`` as in lstm_layer."""
+    per direction.  ``mode`` as in lstm_layer.  ``plan_only``: launch nothing, return the kernel family name the call
+    would take (fnssl_lstm_backward_plan); ``status``: also return the cluster kernel's status word (synchronises)."""
     _need_dev(reserve, dh, da, dx, *packed_bwd)
     ndir = len(packed_bwd)
     nb, nt, nf = dh.shape[:3]
@@ -547,7 +549,16 @@ def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: 
     lib = _lib.load()
     ws = _workspace(lib.fnssl_lstm_bwd_workspace_bytes(d.nseq, hidden, ndir), dh.device, "lstm_bwd")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if plan_only:
+        fam = C.c_int(0)
+        check(lib.fnssl_lstm_backward_plan(C.byref(d), C.byref(fam)), "lstm_backward_plan")
+        return _lib.LSTM_FAMILY[fam.value]
     check(lib.fnssl_lstm_backward(C.byref(d), _stream()), "lstm_backward")
+    if status:
+        word = C.c_uint(0)
+        check(lib.fnssl_lstm_backward_status(ws.data_ptr(), ws.numel(), d.nseq, hidden, ndir, _stream(), C.byref(word)),
+              "lstm_backward_status")
+        return da, dx, word.value
     return da, dx
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 16
+#define FNSSL_ABI_VERSION 17
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -242,6 +242,8 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
 #define FNSSL_LSTM_FAMILY_BF16_PAIR 10      /* pair-split wide bf16 kernels (lstm_bf16p.h)                      */
 #define FNSSL_LSTM_FAMILY_BF16_CLUSTER 11   /* cluster-resident bf16 kernels (lstm_bf16c.h) + guarded fallback  */
 #define FNSSL_LSTM_FAMILY_TRAIN 12          /* reserve-saving training forward (lstm_train.hip)                 */
+#define FNSSL_LSTM_FAMILY_BWD 13            /* fnssl_lstm_backward_plan: per-wave / split BPTT kernels (lstm_train.h) */
+#define FNSSL_LSTM_FAMILY_BWD_CLUSTER 14    /* ... cluster-resident BPTT kernel (lstm_bwdc.h) + guarded fallback */
 int fnssl_lstm_plan(const fnssl_lstm_desc* d, int* family, int* rounds);
 
 /* Status word the cluster-resident kernels left in a workspace that fnssl_lstm_forward has used with the same
@@ -289,6 +291,19 @@ typedef struct {
 } fnssl_lstm_bwd_desc;
 
 int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream);
+
+/* Same contract as fnssl_lstm_forward's cluster kernels (above): for the H = 128 full-band layers of a large shard the
+ * call launches the cluster-resident BPTT kernel (output slices of [W_ih | W_hh]^T over clusters of co_pad / 64 CUs,
+ * hand-offs through memory with bounded, cooperative waits — never a trap) and, behind it in the same call, the per-wave /
+ * split kernels as its guarded fallback, which recompute da and dx from the reserve if — and only if — the cluster kernel
+ * recorded a hand-off it gave up on.  Results are bit-identical either way.
+ *   fnssl_lstm_backward_plan    host only, launches nothing: the FNSSL_LSTM_FAMILY_BWD* code the call would take;
+ *   fnssl_lstm_backward_status  the status word the last call left in `workspace` (0: the cluster kernel completed or was
+ *                               not used; else (reason << 16 | cluster) of the first wave that gave up, the fallback has
+ *                               run); synchronises `stream`.                                                          */
+int fnssl_lstm_backward_plan(const fnssl_lstm_bwd_desc* d, int* family);
+int fnssl_lstm_backward_status(const void* workspace, size_t workspace_bytes, int nseq, int hidden, int ndir, void* stream,
+                               unsigned* status);
 
 /*
  * Weight gradients of one LSTM layer (what autograd accumulates into nn.LSTM's parameters; reference

@@ -305,6 +305,90 @@ def test_cluster_training_forward_equals_split_kernels(dev, monkeypatch, c0, nb,
     assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)), "reserve"
 
 
+@pytest.mark.parametrize("c0g,nb,nt,nf", [(256, 32, 300, 7), (256, 33, 301, 5), (0, 32, 300, 7)])
+def test_cluster_bptt_equals_split_kernels(dev, monkeypatch, c0g, nb, nt, nf):
+    """Round 4: back-propagation through time of the H = 128 full-band layers at config 4's shard on the cluster-resident
+    kernel (lstm_bwdc.h: the 6 output slices of [W_ih | W_hh]^T over clusters of 6 CUs, 30 groups per cluster, the ones
+    beyond one per wave rotating) — dA AND dx bit for bit equal to the 2-waves-per-group split kernels
+    (FNSSL_BWD_NO_CLUSTER=1), twice, status word 0; the second case has a ragged last group and groups that cross
+    utterances; the third is block 1's layer (no input gradient: 2 output slices, clusters of 2 CUs, 4 hidden slices of
+    gate gradients per member)."""
+    from fnssl import ops
+    from fnssl import weights as W
+    H = 128
+    c_in = c0g if c0g else 16
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c_in, H, True)], seed=770 + nb)
+    sfx = ("", "_reverse")
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s], sd["L.bias_hh_l0" + s], c_in, 0, dev)
+              for s in sfx]
+    bw = [torch.from_numpy(ops.pack_lstm_bwd_host(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], c0g)).to(dev) for s in sfx]
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    x = torch.randn((nb, nt, nf, c_in), generator=g, device=dev) * 0.7
+    dh = torch.randn((nb, nt, nf, 2 * H), generator=g, device=dev) * 0.3
+    out = torch.empty((nb, nt, nf, 2 * H), device=dev)
+    reserve = torch.zeros((ops.lstm_reserve_floats(nb * nt, H, 2, nf),), device=dev)
+    ops.lstm_layer("full", x, None, None, packed, H, out, reserve=reserve)
+
+    def run(plan=False):
+        da = torch.full((nb, nt, nf, 2 * 4 * H), float("nan"), device=dev)
+        dx = torch.full((nb, nt, nf, 2 * c0g), float("nan"), device=dev) if c0g else None
+        if plan:
+            return ops.lstm_backward("full", reserve, dh, da, dx, bw, H, c0g, plan_only=True)
+        _, _, word = ops.lstm_backward("full", reserve, dh, da, dx, bw, H, c0g, status=True)
+        return da, (dx if c0g else torch.zeros(1, device=dev)), word
+
+    monkeypatch.delenv("FNSSL_BWD_NO_CLUSTER", raising=False)
+    assert run(plan=True) == "bwd_cluster"
+    a, xa, wa = run()
+    a2, xa2, _ = run()
+    monkeypatch.setenv("FNSSL_BWD_NO_CLUSTER", "1")
+    assert run(plan=True) == "bwd"
+    b, xb, wb = run()
+    assert wa == 0 and wb == 0
+    assert not torch.isnan(a).any() and not torch.isnan(xa).any()
+    assert torch.equal(a, b) and torch.equal(a, a2), "dA"
+    assert torch.equal(xa, xb) and torch.equal(xa, xa2), "dx"
+
+
+def test_cluster_bptt_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch):
+    """A member of cluster 0 that never shows up (FNSSL_CLUSTER_TEST_STALL): the waiting waves give up after the bounded
+    number of spins, record a status word, every workgroup drains — no trap, the device stays usable — and the guarded
+    fallback kernels of the same fnssl_lstm_backward call recompute dA and dx, bit-identical to the split kernels."""
+    from fnssl import ops
+    from fnssl import weights as W
+    H, c0g, nb, nt, nf = 128, 256, 32, 300, 4
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0g, H, True)], seed=31)
+    sfx = ("", "_reverse")
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s], sd["L.bias_hh_l0" + s], c0g, 0, dev)
+              for s in sfx]
+    bw = [torch.from_numpy(ops.pack_lstm_bwd_host(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], c0g)).to(dev) for s in sfx]
+    g = torch.Generator(device=dev)
+    g.manual_seed(8)
+    x = torch.randn((nb, nt, nf, c0g), generator=g, device=dev) * 0.7
+    dh = torch.randn((nb, nt, nf, 2 * H), generator=g, device=dev) * 0.3
+    out = torch.empty((nb, nt, nf, 2 * H), device=dev)
+    reserve = torch.zeros((ops.lstm_reserve_floats(nb * nt, H, 2, nf),), device=dev)
+    ops.lstm_layer("full", x, None, None, packed, H, out, reserve=reserve)
+
+    def run():
+        da = torch.full((nb, nt, nf, 2 * 4 * H), float("nan"), device=dev)
+        dx = torch.full((nb, nt, nf, 2 * c0g), float("nan"), device=dev)
+        return ops.lstm_backward("full", reserve, dh, da, dx, bw, H, c0g, status=True)
+
+    monkeypatch.setenv("FNSSL_BWD_NO_CLUSTER", "1")
+    b, xb, _ = run()
+    monkeypatch.delenv("FNSSL_BWD_NO_CLUSTER")
+    monkeypatch.setenv("FNSSL_CLUSTER_TEST_STALL", "3")
+    monkeypatch.setenv("FNSSL_CLUSTER_SPIN_LIMIT", "2000")
+    a, xa, word = run()
+    assert word != 0 and (word >> 16) in (5, 6) and (word & 0xffff) == 0, hex(word)
+    assert torch.equal(a, b) and torch.equal(xa, xb)
+    monkeypatch.delenv("FNSSL_CLUSTER_TEST_STALL")
+    a, xa, word = run()
+    assert word == 0 and torch.equal(a, b) and torch.equal(xa, xb)
+
+
 @pytest.mark.parametrize("online", [True, False])
 def test_c_abi_training_step_matches_python_engine(dev, online):
     """fnssl_train_backward / fnssl_train_step (the whole step behind the C ABI, weight gradients through rocBLAS called

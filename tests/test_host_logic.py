@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.fnssl_abi_version() == _lib.ABI_VERSION == 16
+    assert lib.fnssl_abi_version() == _lib.ABI_VERSION == 17
 
 
 def test_shape_helpers_match_reference_formulas():

@@ -60,7 +60,7 @@ for c0g in (256, 0):
     line("cluster kernel, no rotation")
     del os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"]
     if ABL_LIB:
-        for m in (1, 2, 4, 6, 64, 65, 8, 16, 32, 8 | 16 | 32, 1 | 8 | 16 | 32 | 64):
+        for m in (128, 256, 384, 2, 4, 8, 1 | 8 | 16 | 32 | 64):
             os.environ["FNSSL_BWDC_ABLATE"] = str(m)
             line("cluster kernel, ablate %d" % m)
         del os.environ["FNSSL_BWDC_ABLATE"]

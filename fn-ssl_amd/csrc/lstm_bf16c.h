@@ -27,10 +27,11 @@
 //     (step + 1) and zeroed by the host before every call; the records are double-buffered by step parity: a member can be
 //     at most one step ahead of the slowest one, because step t + 1 needs every member's h_t; the parity-1 records are
 //     zeroed by the host, so step 0 reads h_{-1} = 0 like any other step;
-//   * every wait is bounded: a tag that does not arrive within ~2 s records a code in the call's status word
-//     (fnssl_lstm_cluster_status) and traps — the launch fails loudly instead of hanging the device.  All members of a
-//     cluster are resident at once by construction: a launch has at most one workgroup per CU (its LDS) and at most
-//     CUs / members clusters.
+//   * every wait is bounded and cooperative: a tag that does not arrive within the spin limit (~1.5 s) records a code in
+//     the call's status word (fnssl_lstm_cluster_status); the wave stops waiting, every other wave sees the word at its next
+//     poll, all workgroups drain — no trap — and the pair-split kernels the same call has enqueued behind this one (guarded
+//     by that word) recompute the layer.  The launcher checks co-residency of the grid with the occupancy query first
+//     (kNoCluster: the caller takes the pair-split kernels unguarded).
 //
 // Arithmetic: per 32-row tile the MFMA chain is the one of lstm_bf16p_kernel — ones block (bias), input blocks, recurrent
 // blocks, in that order, into one fp32 accumulator — and the gate math is the same code, so the results are

@@ -7,8 +7,8 @@
 // backward pass.  Per step and group the backward is  [dx_t | dh_{t-1}]^T = [W_ih | W_hh]^T da_t^T  — a product whose OUTPUT
 // range (c0g + H = 384 channels = 6 "output slices" of 4 x 16 channels in the packed stream's fake-LSTM arrangement,
 // lstm_train.h) splits over a cluster of 6 CUs: member m keeps output slice m of the transposed weight stream (32 quads =
-// 128 KiB) in LDS for the whole launch, and the cluster's groups are work items its 16 waves take in turn; the groups beyond
-// one per wave change hands every step (a group's state — carried dh, dc — lives in memory), so every SIMD carries the same
+// 128 KiB) in LDS for the whole launch, and the cluster's groups are work items its 12 waves take in turn; the groups beyond
+// a multiple of the wave count change hands every step (a group's state — carried dh, dc — lives in memory), so every SIMD carries the same
 // load over the launch.  A group-step of a member:
 //   phase A (VALU)  the gate gradients of the hidden slices whose dh_{t-1} THIS member produces in phase B (so the carried
 //                   state never crosses CUs): slice 2 + m for every member, plus slice 0 / 1 for members 4 / 5 — written to
@@ -28,7 +28,7 @@
 
 namespace fnssl_lstm {
 
-constexpr int kBwdcWaves = 16;
+constexpr int kBwdcWaves = 12;   // waves per member; with the 8-deep dA ring (144 registers) 3 % faster than 16 waves and a 4-deep ring
 
 struct BwdClusterParams {
   unsigned* tags;       // [cluster][group in cluster][16]: words 0..7 = per-member "dA of step s written" (s + 1), 8..15 = "phase B of
@@ -47,12 +47,12 @@ struct BwdClusterParams {
 // ABLRT (make ABLATE=1 only): run-time ablation bits cp.ablate — 1 no tag waits, 2 no phase-A loads, 4 no phase-A stores,
 // 8 no dA loads in phase B, 16 no output stores, 32 no drain in front of the "phase B done" tag, 64 no phase A at all,
 // 128 L1-bypassing dA loads, 256 plain dA stores
-template <int NW_ = kBwdcWaves, bool ABLRT = false>
+template <int NW_ = kBwdcWaves, bool ABLRT = false, int XD_ = 8>
 __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, const BwdClusterParams cp) {
   constexpr int H = 128, NS = H / 16, NW = NW_;
   const int ABL = ABLRT ? cp.ablate : 0;
   constexpr int NVB = 4 * H / 16;                             // 16-channel blocks of a dA row = data quads per output slice
-  constexpr int XD = 4;
+  constexpr int XD = XD_;                                    // depth of the dA operand ring (16-channel blocks in flight)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int b = blockIdx.x;
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
       dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(mine && tv < (unsigned)step + 1) == 0; },
                            [&]() { tv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x50000u);
     }
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(2);   // matrix phase above the gate arithmetic of the SIMD's other waves (none / reversed: +4 %)
     v4f xr[XD];
     // plain loads: a dA row is read by this CU once, after all of it has been announced — no line of it can sit in this CU's
     // L1 from before (stores do not allocate), and the second 64-byte block of a line then comes from L1 (22.4 -> 21.3 ms)
@@ -285,7 +285,8 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
     if (task < g0 + FULL && task + NW < g0 + FULL) {
       task += NW;
     } else {
-      const int j = (w - step) & (NW - 1);
+      int j = (w - step) % NW;
+      if (j < 0) j += NW;
       if (task < g0 + FULL && j < LEFT) {
         task = g0 + FULL + j;
       } else {
@@ -299,10 +300,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NW_ = kBwdcWaves, bool ABLRT = false>
+template <int NW_ = kBwdcWaves, bool ABLRT = false, int XD_ = 8>
 int launch_bwdc_k(const BwdParams& p, const BwdClusterParams& cp, hipStream_t st) {
   const size_t lds = (size_t)(4 * 128 / 16) * 4096;             // 32 quads = 128 KiB
-  auto k = lstm_bwdc_kernel<NW_, ABLRT>;
+  auto k = lstm_bwdc_kernel<NW_, ABLRT, XD_>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = fnssl::device_cus();
   if (!cluster_grid_fits(reinterpret_cast<const void*>(k), NW_ * 64, lds, nwg)) return kNoCluster;

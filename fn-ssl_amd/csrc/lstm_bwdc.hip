@@ -26,7 +26,7 @@ bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
   cp.clusters_per_dir = clusters / p.ndir;
   cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
   const int min_groups = env_int("FNSSL_BWD_CLUSTER_MIN_GROUPS", 1, 1 << 20);
-  return cp.groups_per_cluster >= (min_groups ? min_groups : kBwdcWaves / 2);
+  return cp.groups_per_cluster >= (min_groups ? min_groups : 8);
 }
 
 // ws = the region bwdc_bytes() sizes.  FNSSL_OK, kNoCluster, or an error.
@@ -42,6 +42,7 @@ int backward_cluster(const BwdParams& p, BwdClusterParams cp, void* ws, hipStrea
 #ifdef FNSSL_BUILD_ABLATE
   if ((cp.ablate = env_int("FNSSL_BWDC_ABLATE", 1, 1 << 20)) != 0) return launch_bwdc_k<kBwdcWaves, true>(p, cp, st);
 #endif
+  if (env_int("FNSSL_BWDC_WAVES16", 1, 1)) return launch_bwdc_k<16, false, 4>(p, cp, st);   // the first shape: 16 waves, 4-deep ring
   return launch_bwdc_k<kBwdcWaves>(p, cp, st);
 }
 

@@ -308,8 +308,8 @@ def test_cluster_training_forward_equals_split_kernels(dev, monkeypatch, c0, nb,
 @pytest.mark.parametrize("c0g,nb,nt,nf", [(256, 32, 300, 7), (256, 33, 301, 5), (0, 32, 300, 7)])
 def test_cluster_bptt_equals_split_kernels(dev, monkeypatch, c0g, nb, nt, nf):
     """Round 4: back-propagation through time of the H = 128 full-band layers at config 4's shard on the cluster-resident
-    kernel (lstm_bwdc.h: the 6 output slices of [W_ih | W_hh]^T over clusters of 6 CUs, 30 groups per cluster, the ones
-    beyond one per wave rotating) — dA AND dx bit for bit equal to the 2-waves-per-group split kernels
+    kernel (lstm_bwdc.h: the 6 output slices of [W_ih | W_hh]^T over clusters of 6 CUs, 30 groups per cluster on 12 waves,
+    the 6 beyond two per wave rotating) — dA AND dx bit for bit equal to the 2-waves-per-group split kernels
     (FNSSL_BWD_NO_CLUSTER=1), twice, status word 0; the second case has a ragged last group and groups that cross
     utterances; the third is block 1's layer (no input gradient: 2 output slices, clusters of 2 CUs, 4 hidden slices of
     gate gradients per member)."""

@@ -59,6 +59,9 @@ for c0g in (256, 0):
     os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"] = "1"
     line("cluster kernel, no rotation")
     del os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"]
+    os.environ["FNSSL_BWDC_WAVES16"] = "1"
+    line("cluster kernel, 16 waves, 4-deep ring")
+    del os.environ["FNSSL_BWDC_WAVES16"]
     if ABL_LIB:
         for m in (128, 256, 384, 2, 4, 8, 1 | 8 | 16 | 32 | 64):
             os.environ["FNSSL_BWDC_ABLATE"] = str(m)

@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(NG * 128) lstm_bf16p_kernel(const LstmParams p
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NG = 2>
+// ALLDRAIN: the drained barriers for every shape (FNSSL_BF16P_DRAIN=1; a diagnosis knob: if the stale-record effect below ever
+// shows up on a shape that owns its CU, this tells ring accounting from residency)
+template <int H, int NB0, int NB2, int FLAGS, int ABL = 0, int NG = 2, bool ALLDRAIN = false>
 int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
   if (p.dry) return FNSSL_OK;   // fnssl_lstm_plan: report the family, launch nothing
   constexpr int KT = 1 + NB0 + NB2 + H / 16;
@@ -324,7 +326,7 @@ int launch_bf16p_k(const LstmParams& p, int nwg, hipStream_t st) {
   // — bit-stable with one workgroup per CU (same kernel, LDS padded) and with drained barriers; the cause could not
   // be pinned from here, so the shape runs the canonical "vmcnt(0) + barrier" protocol: 3.99 -> 4.37 ms per launch
   // (three resident workgroups hide each other's waits).  The other shapes own their CU (114-158 KB of LDS).
-  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12), NG>;
+  auto k = lstm_bf16p_kernel<H, NB0, NB2, FLAGS, ABL, NSLOT, (KT <= 12) || ALLDRAIN, NG>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(nwg), dim3(NG * 128), lds, st, p);

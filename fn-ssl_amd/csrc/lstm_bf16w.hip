@@ -31,7 +31,8 @@ int launch_bf16w(const LstmParams& p, int H, int NW, int flags, int nwg, hipStre
 // NG_ = the largest groups-per-workgroup instantiation built for the shape (lstm_bf16p_kernel's NG; 2 = the pair of
 // groups every shape runs with — larger workgroups were measured and do not pay, see forward_bf16w)
 #define TRYP(H_, NB0_, NB2_, FL_)                                                    \
-  if (H == H_ && p.c0 == 16 * NB0_ && p.c2 == 16 * NB2_ && flags == (FL_)) return launch_bf16p_k<H_, NB0_, NB2_, FL_>(p, nwg, st);
+  if (H == H_ && p.c0 == 16 * NB0_ && p.c2 == 16 * NB2_ && flags == (FL_))          \
+    return drain ? launch_bf16p_k<H_, NB0_, NB2_, FL_, 0, 2, true>(p, nwg, st) : launch_bf16p_k<H_, NB0_, NB2_, FL_>(p, nwg, st);
 
 // pair-split kernels (lstm_bf16p.h): workgroup = ng groups of 32 sequences x 2 roles (ng = 2, or 5 for the H = 128 shapes)
 int launch_bf16p(const LstmParams& p, int H, int flags, int nwg, hipStream_t st) {
@@ -47,6 +48,7 @@ int launch_bf16p(const LstmParams& p, int H, int flags, int nwg, hipStream_t st)
     }
   }
 #endif
+  const bool drain = env_int("FNSSL_BF16P_DRAIN", 1, 1) != 0;   // vmcnt(0) at every ring barrier, all shapes
   TRYP(128, 1, 0, kW_F0)
   TRYP(256, 16, 1, kW_F2)
   TRYP(128, 16, 1, kW_F2)

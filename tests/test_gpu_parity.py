@@ -1106,6 +1106,49 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
     assert torch.equal(a, a2), "cluster kernel is not repeatable"
 
 
+@pytest.mark.parametrize("mode,H,bidir,c0,c2,nb,nt,nf", [
+    ("narrow", 256, False, 256, 16, 64, 60, 256),  # config 3's narrow-band batch: 16384 sequences x 60 steps
+    ("full", 128, True, 256, 16, 64, 300, 48),     # config 3's full-band batch (blocks 2, 3): 19200 sequences x 2 directions x 48 steps
+    ("full", 128, True, 16, 0, 64, 300, 48),       # block 1 (the 144-column stream: several workgroups per CU, drained barriers)
+])
+def test_pair_split_kernels_are_bit_stable_over_many_launches(dev, monkeypatch, mode, H, bidir, c0, c2, nb, nt, nf):
+    """Round-3 finding (lstm_bf16p.h, launch_bf16p_k): with counted waits at the ring barriers one shape read a stale weight
+    record a few times per launch whenever several workgroups shared a CU; it runs drained barriers since.  The soak the
+    advisor asked for, on EVERY pair-split shape at config 3's batch: 100 launches (5 - 6 k steps) bit-identical to the first, and identical
+    to the same kernels with drained barriers everywhere (FNSSL_BF16P_DRAIN=1) — a ring-accounting race would show as a
+    difference between the two or between launches."""
+    from fnssl import ops
+    sd = lstm_state(c0 + c2, H, bidir, 6100 + H + c0)
+    sfx = [""] + (["_reverse"] if bidir else [])
+    w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, c2, dev)
+         for s_ in sfx]
+    g = torch.Generator(device=dev)
+    g.manual_seed(6101)
+    x0 = torch.randn((nb, nt, nf, c0), generator=g, device=dev) * 0.7
+    x2 = torch.randn((nb, nt, nf, c2), generator=g, device=dev) * 0.7 if c2 else None
+    x0 = x0.bfloat16() if c2 else x0                     # (block 1: the fp32 feature block is the only input)
+    ndir = len(sfx)
+    monkeypatch.setenv("FNSSL_NO_CLUSTER", "1")          # the pair-split kernels themselves, not as a fallback
+    monkeypatch.setenv("FNSSL_NO_CLUSTER_H128", "1")
+    monkeypatch.delenv("FNSSL_BF16P_DRAIN", raising=False)
+
+    def run():
+        out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops.lstm_layer(mode, x0, None, x2, w, H, out, bf16=True, wide=True)
+        return out
+
+    fam = ops.lstm_plan(mode, x0, None, x2, w, H, torch.empty((nb, nt, nf, ndir * H), device=dev, dtype=torch.bfloat16), bf16=True, wide=True)[0]
+    assert fam == "bf16_pair", fam
+    first = run()
+    assert not torch.isnan(first.float()).any()
+    bad = 0
+    for _ in range(100):
+        bad += int(not torch.equal(run(), first))
+    assert bad == 0, "%d of 100 launches differ from the first" % bad
+    monkeypatch.setenv("FNSSL_BF16P_DRAIN", "1")
+    assert torch.equal(run(), first), "drained barriers give different bits"
+
+
 @pytest.mark.parametrize("nb,nt,nf,summed,c0", [
     (96, 256, 5, True, 256),     # 24576 sequences x 2 directions = 3072 groups: exactly one 12-wave round, 96 groups per cluster
     (97, 300, 4, True, 256),     # 29100 sequences: ragged last group (12 live sequences), groups that cross an utterance boundary

@@ -41,6 +41,8 @@ struct BwdClusterParams {
   unsigned spin_limit;
   int stall_member;     // test knob: this member of cluster 0 exits at once (-1: none)
   int rotate;
+  int simd_token;       // one wave per SIMD in the matrix phase at a time (FNSSL_BWDC_NO_TOKEN=1: off)
+  int no_prefetch;      // A/B knob (FNSSL_BWDC_NO_PREFETCH): phase-A operands requested when needed
   int ablate;           // ablate build only (FNSSL_BWDC_ABLATE): timing experiments, wrong results by construction
 };
 
@@ -82,6 +84,9 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
     v4f* dst = reinterpret_cast<v4f*>(smem);
     for (int i = threadIdx.x; i < NVB * 4 * 64; i += NW * 64) dst[i] = src[i];
   }
+  // one "matrix phase" token per SIMD (wave w runs on SIMD w & 3), behind the weight slice
+  unsigned* const token = reinterpret_cast<unsigned*>(smem + NVB * 4096) + (w & 3);
+  if (threadIdx.x < 4) reinterpret_cast<unsigned*>(smem + NVB * 4096)[threadIdx.x] = 0;
   __syncthreads();
   const char* const lds_rd = smem + lane * 16;
   auto rec = [&](int q, int j) { return *reinterpret_cast<const v4f*>(lds_rd + (q * 4 + j) * 1024); };
@@ -97,6 +102,15 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
     nown += own[qq] >= 0;
   }
   (void)nown;
+  // the (up to) two slices whose read-only operands are requested one group-step ahead
+  int q0 = -1, q1 = -1;
+#pragma unroll
+  for (int qq = 3; qq >= 0; --qq) {
+    if (own[qq] >= 0) {
+      q1 = q0;
+      q0 = qq;
+    }
+  }
 
   const unsigned sdh = (unsigned)(p.dh.st * 4), sda = (unsigned)(p.da_st * 4), sdx = (unsigned)(p.dx_st * 4);
   unsigned* const tag_cl = cp.tags + (size_t)cl * cp.groups_per_cluster * 16;
@@ -160,16 +174,68 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
     }
   };
 
+  // read-only operands of one (group, step, hidden slice) of phase A: forward reserve + upstream gradient
+  struct Ops {
+    v4f ig, fg, gg, og, ct, cp, dhu;
+  };
+  auto issue = [&](int task_, int step_, rsrc_t rdh_, unsigned vdh_, int s_) {
+    const unsigned tt_ = rev ? step_ : p.nsteps - 1 - step_;
+    const bool has_prev_ = step_ + 1 < p.nsteps;
+    const unsigned tp_ = has_prev_ ? (rev ? tt_ + 1 : tt_ - 1) : tt_;
+    const rsrc_t rres_ = make_rsrc(reinterpret_cast<const char*>(p.reserve) +
+                                   ((size_t)dir * p.ntasks + task_) * p.nsteps * (size_t)(NS * kReserveRecs * 1024));
+    const unsigned rb = (tt_ * NS + s_) * (kReserveRecs * 1024);
+    Ops o;
+    o.ig = bld4(rres_, vlane, rb);
+    o.fg = bld4(rres_, vlane, rb + 1024);
+    o.gg = bld4(rres_, vlane, rb + 2048);
+    o.og = bld4(rres_, vlane, rb + 3072);
+    o.ct = bld4(rres_, vlane, rb + 4096);
+    o.dhu = bld4(rdh_, vdh_, tt_ * sdh + 64 * s_);
+    o.cp = zero4;
+    if (has_prev_) o.cp = bld4(rres_, vlane, (tp_ * NS + s_) * (kReserveRecs * 1024) + 4096);
+    return o;
+  };
+  // requested a group-step ahead (behind the tag store of the current one, in front of its tag wait): they travel while the
+  // wave waits for the other members and runs its matrix phase — the two HBM round trips of a two-slice member were the
+  // longest item of the cluster's lock step (profiles/r04/i_bwdc_phase_times*)
+  Ops pre0, pre1;
+  bool have_pre = false;
+  auto advance = [&](int task_, int step_, int& task_n, int& step_n) {
+    task_n = task_;
+    step_n = step_;
+    if (task_ < g0 + FULL && task_ + NW < g0 + FULL) {
+      task_n = task_ + NW;
+    } else {
+      int j = (w - step_) % NW;
+      if (j < 0) j += NW;
+      if (task_ < g0 + FULL && j < LEFT) {
+        task_n = g0 + FULL + j;
+      } else {
+        task_n = g0 + w;
+        step_n = step_ + 1;
+      }
+    }
+  };
+
+  // ablate build, bit 512: where a wave's time goes (shader-clock cycles per phase, summed over its group-steps)
+  const bool TIMED = ABLRT && (ABL & 512);
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = 0, t_begin = 0;
+  unsigned nitems = 0;
+  auto lap = [&](int k) {
+    if (TIMED) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[k] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (TIMED) t_begin = tlast = __builtin_amdgcn_s_memtime();
   for (;;) {
     Grp gr;
     rsrc_t rdh, rda, rdx;
     locate(task, gr, rdh, rda, rdx);
     const unsigned tt = rev ? step : p.nsteps - 1 - step;      // the forward direction's gradient flows T-1 .. 0
-    const bool has_prev = step + 1 < p.nsteps;                 // the forward pass had a step before tt
-    const unsigned tp = has_prev ? (rev ? tt + 1 : tt - 1) : tt;
     const unsigned oa = tt * sda;
-    const rsrc_t rres = make_rsrc(reinterpret_cast<const char*>(p.reserve) +
-                                  ((size_t)dir * p.ntasks + task) * p.nsteps * (size_t)(NS * kReserveRecs * 1024));
     const rsrc_t rsc = make_rsrc(reinterpret_cast<const char*>(p.scratch) +
                                  ((size_t)dir * (p.ntasks + 16) + task) * (2 * NS * 1024));
     unsigned* const tag_g = tag_cl + (size_t)(task - g0) * 16;
@@ -181,24 +247,33 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
       dead = !bounded_wait([&]() { return tv >= (unsigned)step; },
                            [&]() { tv = __hip_atomic_load(tag_g + 8 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x60000u);
     }
+    lap(0);   // drain of the previous item's output stores + hand-over wait
 
     // ---- phase A: gate gradients of my hidden slices (the expressions of lstm_bwd_kernel, in its order) -------------
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int s = own[qq];
       if (s < 0 || (ABL & 64)) continue;
-      const unsigned rb = (tt * NS + s) * (kReserveRecs * 1024);
       v4f ig = one4 * 0.5f, fg = ig, gg = ig, og = ig, ct = ig, dhu = ig;
       v4f cprev = zero4, dhc = zero4, dcc = zero4;
       if (!(ABL & 2)) {
-        ig = bld4(rres, vlane, rb), fg = bld4(rres, vlane, rb + 1024), gg = bld4(rres, vlane, rb + 2048);
-        og = bld4(rres, vlane, rb + 3072), ct = bld4(rres, vlane, rb + 4096);
-        dhu = bld4(rdh, gr.vdh, tt * sdh + 64 * s);
-        if (has_prev) cprev = bld4(rres, vlane, (tp * NS + s) * (kReserveRecs * 1024) + 4096);
-        if (step > 0) {
+        Ops o;
+        if (have_pre && qq == q0) {
+          o = pre0;
+        } else if (have_pre && qq == q1) {
+          o = pre1;
+        } else {
+          o = issue(task, step, rdh, gr.vdh, s);
+        }
+        ig = o.ig, fg = o.fg, gg = o.gg, og = o.og, ct = o.ct, dhu = o.dhu, cprev = o.cp;
+        if (step > 0) {   // the carried state: written by the previous step's matrix phase, never requested ahead
           dhc = bld4_l2(rsc, vlane, s * 1024);
           dcc = bld4_l2(rsc, vlane, (NS + s) * 1024);
         }
+      }
+      if (TIMED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(1);   // phase-A operands arriving
       }
       v4f dh = dhu + dhc, dc = dcc;
       const v4f tc = tanh4(ct);
@@ -222,9 +297,23 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
         }
       }
     }
+    lap(2);   // gate arithmetic + issuing the stores
     // publish my dA rows of (group, step): payload stores -> vmcnt(0) -> tag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lap(3);   // store drain
     if (lane == 0) __hip_atomic_store(tag_g + m, (unsigned)step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int task_n, step_n;
+    advance(task, step, task_n, step_n);
+    have_pre = step_n < p.nsteps && !(ABL & 2) && !cp.no_prefetch;
+    auto prefetch_next = [&]() {   // called once the last dA block of this group-step has been requested (in-order returns:
+      if (have_pre) {              //  requested earlier, these HBM reads would hold up the ring's L2 hits behind them)
+        Grp gn;
+        rsrc_t rdhn, rdan, rdxn;
+        locate(task_n, gn, rdhn, rdan, rdxn);
+        pre0 = issue(task_n, step_n, rdhn, gn.vdh, own[q0 & 3]);
+        if (q1 >= 0) pre1 = issue(task_n, step_n, rdhn, gn.vdh, own[q1 & 3]);
+      }
+    };
 
     // ---- phase B: my output slice of [dx | dh_prev]^T = [W_ih | W_hh]^T da^T -------------------------------------
     if (!dead && !(ABL & 1)) {
@@ -233,13 +322,27 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
       dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(mine && tv < (unsigned)step + 1) == 0; },
                            [&]() { tv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x50000u);
     }
-    __builtin_amdgcn_s_setprio(2);   // matrix phase above the gate arithmetic of the SIMD's other waves (none / reversed: +4 %)
+    lap(4);   // waiting for the other members' tags
+    __builtin_amdgcn_s_setprio(2);   // matrix phase above the gate arithmetic of the SIMD's other waves (none / reversed: +4 %; by wave rank: no effect)
     v4f xr[XD];
     // plain loads: a dA row is read by this CU once, after all of it has been announced — no line of it can sit in this CU's
     // L1 from before (stores do not allocate), and the second 64-byte block of a line then comes from L1 (22.4 -> 21.3 ms)
     static_for<XD>([&](auto v) {
       xr[v.value] = (ABL & 8) ? one4 : (ABL & 128) ? bld4_l2(rda, gr.vda, oa + 64 * v.value) : bld4(rda, gr.vda, oa + 64 * v.value);
     });
+    // One wave of a SIMD at a time in the matrix phase.  The matrix pipe is shared round-robin whatever the wave
+    // priorities, so the three (four) waves of a SIMD that became ready together ran their matrix phases together — each
+    // three times as long — and then stood in their memory round trips together, the pipe idle (profiles/r04/
+    // i_bwdc_phase_times*: matrix phase 45 k cycles for 16.4 k of MFMAs, 30 k cycles of waits per group-step on top).
+    // With the token a wave's matrix phase runs alone at the pipe's rate and the others' waits hide behind it.
+    if (cp.simd_token) {   // (two waves per SIMD at a time, as a counting semaphore: 19.0 against 18.1 ms)
+      for (unsigned spins = 0; spins < cp.spin_limit; ++spins) {
+        const unsigned old = __hip_atomic_exchange(token, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // all lanes: one word
+        if (__builtin_amdgcn_ballot_w64(old == 0u) != 0) break;   // some lane saw it free: the wave owns it now
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    lap(6);   // waiting for the SIMD's token
     v4f acc[4] = {zero4, zero4, zero4, zero4};
     v4f ra[4];
     static_for<4>([&](auto j) { ra[j.value] = rec(0, j.value); });
@@ -264,8 +367,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (V + XD < NVB)
         if (!(ABL & 8)) xr[V % XD] = (ABL & 128) ? bld4_l2(rda, gr.vda, oa + 64 * (V + XD)) : bld4(rda, gr.vda, oa + 64 * (V + XD));
+      if constexpr (V + XD == NVB - 1) prefetch_next();   // (behind the matrix phase instead: 19.5 against 18.1 ms)
     });
     __builtin_amdgcn_s_setprio(0);
+    if (cp.simd_token) __hip_atomic_store(token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int ob = qq * hq + 16 * m;                          // first channel of this 16-channel block
@@ -277,32 +382,31 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
         bst4(acc[qq], rsc, vlane, ((ob - p.c0g) >> 4) * 1024);
       }
     }
+    lap(5);   // matrix phase (dA loads, MFMAs), output stores issued
+    ++nitems;
     pub_val = (unsigned)step + 1;
     pub_tag = tag_g + 8 + m;
     if (dead) break;
 
     // ---- next work item
-    if (task < g0 + FULL && task + NW < g0 + FULL) {
-      task += NW;
-    } else {
-      int j = (w - step) % NW;
-      if (j < 0) j += NW;
-      if (task < g0 + FULL && j < LEFT) {
-        task = g0 + FULL + j;
-      } else {
-        task = g0 + w;
-        ++step;
-      }
-    }
+    task = task_n;
+    step = step_n;
     if (step >= p.nsteps) break;
   }
   pub_flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (TIMED && cl == 0 && (w == 0 || w == 5) && lane == 0) {
+    const unsigned long long total = __builtin_amdgcn_s_memtime() - t_begin;
+    printf("bwdc member %d wave %d: %u group-steps, cycles per group-step: total %llu = prev-store drain + hand-over %llu, operand wait %llu, "
+           "gates + store issue %llu, store drain %llu, tag wait %llu, token wait %llu, matrix phase %llu\n",
+           m, w, nitems, total / nitems, tacc[0] / nitems, tacc[1] / nitems, tacc[2] / nitems, tacc[3] / nitems, tacc[4] / nitems,
+           tacc[6] / nitems, tacc[5] / nitems);
+  }
 }
 
 template <int NW_ = kBwdcWaves, bool ABLRT = false, int XD_ = 8>
 int launch_bwdc_k(const BwdParams& p, const BwdClusterParams& cp, hipStream_t st) {
-  const size_t lds = (size_t)(4 * 128 / 16) * 4096;             // 32 quads = 128 KiB
+  const size_t lds = (size_t)(4 * 128 / 16) * 4096 + 64;        // 32 quads = 128 KiB, + the SIMD tokens
   auto k = lstm_bwdc_kernel<NW_, ABLRT, XD_>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int nwg = fnssl::device_cus();

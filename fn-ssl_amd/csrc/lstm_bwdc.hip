@@ -36,6 +36,8 @@ int backward_cluster(const BwdParams& p, BwdClusterParams cp, void* ws, hipStrea
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
   cp.rotate = !env_int("FNSSL_BWD_CLUSTER_NO_ROTATE", 1, 1);
+  cp.no_prefetch = env_int("FNSSL_BWDC_NO_PREFETCH", 1, 1);
+  cp.simd_token = !env_int("FNSSL_BWDC_NO_TOKEN", 1, 1);
   if (p.dry) return FNSSL_OK;
   const size_t tag_bytes = (size_t)cp.clusters_per_dir * p.ndir * cp.groups_per_cluster * 16 * sizeof(unsigned);
   FNSSL_HIP(hipMemsetAsync(ws, 0, 256 + tag_bytes, st));

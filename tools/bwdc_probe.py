@@ -59,6 +59,12 @@ for c0g in (256, 0):
     os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"] = "1"
     line("cluster kernel, no rotation")
     del os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"]
+    os.environ["FNSSL_BWDC_NO_PREFETCH"] = "1"
+    line("cluster kernel, operands requested when needed")
+    del os.environ["FNSSL_BWDC_NO_PREFETCH"]
+    os.environ["FNSSL_BWDC_NO_TOKEN"] = "1"
+    line("cluster kernel, no SIMD token")
+    del os.environ["FNSSL_BWDC_NO_TOKEN"]
     os.environ["FNSSL_BWDC_WAVES16"] = "1"
     line("cluster kernel, 16 waves, 4-deep ring")
     del os.environ["FNSSL_BWDC_WAVES16"]

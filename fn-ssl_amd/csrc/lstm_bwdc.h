@@ -8,14 +8,18 @@
 // range (c0g + H = 384 channels = 6 "output slices" of 4 x 16 channels in the packed stream's fake-LSTM arrangement,
 // lstm_train.h) splits over a cluster of 6 CUs: member m keeps output slice m of the transposed weight stream (32 quads =
 // 128 KiB) in LDS for the whole launch, and the cluster's groups are work items its 12 waves take in turn; the groups beyond
-// a multiple of the wave count change hands every step (a group's state — carried dh, dc — lives in memory), so every SIMD carries the same
-// load over the launch.  A group-step of a member:
+// a multiple of the wave count change hands every step (a group's state — carried dh, dc — lives in memory), so every SIMD
+// carries the same load over the launch.  A group-step of a member:
 //   phase A (VALU)  the gate gradients of the hidden slices whose dh_{t-1} THIS member produces in phase B (so the carried
 //                   state never crosses CUs): slice 2 + m for every member, plus slice 0 / 1 for members 4 / 5 — written to
-//                   the dA tensor (write-through), then the member's tag of (group) is set to step + 1;
-//   phase B (MFMA)  once all six tags show the step: the whole dA row of the group (32 blocks, 4-deep operand ring, sc1
-//                   loads) against the member's weight slice; dx_t blocks go to the input-gradient tensor, dh_{t-1} blocks
-//                   to the group's carried-state record.
+//                   the dA tensor (sc1 write-through stores), then the member's tag of (group) is set to step + 1.  The
+//                   read-only operands (forward reserve, upstream gradient) were requested one group-step ahead;
+//   phase B (MFMA)  once all six tags show the step: the whole dA row of the group (32 blocks through an 8-deep operand
+//                   ring; plain loads — the row is read once per CU, after it is complete) against the member's weight
+//                   slice; dx_t blocks go to the input-gradient tensor, dh_{t-1} blocks to the group's carried-state
+//                   record.  One wave per SIMD at a time (an LDS token): the matrix pipe is shared round-robin whatever the
+//                   priorities, and waves that became ready together otherwise run their matrix phases together and then
+//                   wait on memory together.
 // Same stream, same k order per output block, same phase-A expressions as lstm_bwd_kernel: bit-identical dA and dx.
 // Waits are bounded and cooperative (status word, no trap), the call enqueues lstm_bwd_kernel behind this kernel as its
 // guarded fallback — exactly as fnssl_lstm_forward does for lstm_f32c.h (include/fnssl.h).
@@ -48,7 +52,7 @@ struct BwdClusterParams {
 
 // ABLRT (make ABLATE=1 only): run-time ablation bits cp.ablate — 1 no tag waits, 2 no phase-A loads, 4 no phase-A stores,
 // 8 no dA loads in phase B, 16 no output stores, 32 no drain in front of the "phase B done" tag, 64 no phase A at all,
-// 128 L1-bypassing dA loads, 256 plain dA stores
+// 128 L1-bypassing dA loads, 256 plain dA stores, 512 per-phase cycle counters (printed for cluster 0, waves 0 and 5)
 template <int NW_ = kBwdcWaves, bool ABLRT = false, int XD_ = 8>
 __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, const BwdClusterParams cp) {
   constexpr int H = 128, NS = H / 16, NW = NW_;

@@ -7,6 +7,7 @@
 #include "lstm_train.h"
 #include "lstm_split_static.h"
 #include "lstm_bwdc.h"
+#include "lstm_bwd2.h"
 
 using namespace fnssl_lstm;
 
@@ -239,6 +240,12 @@ static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dr
     p.task1 = gm.t1;
     const int groups_per_wg = gm.nw / gm.split;
     p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
+    // H = 256 with four waves per group (config 4's narrow-band layers: two groups per CU): both groups of a CU against one
+    // stream of weight records (lstm_bwd2.h)
+    if (H == 256 && gm.split == 4 && gm.nw == 8 && nso % 4 == 0 && !env_int("FNSSL_NO_BWD2", 1, 1)) {
+      p.wgs_per_dir = (gm.t1 - gm.t0 + 1) / 2;
+      return launch_bwd2_k<256>(p, p.wgs_per_dir * p.ndir, st);
+    }
     const Variant vr{gm.nw, gm.split > 1 ? 8 : 4, 1};
     const int nwg = p.wgs_per_dir * p.ndir;
     choose_chunk(p.quads_per_slice, vr, p.chq, p.pad, gm.split, gm.split > 1 ? lds_chunk_cap(nwg, gm.split) : 0);

@@ -351,6 +351,43 @@ def test_cluster_bptt_equals_split_kernels(dev, monkeypatch, c0g, nb, nt, nf):
     assert torch.equal(xa, xb) and torch.equal(xa, xa2), "dx"
 
 
+@pytest.mark.parametrize("nb,nt,nf", [(32, 7, 256), (33, 5, 250), (31, 6, 256)])
+def test_two_groups_per_wave_bptt_equals_one_group_per_wave_set(dev, monkeypatch, nb, nt, nf):
+    """Round 4: the narrow-band layers' BPTT (H = 256, one direction, ~512 groups at config 4's shard) with both groups of a CU
+    against ONE stream of weight records (lstm_bwd2.h) — dA and dx bit for bit equal to the 4-waves-per-group kernels that
+    stream the matrix once per group (FNSSL_NO_BWD2=1), twice; ragged last group, groups that cross utterances, and an odd
+    number of groups (the last workgroup has one)."""
+    from fnssl import ops
+    from fnssl import weights as W
+    H, c0g, c2 = 256, 256, 4
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0g + c2, H, False)], seed=880 + nb)
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0g, c2, dev)]
+    bw = [torch.from_numpy(ops.pack_lstm_bwd_host(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], c0g)).to(dev)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    x0 = torch.randn((nb, nt, nf, c0g), generator=g, device=dev) * 0.7
+    x2 = torch.randn((nb, nt, nf, c2), generator=g, device=dev) * 0.7
+    dh = torch.randn((nb, nt, nf, H), generator=g, device=dev) * 0.3
+    out = torch.empty((nb, nt, nf, H), device=dev)
+    reserve = torch.zeros((ops.lstm_reserve_floats(nb * nf, H, 1, nt),), device=dev)
+    ops.lstm_layer("narrow", x0, None, x2, packed, H, out, reserve=reserve)
+
+    def run():
+        da = torch.full((nb, nt, nf, 4 * H), float("nan"), device=dev)
+        dx = torch.full((nb, nt, nf, c0g), float("nan"), device=dev)
+        ops.lstm_backward("narrow", reserve, dh, da, dx, bw, H, c0g)
+        return da, dx
+
+    monkeypatch.delenv("FNSSL_NO_BWD2", raising=False)
+    a, xa = run()
+    a2, xa2 = run()
+    monkeypatch.setenv("FNSSL_NO_BWD2", "1")
+    b, xb = run()
+    assert not torch.isnan(a).any() and not torch.isnan(xa).any()
+    assert torch.equal(a, b) and torch.equal(a, a2), "dA"
+    assert torch.equal(xa, xb) and torch.equal(xa, xa2), "dx"
+
+
 def test_cluster_bptt_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch):
     """A member of cluster 0 that never shows up (FNSSL_CLUSTER_TEST_STALL): the waiting waves give up after the bounded
     number of spins, record a status word, every workgroup drains — no trap, the device stays usable — and the guarded

@@ -7,7 +7,7 @@
 // roof whatever the phases of the co-resident groups do (profiles/r04).  Here the four waves of a workgroup own the
 // same quarters but every weight record they load multiplies the dA rows of BOTH of the CU's groups: half the L2 traffic per
 // flop.  A SIMD then holds ONE wave, so nothing hides a memory round trip for it — which is why
-//   * the weight quads run through an 8-deep register pipeline (128 registers; a wave has 512 to itself) and are the ONLY
+//   * the weight quads run through a 4-deep register pipeline (8-deep measured the same) and are the ONLY
 //     vector-memory requests of the matrix loop: the dA rows both groups need as B operands go through LDS (128 KiB, written
 //     by phase A next to the global copy the weight-gradient kernel reads), and
 //   * the read-only operands of phase A (forward reserve, upstream gradient) of the NEXT step are requested at the start of
@@ -24,7 +24,10 @@ namespace fnssl_lstm {
 
 template <int H>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) lstm_bwd2_kernel(const BwdParams p) {
-  constexpr int NS = H / 16, SPLIT = 4, NSL = NS / SPLIT, NVB = 4 * H / 16, G = 2, WD = 8;
+  constexpr int NS = H / 16, SPLIT = 4, NSL = NS / SPLIT, NVB = 4 * H / 16, G = 2, WD = 4;
+  constexpr int NPRE = NSL;             // (group, slice) operand sets requested a step ahead: group 0's; group 1's at the top of phase A, behind
+                                        // group 0's arithmetic (all of them ahead, or half of group 1's too: 2 - 4 % slower)
+  constexpr int NLATE = G * NSL - NPRE > 0 ? G * NSL - NPRE : 1;
   // LDS: the dA rows of both groups, [group][block][lane] float4 (128 KiB), then the carried dh of both groups,
   // [group][hidden slice][lane] (32 KiB) — 160 KiB, the whole CU's
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,15 +103,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (has_prev) o.cp = bld4(rres[k], vlane, (tp * NS + s) * (kReserveRecs * 1024) + 4096);
     return o;
   };
-  // group 0's operands are requested a step ahead; group 1's at the top of phase A, behind group 0's arithmetic (all of
-  // them a step ahead needs 96 registers more than a wave has)
-  Ops pre[NSL];
+  Ops pre[NPRE];
   v4f ct_keep[G][NSL], dc_keep[G][NSL];   // c_t of the step about to be processed; the carried dc (this wave's own slices)
 #pragma unroll
   for (int k = 0; k < G; ++k)
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) {
-      if (k == 0) pre[sl] = issue(0, 0, part * NSL + sl);
+      if (k * NSL + sl < NPRE) pre[k * NSL + sl] = issue(k, 0, part * NSL + sl);
       const unsigned tt0 = rev ? 0 : p.nsteps - 1;
       ct_keep[k][sl] = bld4(rres[k], vlane, (tt0 * NS + part * NSL + sl) * (kReserveRecs * 1024) + 4096);
       dc_keep[k][sl] = zero4;
@@ -120,15 +121,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned oa = tt * sda;
 
     // ---- phase A: gate gradients of my hidden slices, both groups
-    Ops late[NSL];
+    Ops late[NLATE];
 #pragma unroll
-    for (int sl = 0; sl < NSL; ++sl) late[sl] = issue(1, step, part * NSL + sl);
+    for (int i = NPRE; i < G * NSL; ++i) late[(i - NPRE) % NLATE] = issue(i / NSL, step, part * NSL + i % NSL);
 #pragma unroll
     for (int k = 0; k < G; ++k) {
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) {
         const int s = part * NSL + sl;
-        const Ops& in = k == 0 ? pre[sl] : late[sl];
+        const Ops& in = k * NSL + sl < NPRE ? pre[(k * NSL + sl) % NPRE] : late[(k * NSL + sl + NLATE * NPRE - NPRE) % NLATE];
         const v4f ig = in.ig, fg = in.fg, gg = in.gg, og = in.og, ct = ct_keep[k][sl], cp = in.cp;
         v4f dhc = zero4;
         if (step > 0) dhc = dhs[(k * NS + s) * 64];   // the previous step's matrix phase left it there (barrier since)
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // ---- next step's read-only operands travel during the matrix phase
     if (step + 1 < p.nsteps) {
 #pragma unroll
-      for (int sl = 0; sl < NSL; ++sl) pre[sl] = issue(0, step + 1, part * NSL + sl);
+      for (int i = 0; i < NPRE; ++i) pre[i] = issue(i / NSL, step + 1, part * NSL + i % NSL);
     }
 
     // ---- phase B: [dx | dh_prev]^T = [W_ih | W_hh]^T da^T for both groups against one stream of weight records

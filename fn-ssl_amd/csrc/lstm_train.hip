@@ -8,6 +8,7 @@
 #include "lstm_split_static.h"
 #include "lstm_bwdc.h"
 #include "lstm_bwd2.h"
+#include "lstm_fwd2.h"
 
 using namespace fnssl_lstm;
 
@@ -77,6 +78,16 @@ int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
     p.task1 = gm.t1;
     const int groups_per_wg = gm.nw / gm.split;
     p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
+    // H = 256 with four waves per group (config 4's narrow-band layers: two groups per CU): both groups of a CU against one
+    // stream of weight records (lstm_fwd2.h)
+    if (H == 256 && gm.split == 4 && gm.nw == 8 && p.c0 == 256 && !(mode & ~kHas2) && !env_int("FNSSL_NO_FWD2", 1, 1)) {
+      const bool has2 = (mode & kHas2) != 0;
+      if ((!has2 && p.quads_per_slice == 33) || (has2 && p.c2 == 4 && p.quads_per_slice == 34)) {
+        p.wgs_per_dir = (gm.t1 - gm.t0 + 1) / 2;
+        const int nwg2 = p.wgs_per_dir * p.ndir;
+        return has2 ? launch_fwd2_k<256, 16, 1>(p, nwg2, st) : launch_fwd2_k<256, 16, 0>(p, nwg2, st);
+      }
+    }
     const Variant vr{gm.nw, (gm.split > 1 && gm.nw == 8) ? 8 : 4, 1};   // staging registers as in launch_save_m
     const int nwg = p.wgs_per_dir * p.ndir;
     if (gm.split > 1 && !env_int("FNSSL_TRAIN_NO_STATIC", 1, 1)) {   // shape-specialised kernels first

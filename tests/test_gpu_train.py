@@ -388,6 +388,39 @@ def test_two_groups_per_wave_bptt_equals_one_group_per_wave_set(dev, monkeypatch
     assert torch.equal(xa, xb) and torch.equal(xa, xa2), "dx"
 
 
+@pytest.mark.parametrize("c2,nb,nt,nf", [(0, 32, 7, 256), (4, 32, 6, 256), (4, 33, 5, 250), (0, 31, 6, 256)])
+def test_two_groups_per_wave_training_forward_equals_four_waves_per_group(dev, monkeypatch, c2, nb, nt, nf):
+    """Round 4: the narrow-band layers' reserve-saving forward (H = 256, one direction, ~512 groups at config 4's shard) with
+    both groups of a CU against ONE stream of weight records (lstm_fwd2.h; x_t and h_{t-1} through LDS, cell state in
+    registers) — h AND the reserve bit for bit equal to the 4-waves-per-group kernels (FNSSL_NO_FWD2=1), twice; with and
+    without block 1's 4-channel second input, ragged last group, an odd number of groups."""
+    from fnssl import ops
+    from fnssl import weights as W
+    H, c0 = 256, 256
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0 + c2, H, False)], seed=660 + nb + c2)
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], c0, c2, dev)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    x0 = torch.randn((nb, nt, nf, c0), generator=g, device=dev) * 0.7
+    x2 = torch.randn((nb, nt, nf, c2), generator=g, device=dev) * 0.7 if c2 else None
+
+    def run():
+        out = torch.full((nb, nt, nf, H), float("nan"), device=dev)
+        reserve = torch.full((ops.lstm_reserve_floats(nb * nf, H, 1, nt),), float("nan"), device=dev)
+        ops.lstm_layer("narrow", x0, None, x2, packed, H, out, reserve=reserve)
+        return out, reserve
+
+    monkeypatch.delenv("FNSSL_NO_FWD2", raising=False)
+    a, ra = run()
+    a2, ra2 = run()
+    monkeypatch.setenv("FNSSL_NO_FWD2", "1")
+    b, rb = run()
+    assert not torch.isnan(a).any()
+    assert torch.equal(a, b) and torch.equal(a, a2), "h"
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0)  # noqa: E731  (rows of a ragged last group stay unwritten in both)
+    assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)), "reserve"
+
+
 def test_cluster_bptt_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch):
     """A member of cluster 0 that never shows up (FNSSL_CLUSTER_TEST_STALL): the waiting waves give up after the bounded
     number of spins, record a status word, every workgroup drains — no trap, the device stays usable — and the guarded

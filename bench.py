@@ -392,7 +392,7 @@ class FnsslTrain:
 
     def roofline(self, kern):
         traffic, src = traffic_of("c4_lstm_bwd_h256")
-        return kernel_roof(kern, "lstm_bwd_h256", "lstm_bwd_kernel<H=256> (narrow-band BPTT)", PEAK_FP32_MFMA_TFLOPS,
+        return kernel_roof(kern, "lstm_bwd_h256", "lstm_bwd2_kernel<H=256> (narrow-band BPTT, two groups per wave set)", PEAK_FP32_MFMA_TFLOPS,
                            traffic=traffic, traffic_source=src)
 
     def cpu_baseline(self):

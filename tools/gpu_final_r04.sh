@@ -14,7 +14,7 @@ cp $(ls $O/prof/*kernel_stats.csv | head -1) $O/kernel_stats_bench_default_steps
 for cfg in 2 3 4 5; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --config $cfg --steps 1 --warmup 1 --no-cpu-baseline --other-configs "" --ab-steps 0 > $O/pmc_${cfg}_$c.log 2>&1
-    python $R/tools/pmc_summary.py $(ls $O/pmc_$c/*counter_collection.csv | head -1) "lstm_static3|lstm_bf16c_kernel<256|lstm_bwd_kernel<256|sn_mamba_scan" > $O/pmc_c${cfg}_$c.json; rm -rf $O/pmc_$c
+    python $R/tools/pmc_summary.py $(ls $O/pmc_$c/*counter_collection.csv | head -1) "lstm_static3|lstm_bf16c_kernel<256|lstm_bwd2_kernel<256|sn_mamba_scan" > $O/pmc_c${cfg}_$c.json; rm -rf $O/pmc_$c
   done
 done
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc5 -o p -- python $R/bench.py --config 5 --steps 1 --warmup 1 --no-cpu-baseline --other-configs "" > $O/pmc5.log 2>&1

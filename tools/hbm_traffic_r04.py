@@ -8,7 +8,7 @@ d = sys.argv[1]
 KEYS = {2: ("c2_lstm_h256", "lstm_static3", 105696460800.0,
             "49152 sequences x 300 steps x 7 KiB per sequence-step: x_t and the residual operand read, h and h + skip written, h_{t-1} read back once, cell state both ways"),
         3: ("c3_lstm_h256", "lstm_bf16c_kernel<256", None, ""),
-        4: ("c4_lstm_bwd_h256", "lstm_bwd_kernel<256", None, ""),
+        4: ("c4_lstm_bwd_h256", "lstm_bwd2_kernel<256", None, ""),
         5: ("c5_sn_mamba_scan", "sn_mamba_scan", None, "")}
 out = {}
 for cfg, (key, pat, algo, note) in KEYS.items():

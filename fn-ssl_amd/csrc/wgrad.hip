@@ -59,6 +59,7 @@ struct WgradParams {
   const float* xs;      // [rows, 4] (row stride ldxs) or nullptr
   long long ldxs;
   int xs_col;           // its first column in [x0 | x2 | h]
+  int timed;            // ablate build: print per-phase cycles of two workgroups
 };
 
 __device__ __forceinline__ v4f ldg4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
@@ -209,18 +210,41 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
     if (nstage > 2) load_stage(2, R0);
   }
   __syncthreads();
+#ifdef FNSSL_BUILD_ABLATE
+  unsigned long long tm = 0, ts = 0, tb2 = 0, t0 = __builtin_amdgcn_s_memtime(), tbeg = t0;
+#define LAP(X)                                                    \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    X += now_ - t0;                                               \
+    t0 = now_;                                                    \
+  } while (0)
+#else
+#define LAP(X)
+#endif
   for (int st = 0; st < nstage; st += 2) {
     multiply(0);
+    LAP(tm);
     if (st + 1 < nstage) store_stage(1, R1);
     if (st + 3 < nstage) load_stage(st + 3, R1);
+    LAP(ts);
     __syncthreads();
+    LAP(tb2);
     if (st + 1 < nstage) {
       multiply(1);
+      LAP(tm);
       if (st + 2 < nstage) store_stage(0, R0);
       if (st + 4 < nstage) load_stage(st + 4, R0);
+      LAP(ts);
       __syncthreads();
+      LAP(tb2);
     }
   }
+#ifdef FNSSL_BUILD_ABLATE
+  if (p.timed && (blockIdx.x == 0 || blockIdx.x == 777) && (tid & 63) == 0 && (w == 0 || w == 5))
+    printf("wgrad block %d wave %d: %d stages, cycles per stage: total %llu = multiply %llu + stage store / request %llu + barrier %llu\n",
+           (int)blockIdx.x, w, nstage, (__builtin_amdgcn_s_memtime() - tbeg) / nstage, tm / nstage, ts / nstage, tb2 / nstage);
+#endif
+#undef LAP
 
   // ---- partial tile -> workspace [slab][M][ncat]; D fragment: lane (l16, kq) holds rows 4 kq + r, column l16
   float* out = p.part + ((long long)slab * p.M + m0) * p.ncat + ncol0;
@@ -370,6 +394,7 @@ int fnssl_lstm_weight_grads(const fnssl_wgrad_desc* d, void* stream) {
   p.mtiles = p.M / kTM;
   p.ntiles = p.nt0 + p.nt2 + p.nth;
   p.slabs = plan_slabs(p.rows, p.mtiles, p.ntiles, &p.rows_per_slab);
+  p.timed = getenv("FNSSL_WGRAD_TIMED") != nullptr;
   const size_t need = fnssl_lstm_weight_grads_workspace_bytes(p.rows, H, nd, d->c0, d->c2);
   if (!d->workspace || d->workspace_bytes < need) {
     fnssl::set_error("lstm_weight_grads: workspace %zu < %zu bytes", d->workspace_bytes, need);

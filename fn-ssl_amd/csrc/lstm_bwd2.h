@@ -11,7 +11,10 @@
 //     vector-memory requests of the matrix loop: the dA rows both groups need as B operands go through LDS (128 KiB, written
 //     by phase A next to the global copy the weight-gradient kernel reads), and
 //   * the read-only operands of phase A (forward reserve, upstream gradient) of the NEXT step are requested at the start of
-//     the current step's matrix phase (lstm_bwdc.h's lesson: requested when needed they were the longest item of the step).
+//     the current step's matrix phase for the first group (lstm_bwdc.h's lesson: requested when needed they were the longest
+//     item of the step), the second group's at the top of phase A behind the first group's arithmetic;
+//   * the carried dh goes through LDS as well (32 KiB: 160 KiB in all), the carried dc and c_t stay in registers, and the two
+//     barriers of a step wait for LDS only: no vector-memory drain anywhere in the step loop.
 // Arithmetic: lstm_bwd_kernel's phase-A expressions and its k order per output block — bit-identical dA and dx.
 #pragma once
 

@@ -11,9 +11,16 @@ same classes, constructor arguments, ``forward`` signatures, return shapes and
 
 The ``nn.LSTM`` / ``nn.Linear`` sub-modules are kept purely as parameter
 containers (names, shapes, ``load_state_dict``, ``.cuda()``); they are never
-called.  The path is forward-only: modules must be in ``eval()`` mode (the
-reference's dropout is the identity there) and inputs must be ROCm tensors —
-there is no CPU fallback.
+called.  Inputs must be ROCm tensors — there is no CPU fallback.
+
+``eval()`` mode (the reference's dropout is the identity there) takes the
+forward-only inference kernels and returns tensors without a ``grad_fn``.
+``train()`` mode takes the reserve-saving kernels behind a
+``torch.autograd.Function`` (``fnssl/autograd.py``): ``loss.backward()`` runs the
+HIP BPTT / weight-gradient kernels and fills the parameters' ``.grad``, so the
+reference's training loops (Lightning automatic optimisation + DDP,
+main.py:149-157,286-288; ``Learner.train_epoch``, Learner.py:104-115) and any
+``torch.optim`` optimizer work unchanged.  Dropout masks: see ``fnssl/autograd.py``.
 """
 import torch
 import torch.nn as nn
@@ -47,10 +54,10 @@ def _is_bf16(module: nn.Module) -> bool:
     return next(module.parameters()).dtype == torch.bfloat16
 
 
-def _require_eval(m: nn.Module):
+def _require_eval(m: nn.Module, what: str = "forward"):
     if m.training:
-        raise RuntimeError("%s: this is the forward-only MI355X path — call .eval() first "
-                           "(training / dropout are not part of it)" % type(m).__name__)
+        raise RuntimeError("%s.%s: forward-only MI355X entry — call .eval() first (of the drop-in modules only "
+                           "Model.FN_SSL / Model.FNblock carry an autograd graph in train mode)" % (type(m).__name__, what))
 
 
 class FNblock(nn.Module):
@@ -108,8 +115,13 @@ class FNblock(nn.Module):
         As in the reference the incoming ``nb_skip`` is ignored: it is recomputed
         from ``x`` (Model.py:34).  The returned ``x`` is a permuted view of the
         narrow-band output, exactly like the reference's (Model.py:49).
+
+        ``train()`` mode: dropout_full / dropout_narr are active (Model.py:40,48) and the three outputs carry a
+        ``grad_fn`` (``fnssl.autograd.FNblockTrainFunction``: BPTT + weight-gradient kernels on ``backward()``).
         """
-        _require_eval(self)
+        if self.training:
+            from fnssl import autograd as _ag
+            return _ag.fnblock_train_forward(self, x, fb_skip)
         if _is_bf16(self):
             raise RuntimeError("FNblock.forward: the bf16 path runs through FN_SSL.forward (blocks are fused there)")
         nb, nt, nf, nc = x.shape
@@ -151,6 +163,11 @@ class FN_SSL(nn.Module):
         self._net = None
         self._net_key = None
         self.chunk_pairs = 0      # pairs per pass inside the library (0 = whole batch)
+        # train mode (fnssl/autograd.py): dropout-mask keys.  seed None = torch.initial_seed(); pair_offset None =
+        # rank * pairs under an initialised process group (DDP's equal shards), else 0
+        self.dropout_seed, self.dropout_calls, self.pair_offset = None, 0, None
+        for k, blk in enumerate((self.block_1, self.block_2, self.block_3)):
+            blk.dropout_layer = 2 * k          # mask ids when a block is driven on its own
 
     def device_net(self, device) -> "ops.DeviceNet":
         key = (_param_key(self), str(device))
@@ -163,7 +180,9 @@ class FN_SSL(nn.Module):
     @ops.on_device
     def forward_seq(self, x0):
         """x0 [nb', nt, nf, input_size] (the layout the front-end kernels emit) -> DP-IPD."""
-        _require_eval(self)
+        if self.training:
+            from fnssl import autograd as _ag
+            return _ag.fnssl_train_forward(self, x0.permute(0, 3, 2, 1).float())
         if _is_bf16(self):
             return self._forward_seq_bf16(x0.float()).to(x0.dtype)
         return self.device_net(x0.device).forward(x0, self.chunk_pairs)
@@ -207,10 +226,15 @@ class FN_SSL(nn.Module):
 
     @ops.on_device
     def forward(self, x):
-        """x [nb', input_size, nf, nt] -> [nb', nt//12, 2*nf]  (or [.., 180] with is_doa)."""
-        _require_eval(self)
+        """x [nb', input_size, nf, nt] -> [nb', nt//12, 2*nf]  (or [.., 180] with is_doa).
+
+        ``train()`` mode returns a tensor with a ``grad_fn`` (``fnssl.autograd.FNSSLTrainFunction``): the reference's
+        ``pred = self(in_batch); loss.backward()`` (main.py:153-154, Learner.py:104-112) runs on the HIP kernels."""
         if x.ndim != 4 or x.shape[1] != self.input_size:
             raise RuntimeError("FN_SSL: expected [nb, %d, nf, nt], got %s" % (self.input_size, tuple(x.shape)))
+        if self.training:
+            from fnssl import autograd as _ag
+            return _ag.fnssl_train_forward(self, x.float()).to(x.dtype)
         return self.forward_seq(ops.nchw_to_seq(x.float())).to(x.dtype)   # permute(0,3,2,1), Model.py:73
 
 
@@ -225,7 +249,7 @@ class FN_SSL(nn.Module):
         full-band BiLSTMs only look along frequency inside a frame, the narrow-band LSTMs continue from
         their carried (h, c).
         """
-        _require_eval(self)
+        _require_eval(self, "forward_stream")
         if _is_bf16(self):
             raise RuntimeError("FN_SSL.forward_stream: fp32 model only (the streaming kernels are the exact-fp32 ones)")
         if not self.is_online:

@@ -113,6 +113,181 @@ class _Layer:
         self.sfx = [""] + (["_reverse"] if ndir == 2 else [])
 
 
+def build_layers(online: bool):
+    """The six LSTMs of FN_SSL (Model.py:25-29) in forward order: full 1, narrow 1, full 2, ..."""
+    nh = H_NARR_ONLINE if online else H_FULL
+    nd = 1 if online else 2
+    layers = []
+    for k in (1, 2, 3):
+        first = k == 1
+        layers.append(_Layer("block_%d.fullLstm" % k, "full", H_FULL, 2, 4 if first else CH, 0, 0 if first else CH))
+        layers.append(_Layer("block_%d.narrLstm" % k, "narrow", nh, nd, CH, 4 if first else 0, CH))
+    return layers
+
+
+def flat_layout(named_shapes):
+    """name -> (offset, shape) of a flat fp32 vector holding the parameters in the given order; element 0 is a constant
+    0 so that index maps can point "nowhere".  Returns (offset dict, total length incl. element 0)."""
+    offset, off = {}, 1
+    for k, shape in named_shapes:
+        offset[k] = (off, tuple(shape))
+        off += int(np.prod(shape))
+    return offset, off
+
+
+def build_index_maps(layers, offset, dev):
+    """Gather maps flat-vector -> packed weight streams, built once by running the host packers on
+    index-valued weights (indices < 2^24 are exact in fp32)."""
+    maps = {}
+    for L in layers:
+        for s in L.sfx:
+            oi, shi = offset["%s.weight_ih_l0%s" % (L.name, s)]
+            oh, shh = offset["%s.weight_hh_l0%s" % (L.name, s)]
+            obi, shb = offset["%s.bias_ih_l0%s" % (L.name, s)]
+            obh, _ = offset["%s.bias_hh_l0%s" % (L.name, s)]
+            wi = (oi + np.arange(np.prod(shi), dtype=np.float64)).astype(np.float32).reshape(shi)
+            wh = (oh + np.arange(np.prod(shh), dtype=np.float64)).astype(np.float32).reshape(shh)
+            bi = (obi + np.arange(shb[0], dtype=np.float64)).astype(np.float32)
+            bh = (obh + np.arange(shb[0], dtype=np.float64)).astype(np.float32)
+            z = np.zeros(shb[0], dtype=np.float32)
+            a = ops.pack_lstm_host(wi, wh, bi, z, L.c0, L.c2)
+            b = ops.pack_lstm_host(np.zeros_like(wi), np.zeros_like(wh), z, bh, L.c0, L.c2)
+            bw = ops.pack_lstm_bwd_host(wi, wh, L.c0g)
+            to = lambda v: torch.from_numpy(v.astype(np.int64)).to(dev)  # noqa: E731
+            maps[(L.name, s)] = (to(a), to(b), to(bw))
+    return maps
+
+
+def pack_streams(layers, maps, theta):
+    """Device-side re-pack of every weight stream from the current flat parameters (two gathers per direction)."""
+    fw, bw = {}, {}
+    for L in layers:
+        fw[L.name], bw[L.name] = [], []
+        for s in L.sfx:
+            ia, ib, ibw = maps[(L.name, s)]
+            fw[L.name].append(theta[ia] + theta[ib])
+            bw[L.name].append(theta[ibw])
+    return fw, bw
+
+
+class TrainGraph:
+    """Train-mode forward and backward of FN_SSL (Model.py:31-50, 72-90) as two halves over the C-ABI kernels.  Shared by
+    ``TrainEngine`` (which runs loss + both halves per chunk, buffers reused across steps) and ``fnssl.autograd`` (forward
+    in ``Function.forward``, backward in ``Function.backward``, fresh buffers per call).
+
+    ``alloc(key, shape)`` returns an fp32 device tensor; ``pview(name)`` a parameter, ``gview(name)`` the tensor its
+    gradient is ACCUMULATED into; ``layer_done(prefix)`` is called when every gradient under ``prefix`` is final.
+    ``seeds``: six 32-bit dropout seeds (``layer_seed``) or None = dropout off (the eval-mode graph)."""
+
+    def __init__(self, layers, alloc):
+        self.layers, self.alloc = layers, alloc
+        self.Lf = [layers[0], layers[2], layers[4]]
+        self.Ln = [layers[1], layers[3], layers[5]]
+
+    def _natural(self, key, L, nbp, nt, nf, c):
+        """Logical [b, t, f, c] tensor stored in layer L's natural layout."""
+        if L.mode == "full":
+            return self.alloc(key, (nbp, nt, nf, c))
+        return self.alloc(key, (nbp, nf, nt, c)).permute(0, 2, 1, 3)
+
+    @staticmethod
+    def _rows(t_logical, L):
+        """[rows = seq * step, C] matrix of a tensor stored in L's natural layout."""
+        st = t_logical if L.mode == "full" else t_logical.permute(0, 2, 1, 3)
+        return st.reshape(-1, st.shape[-1])
+
+    def _weight_grads(self, L, da, x0, x2, hout, gview, layer_done):
+        """dW_ih = dA^T [x0 | x2],  dW_hh = dA^T h_prev,  db = sum dA, accumulated into the gradient tensors: ONE
+        hand-written split-K fp32-MFMA launch per layer (``fnssl_lstm_weight_grads``, csrc/wgrad.hip; both directions, the
+        three operand segments read in place, h_prev as an index shift) — no vendor GEMM on the path."""
+        nsteps = da.shape[2] if L.mode == "full" else da.shape[1]
+        g = lambda n: [gview("%s.%s%s" % (L.name, n, s)) for s in L.sfx]   # noqa: E731
+        ops.lstm_weight_grads(self._rows(da, L), self._rows(x0, L) if L.c0 else None, self._rows(x2, L) if L.c2 else None,
+                              self._rows(hout, L), L.hidden, L.ndir, nsteps, g("weight_ih_l0"), g("weight_hh_l0"),
+                              g("bias_ih_l0"), g("bias_hh_l0"))
+        layer_done(L.name + ".")
+
+    def forward(self, x, fw, seeds, b0, pview):
+        """x [nbp, 4, nf, nt] features -> (pred [nbp, nt//12, 2nf], saved activations for ``backward``)."""
+        nbp, _, nf, nt = x.shape
+        Lf, Ln = self.Lf, self.Ln
+        sd = (lambda i: None) if seeds is None else (lambda i: seeds[i])
+        XF = ops.nchw_to_seq(x)                                    # [b, t, f, 4]
+        XN = XF.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)   # same numbers, stored [b, f, t, 4]
+        res, U, F, V, N = {}, {}, {}, {}, {}
+        Xk = None
+        for k in (1, 2, 3):
+            lf, ln = Lf[k - 1], Ln[k - 1]
+            F[k] = self._natural("F%d" % k, lf, nbp, nt, nf, 2 * H_FULL)
+            res[lf.name] = self.alloc("R" + lf.name, (ops.lstm_reserve_floats(nbp * nt, lf.hidden, 2, nf),))
+            if k == 1:
+                ops.lstm_layer("full", XF, None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+            else:
+                U[k] = self._natural("U%d" % k, lf, nbp, nt, nf, CH)
+                combine(U[k], plain=(Xk, F[k - 1]))                                   # x + fb_skip  (:36-37)
+                ops.lstm_layer("full", U[k], None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+            V[k] = self._natural("V%d" % k, ln, nbp, nt, nf, CH)
+            if k == 1:
+                combine(V[k], masked=(F[k],), seed32=sd(0), b0=b0)                   # dropout_full (:40)
+            else:
+                combine(V[k], masked=(F[k],), plain=(Xk,), seed32=sd(2 * k - 2), b0=b0)   # + nb_skip (:44-45)
+            N[k] = self._natural("N%d" % k, ln, nbp, nt, nf, ln.ndir * ln.hidden)
+            res[ln.name] = self.alloc("R" + ln.name, (ops.lstm_reserve_floats(nbp * nf, ln.hidden, ln.ndir, nt),))
+            ops.lstm_layer("narrow", V[k], None, XN if k == 1 else None, fw[ln.name], ln.hidden, N[k],
+                           reserve=res[ln.name])
+            Xk = self._natural("X", ln, nbp, nt, nf, CH)
+            combine(Xk, masked=(N[k],), seed32=sd(2 * k - 1), b0=b0)                # dropout_narr (:48)
+        X4 = Xk.permute(0, 2, 1, 3)                                                  # storage [b, f, t, 256]
+        pred = ops.head(X4, pview("emb2ipd.weight"), pview("emb2ipd.bias"))          # [nbp, nt2, 2nf]
+        saved = {"XF": XF, "XN": XN, "res": res, "U": U, "F": F, "V": V, "N": N, "X4": X4, "pred": pred,
+                 "shape": (nbp, nf, nt)}
+        return pred, saved
+
+    def backward(self, saved, dpred, bw, seeds, b0, pview, gview, layer_done=lambda prefix: None):
+        """Accumulate every parameter gradient of the chunk given dL/dpred (contiguous [nbp, nt//12, 2nf])."""
+        nbp, nf, nt = saved["shape"]
+        Lf, Ln = self.Lf, self.Ln
+        sd = (lambda i: None) if seeds is None else (lambda i: seeds[i])
+        XF, XN, res, U, F, V, N, X4, pred = (saved[k] for k in ("XF", "XN", "res", "U", "F", "V", "N", "X4", "pred"))
+        lib = _lib.load()
+        wname, bname = "emb2ipd.weight", "emb2ipd.bias"
+        ws = self.alloc("ws_small", (max(lib.fnssl_head_backward_workspace_bytes() // 4, 256),))
+        G = self.alloc("G", (nbp, nf, nt, CH))                                       # dL/dX4, N storage
+        check(lib.fnssl_head_backward(X4.data_ptr(), pview(wname).data_ptr(), pred.data_ptr(), dpred.data_ptr(),
+                                      nbp, nf, nt, G.data_ptr(), gview(wname).data_ptr(),
+                                      gview(bname).data_ptr(), 1, ws.data_ptr(), ws.numel() * 4, ops._stream()),
+              "head_backward")
+        layer_done("emb2ipd.")
+        gx = (G.permute(0, 2, 1, 3),)                     # operands whose sum is dL/dX_{k+1}
+        dfb = ()                                           # operands whose sum is dL/dF_k through fb_skip
+        for k in (3, 2, 1):
+            lf, ln = Lf[k - 1], Ln[k - 1]
+            DN = self._natural("DN", ln, nbp, nt, nf, ln.ndir * ln.hidden)
+            combine(DN, masked=gx, seed32=sd(2 * k - 1), b0=b0)                      # dropout_narr backward
+            dA = self._natural("dA", ln, nbp, nt, nf, ln.ndir * 4 * ln.hidden)
+            DV = self._natural("DV%d" % (k & 1), ln, nbp, nt, nf, ln.ndir * CH)
+            ops.lstm_backward("narrow", res[ln.name], DN, dA, DV, bw[ln.name], ln.hidden, CH)
+            self._weight_grads(ln, dA, V[k], XN if k == 1 else None, N[k], gview, layer_done)
+            dv = tuple(DV[..., d * CH:(d + 1) * CH] for d in range(ln.ndir))        # one slab per direction
+            DF = self._natural("DF", lf, nbp, nt, nf, 2 * H_FULL)
+            combine(DF, masked=dv, plain=dfb, seed32=sd(2 * k - 2), b0=b0)          # dropout_full backward + fb_skip
+            dA = self._natural("dA", lf, nbp, nt, nf, 2 * 4 * H_FULL)
+            if k > 1:
+                DU = self._natural("DU%d" % (k & 1), lf, nbp, nt, nf, 2 * CH)
+                ops.lstm_backward("full", res[lf.name], DF, dA, DU, bw[lf.name], lf.hidden, CH)
+                self._weight_grads(lf, dA, U[k], None, F[k], gview, layer_done)
+                du = (DU[..., :CH], DU[..., CH:])
+                if len(dv) + 2 > 3:          # offline narrow-band: 2 + 2 operands -> fold the full-band pair first
+                    S = self._natural("S", lf, nbp, nt, nf, CH)
+                    combine(S, plain=du)
+                    du = (S,)
+                gx = dv + du                 # dL/dX_k = dV_k + dU_k  (both uses of x: nb_skip and the full-band input)
+                dfb = du                     # dL/dF_{k-1} through fb_skip
+            else:
+                ops.lstm_backward("full", res[lf.name], DF, dA, None, bw[lf.name], lf.hidden, 0)
+                self._weight_grads(lf, dA, XF, None, F[k], gview, layer_done)
+
+
 class TrainEngine:
     """Owns the flat parameter / gradient / Adam-moment vectors of a ``Model.FN_SSL`` and runs training steps.
 
@@ -139,28 +314,20 @@ class TrainEngine:
         self.dev = dev
         named = list(model.named_parameters())
         self.names = [k for k, _ in named]
-        sizes = [p.numel() for _, p in named]
-        self.nparam = int(sum(sizes))
+        self.offset, total = flat_layout([(k, p.shape) for k, p in named])
+        self.nparam = total - 1
         # element 0 is a constant 0 so that index maps can point "nowhere"
-        self.theta = torch.zeros(1 + self.nparam, dtype=torch.float32, device=dev)
+        self.theta = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros_like(self.theta)
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
-        self.offset, off = {}, 1
-        for (k, p), n in zip(named, sizes):
+        for k, p in named:
+            off, shape = self.offset[k]
+            n = p.numel()
             self.theta[off:off + n].copy_(p.detach().reshape(-1))
             p.data = self.theta[off:off + n].view(p.shape)
-            self.offset[k] = (off, tuple(p.shape))
-            off += n
-        nh = H_NARR_ONLINE if self.online else H_FULL
-        nd = 1 if self.online else 2
-        self.layers = []
-        for k in (1, 2, 3):
-            first = k == 1
-            self.layers.append(_Layer("block_%d.fullLstm" % k, "full", H_FULL, 2, 4 if first else CH, 0,
-                                      0 if first else CH))
-            self.layers.append(_Layer("block_%d.narrLstm" % k, "narrow", nh, nd, CH, 4 if first else 0, CH))
-        self._build_index_maps()
+        self.layers = build_layers(self.online)
+        self.maps = build_index_maps(self.layers, self.offset, dev)
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = {}
 
@@ -175,7 +342,8 @@ class TrainEngine:
         """Index of this rank's first pair in the global batch = the pairs of all lower ranks.  Equal shards give
         rank * nbp without communication; shards are compared with ONE small all-gather (shard_utterances() hands
         the first ranks one utterance more when the batch does not divide), so uneven shards never draw overlapping
-        dropout masks."""
+        dropout masks.  This is a collective plus a host read-back: callers whose shards are equal by construction
+        (a DistributedSampler, ``equal_shard_pair_offset``) pass ``pair_offset`` to ``step`` and never get here."""
         world, rank = self._world_rank()
         if world <= 1:
             return 0
@@ -185,6 +353,12 @@ class TrainEngine:
         counts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(counts, mine, group=self.pg or None)
         return int(sum(int(c.item()) for c in counts[:rank]))
+
+    def equal_shard_pair_offset(self, nbp: int) -> int:
+        """rank * nbp: the first global pair of this rank when every rank holds ``nbp`` pairs (what DDP's
+        DistributedSampler guarantees) — no communication, no host synchronisation."""
+        _, rank = self._world_rank()
+        return rank * int(nbp)
 
     def _bucket(self, prefix):
         """[lo, hi) of the flat vector covered by the parameters whose name starts with ``prefix`` (contiguous:
@@ -230,38 +404,9 @@ class TrainEngine:
         off, shape = self.offset[name]
         return self.theta[off:off + int(np.prod(shape))].view(shape)
 
-    def _build_index_maps(self):
-        """Gather maps flat-vector -> packed weight streams, built once by running the host packers on
-        index-valued weights (indices < 2^24 are exact in fp32)."""
-        self.maps = {}
-        for L in self.layers:
-            for s in L.sfx:
-                oi, shi = self.offset["%s.weight_ih_l0%s" % (L.name, s)]
-                oh, shh = self.offset["%s.weight_hh_l0%s" % (L.name, s)]
-                obi, shb = self.offset["%s.bias_ih_l0%s" % (L.name, s)]
-                obh, _ = self.offset["%s.bias_hh_l0%s" % (L.name, s)]
-                wi = (oi + np.arange(np.prod(shi), dtype=np.float64)).astype(np.float32).reshape(shi)
-                wh = (oh + np.arange(np.prod(shh), dtype=np.float64)).astype(np.float32).reshape(shh)
-                bi = (obi + np.arange(shb[0], dtype=np.float64)).astype(np.float32)
-                bh = (obh + np.arange(shb[0], dtype=np.float64)).astype(np.float32)
-                z = np.zeros(shb[0], dtype=np.float32)
-                a = ops.pack_lstm_host(wi, wh, bi, z, L.c0, L.c2)
-                b = ops.pack_lstm_host(np.zeros_like(wi), np.zeros_like(wh), z, bh, L.c0, L.c2)
-                bw = ops.pack_lstm_bwd_host(wi, wh, L.c0g)
-                to = lambda v: torch.from_numpy(v.astype(np.int64)).to(self.dev)  # noqa: E731
-                self.maps[(L.name, s)] = (to(a), to(b), to(bw))
-
     def _pack_all(self):
         """Device-side re-pack of every weight stream from the current flat parameters (two gathers)."""
-        fw, bw = {}, {}
-        for L in self.layers:
-            fw[L.name] = []
-            bw[L.name] = []
-            for s in L.sfx:
-                ia, ib, ibw = self.maps[(L.name, s)]
-                fw[L.name].append(self.theta[ia] + self.theta[ib])
-                bw[L.name].append(self.theta[ibw])
-        return fw, bw
+        return pack_streams(self.layers, self.maps, self.theta)
 
     def _buf(self, key, shape):
         n = int(np.prod(shape))
@@ -272,64 +417,15 @@ class TrainEngine:
         return b[:n].view(shape)
 
     # ------------------------------------------------------------------ one chunk of pairs
-    def _natural(self, key, L, nbp, nt, nf, c):
-        """Logical [b, t, f, c] tensor stored in layer L's natural layout."""
-        if L.mode == "full":
-            return self._buf(key, (nbp, nt, nf, c))
-        return self._buf(key, (nbp, nf, nt, c)).permute(0, 2, 1, 3)
-
-    @staticmethod
-    def _rows(t_logical, L):
-        """[rows = seq * step, C] matrix of a tensor stored in L's natural layout."""
-        st = t_logical if L.mode == "full" else t_logical.permute(0, 2, 1, 3)
-        return st.reshape(-1, st.shape[-1])
-
-    def _weight_grads(self, L, da, x0, x2, hout):
-        """dW_ih = dA^T [x0 | x2],  dW_hh = dA^T h_prev,  db = sum dA, accumulated into the flat gradient: ONE
-        hand-written split-K fp32-MFMA launch per layer (``fnssl_lstm_weight_grads``, csrc/wgrad.hip; both directions, the
-        three operand segments read in place, h_prev as an index shift) — no vendor GEMM on the path."""
-        nsteps = da.shape[2] if L.mode == "full" else da.shape[1]
-        g = lambda n: [self.gview("%s.%s%s" % (L.name, n, s)) for s in L.sfx]   # noqa: E731
-        ops.lstm_weight_grads(self._rows(da, L), self._rows(x0, L) if L.c0 else None, self._rows(x2, L) if L.c2 else None,
-                              self._rows(hout, L), L.hidden, L.ndir, nsteps, g("weight_ih_l0"), g("weight_hh_l0"),
-                              g("bias_ih_l0"), g("bias_hh_l0"))
-        self._reduce_async(L.name + ".")
+    def _layer_done(self, prefix):
+        self._reduce_async(prefix)
 
     def _chunk(self, x, gt, b0, n_total, fw, bw, seeds):
-        """Forward + backward of pairs [b0, b0 + nbp) (x [nbp, 4, nf, nt]); accumulates grads and the loss."""
+        """Forward + loss + backward of pairs [b0, b0 + nbp) (x [nbp, 4, nf, nt]); accumulates grads and the loss."""
         nbp, _, nf, nt = x.shape
         npair = gt.shape[3]
-        Lf = [self.layers[0], self.layers[2], self.layers[4]]
-        Ln = [self.layers[1], self.layers[3], self.layers[5]]
-        XF = ops.nchw_to_seq(x)                                    # [b, t, f, 4]
-        XN = XF.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)   # same numbers, stored [b, f, t, 4]
-        res, U, F, V, N = {}, {}, {}, {}, {}
-        Xk = None
-        # ---------------- forward (train mode) ----------------
-        for k in (1, 2, 3):
-            lf, ln = Lf[k - 1], Ln[k - 1]
-            F[k] = self._natural("F%d" % k, lf, nbp, nt, nf, 2 * H_FULL)
-            res[lf.name] = self._buf("R" + lf.name, (ops.lstm_reserve_floats(nbp * nt, lf.hidden, 2, nf),))
-            if k == 1:
-                ops.lstm_layer("full", XF, None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
-            else:
-                U[k] = self._natural("U%d" % k, lf, nbp, nt, nf, CH)
-                combine(U[k], plain=(Xk, F[k - 1]))                                   # x + fb_skip  (:36-37)
-                ops.lstm_layer("full", U[k], None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
-            V[k] = self._natural("V%d" % k, ln, nbp, nt, nf, CH)
-            if k == 1:
-                combine(V[k], masked=(F[k],), seed32=seeds[0], b0=b0)                # dropout_full (:40)
-            else:
-                combine(V[k], masked=(F[k],), plain=(Xk,), seed32=seeds[2 * k - 2], b0=b0)   # + nb_skip (:44-45)
-            N[k] = self._natural("N%d" % k, ln, nbp, nt, nf, ln.ndir * ln.hidden)
-            res[ln.name] = self._buf("R" + ln.name, (ops.lstm_reserve_floats(nbp * nf, ln.hidden, ln.ndir, nt),))
-            ops.lstm_layer("narrow", V[k], None, XN if k == 1 else None, fw[ln.name], ln.hidden, N[k],
-                           reserve=res[ln.name])
-            Xk = self._natural("X", ln, nbp, nt, nf, CH)
-            combine(Xk, masked=(N[k],), seed32=seeds[2 * k - 1], b0=b0)             # dropout_narr (:48)
-        X4 = Xk.permute(0, 2, 1, 3)                                                  # storage [b, f, t, 256]
-        wname, bname = "emb2ipd.weight", "emb2ipd.bias"
-        pred = ops.head(X4, self.pview(wname), self.pview(bname))                    # [nbp, nt2, 2nf]
+        graph = TrainGraph(self.layers, self._buf)
+        pred, saved = graph.forward(x, fw, seeds, b0, self.pview)
         nt2 = pred.shape[1]
         lib = _lib.load()
         dpred = self._buf("dpred", tuple(pred.shape))
@@ -337,41 +433,7 @@ class TrainEngine:
         check(lib.fnssl_mse_loss(pred.data_ptr(), gt.data_ptr(), nbp // npair, npair, nt2, 2 * nf, n_total,
                                  dpred.data_ptr(), self.loss_dev.data_ptr(), 1, ws.data_ptr(), ws.numel() * 4,
                                  ops._stream()), "mse_loss")
-        # ---------------- backward ----------------
-        G = self._buf("G", (nbp, nf, nt, CH))                                        # dL/dX4, N storage
-        check(lib.fnssl_head_backward(X4.data_ptr(), self.pview(wname).data_ptr(), pred.data_ptr(), dpred.data_ptr(),
-                                      nbp, nf, nt, G.data_ptr(), self.gview(wname).data_ptr(),
-                                      self.gview(bname).data_ptr(), 1, ws.data_ptr(), ws.numel() * 4, ops._stream()),
-              "head_backward")
-        self._reduce_async("emb2ipd.")
-        gx = (G.permute(0, 2, 1, 3),)                     # operands whose sum is dL/dX_{k+1}
-        dfb = ()                                           # operands whose sum is dL/dF_k through fb_skip
-        for k in (3, 2, 1):
-            lf, ln = Lf[k - 1], Ln[k - 1]
-            DN = self._natural("DN", ln, nbp, nt, nf, ln.ndir * ln.hidden)
-            combine(DN, masked=gx, seed32=seeds[2 * k - 1], b0=b0)                   # dropout_narr backward
-            dA = self._natural("dA", ln, nbp, nt, nf, ln.ndir * 4 * ln.hidden)
-            DV = self._natural("DV%d" % (k & 1), ln, nbp, nt, nf, ln.ndir * CH)
-            ops.lstm_backward("narrow", res[ln.name], DN, dA, DV, bw[ln.name], ln.hidden, CH)
-            self._weight_grads(ln, dA, V[k], XN if k == 1 else None, N[k])
-            dv = tuple(DV[..., d * CH:(d + 1) * CH] for d in range(ln.ndir))        # one slab per direction
-            DF = self._natural("DF", lf, nbp, nt, nf, 2 * H_FULL)
-            combine(DF, masked=dv, plain=dfb, seed32=seeds[2 * k - 2], b0=b0)       # dropout_full backward + fb_skip
-            dA = self._natural("dA", lf, nbp, nt, nf, 2 * 4 * H_FULL)
-            if k > 1:
-                DU = self._natural("DU%d" % (k & 1), lf, nbp, nt, nf, 2 * CH)
-                ops.lstm_backward("full", res[lf.name], DF, dA, DU, bw[lf.name], lf.hidden, CH)
-                self._weight_grads(lf, dA, U[k], None, F[k])
-                du = (DU[..., :CH], DU[..., CH:])
-                if len(dv) + 2 > 3:          # offline narrow-band: 2 + 2 operands -> fold the full-band pair first
-                    S = self._natural("S", lf, nbp, nt, nf, CH)
-                    combine(S, plain=du)
-                    du = (S,)
-                gx = dv + du                 # dL/dX_k = dV_k + dU_k  (both uses of x: nb_skip and the full-band input)
-                dfb = du                     # dL/dF_{k-1} through fb_skip
-            else:
-                ops.lstm_backward("full", res[lf.name], DF, dA, None, bw[lf.name], lf.hidden, 0)
-                self._weight_grads(lf, dA, XF, None, F[k])
+        graph.backward(saved, dpred, bw, seeds, b0, self.pview, self.gview, self._layer_done)
         return pred
 
     # ------------------------------------------------------------------ public API

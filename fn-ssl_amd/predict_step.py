@@ -6,13 +6,20 @@ returns the raw DP-IPD predictions ``[nb*np, nt//12, 512]``.
 ``LightningModule`` (so ``Trainer.predict`` / ``LightningCLI`` drive it exactly
 like the reference's ``main.py predict``); without it the same class derives
 from ``nn.Module`` and ``predict_step`` is called directly (``Predict.py``).
-``training_step`` (main.py:149-157) runs the HIP training path (fnssl.train: forward with
-dropout, MSE loss, BPTT, RCCL gradient all-reduce, Adam) and, because that path carries its own
-backward and optimizer, returns the loss as a detached scalar; ``configure_optimizers`` hands Lightning an
-``EngineOptimizer`` — a ``torch.optim.Optimizer`` whose ``step()`` does no arithmetic (the engine has already
-applied Adam) but which Lightning's manual-optimisation loop counts, so ``trainer.global_step`` advances and
-``ModelCheckpoint`` / ``max_steps`` / logger step indices work, and whose ``state_dict`` carries the engine's Adam
-moments into checkpoints.  The numpy DP-IPD target generator and the DOA metrics stay outside this path
+``training_step`` (main.py:149-157) has two routes, chosen by the constructor's ``fused_engine``:
+
+* ``fused_engine=False`` — the reference's own code path: ``pred = self(in_batch)`` in train mode carries an autograd
+  graph (fnssl/autograd.py: ``torch.autograd.Function`` over the reserve-saving forward and the BPTT / weight-gradient
+  kernels), ``cal_loss`` is differentiable, the returned ``{"loss": loss}`` is what Lightning's AUTOMATIC optimisation
+  calls ``backward()`` on, ``configure_optimizers`` returns the reference's ``torch.optim.Adam`` + ``ExponentialLR``
+  (main.py:269-279), and under ``strategy="ddp"`` (main.py:286-288) DDP's reducer all-reduces the ``.grad``s over RCCL.
+* ``fused_engine=True`` (default; the fast path) — the HIP training engine (fnssl.train: forward with dropout, MSE loss,
+  BPTT, per-layer asynchronous RCCL gradient all-reduce, fused Adam) carries its own backward and optimizer and returns
+  the loss as a detached scalar; ``configure_optimizers`` hands Lightning an ``EngineOptimizer`` — a
+  ``torch.optim.Optimizer`` whose ``step()`` does no arithmetic (the engine has already applied Adam) but which
+  Lightning's manual-optimisation loop counts, so ``trainer.global_step`` advances and ``ModelCheckpoint`` /
+  ``max_steps`` / logger step indices work, and whose ``state_dict`` carries the engine's Adam moments into checkpoints.
+  The numpy DP-IPD target generator and the DOA metrics stay outside this path
 (SURVEY.md §8): ``gt_batch['ipd']`` must already hold the target IPDs.
 """
 import torch
@@ -64,20 +71,45 @@ class EngineOptimizer(torch.optim.Optimizer):
             eng.step_count, eng.lr = int(es["step_count"]), float(es["lr"])
 
 
+class _MSELoss(torch.autograd.Function):
+    """cal_loss (main.py:191-198) as one HIP kernel with its gradient: loss = mean((rebatch(pred) - gt)^2)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        nb, nt2, nf2, npair = gt.shape
+        with torch.cuda.device(pred.device):
+            dpred = torch.empty_like(pred)
+            loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+            ws = torch.empty(256, dtype=torch.float32, device=pred.device)
+            ops.check(ops._lib.load().fnssl_mse_loss(pred.data_ptr(), gt.data_ptr(), nb, npair, nt2, nf2, pred.numel(),
+                                                     dpred.data_ptr(), loss.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4,
+                                                     ops._stream()), "mse_loss")
+        ctx.dpred = dpred
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return ctx.dpred * g, None
+
+
 class MyModel(_Base):
     def __init__(self, tar_useVAD: bool = True, ch_mode: str = 'MM', res_the: int = 37, res_phi: int = 73,
                  fs: int = 16000, win_len: int = 512, nfft: int = 512, win_shift_ratio: float = 0.5,
                  method_mode: str = 'IDL', source_num_mode: str = 'KNum', max_num_sources: int = 1,
                  return_metric: bool = True, exp_name: str = 'exp', compile: bool = False,
-                 device: str = "cuda"):
+                 device: str = "cuda", fused_engine: bool = True):
         super().__init__()
         if (win_len, nfft, win_shift_ratio) != (512, 512, 0.5):
             raise ValueError("the MI355X path is built for win_len = nfft = 512, hop 256 (main.py:38-44)")
         self.arch = at_model.FN_SSL()
-        # Under Lightning the optimisation runs inside the HIP engine (training_step = one complete step and
-        # returns a detached loss): manual optimisation, or Lightning 2.x would call backward() on that loss.
+        self.fused_engine = bool(fused_engine)
+        # fused engine: the optimisation runs inside the HIP engine (training_step = one complete step and returns a
+        # detached loss): manual optimisation, or Lightning 2.x would call backward() on that loss.  Otherwise the
+        # reference's automatic optimisation: Lightning calls loss.backward() (-> fnssl.autograd) and optimizer.step().
         if hasattr(self, "automatic_optimization") or _Base is not torch.nn.Module:
-            self.automatic_optimization = False
+            self.automatic_optimization = not self.fused_engine
         self.method_mode, self.source_num_mode, self.max_num_sources = method_mode, source_num_mode, max_num_sources
         self.ch_mode = ch_mode
         self.nfft = nfft
@@ -100,7 +132,18 @@ class MyModel(_Base):
         One complete optimisation step on this rank's shard; returns {"loss": detached scalar}."""
         mic_sig_batch, gt_batch = batch[0], batch[1]
         x = ops.preprocess(mic_sig_batch.to(self.dev), self.ch_mode, 1e-6, layout=1)
-        loss = self._engine().step(x, gt_batch['ipd'].to(self.dev), sync_loss=False)
+        if not self.fused_engine:
+            # main.py:153-157 as written: forward with a graph (the module must be in train() mode, which Lightning's fit
+            # loop / Learner.train_epoch set), differentiable loss; Lightning or the caller does backward + optimizer step
+            pred_batch = self(x)
+            loss = self.cal_loss(pred_batch=pred_batch, gt_batch=gt_batch)
+            if hasattr(self, "log") and getattr(self, "_trainer", None) is not None:
+                self.log("train/loss", loss, prog_bar=True)
+            return {"loss": loss}
+        eng = self._engine()
+        # a DistributedSampler hands every rank the same number of utterances: the first global pair of this rank is
+        # rank * pairs, no collective and no host synchronisation per step
+        loss = eng.step(x, gt_batch['ipd'].to(self.dev), sync_loss=False, pair_offset=eng.equal_shard_pair_offset(x.shape[0]))
         # manual optimisation: Lightning counts optimizer steps, not training_step calls.  Stepping the (arithmetic-
         # free) EngineOptimizer through self.optimizers() — Lightning's wrapper — advances trainer.global_step, which
         # ModelCheckpoint, max_steps and the loggers key on.
@@ -111,23 +154,22 @@ class MyModel(_Base):
 
     @ops.on_device
     def cal_loss(self, pred_batch=None, gt_batch=None):
-        """main.py:191-198 on device: MSE of the re-batched prediction (no gradient is recorded)."""
-        pred = pred_batch.contiguous()
-        gt = gt_batch['ipd'].to(pred.device).contiguous()
+        """main.py:191-198 on device: MSE of the re-batched prediction — one HIP kernel, differentiable w.r.t.
+        ``pred_batch`` (``_MSELoss``: the kernel emits d loss / d pred alongside the loss)."""
+        gt = gt_batch['ipd'].to(pred_batch.device)
         nb, nt2, nf2, npair = gt.shape
-        lib = ops._lib.load()
-        dpred = torch.empty_like(pred)
-        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
-        ws = torch.empty(256, dtype=torch.float32, device=pred.device)
-        ops.check(lib.fnssl_mse_loss(pred.data_ptr(), gt.data_ptr(), nb, npair, nt2, nf2, pred.numel(),
-                                     dpred.data_ptr(), loss.data_ptr(), 0, ws.data_ptr(), ws.numel() * 4,
-                                     ops._stream()), "mse_loss")
-        return loss.reshape(())
+        if pred_batch.shape[0] != nb * npair or tuple(pred_batch.shape[1:]) != (nt2, nf2):
+            raise RuntimeError("cal_loss: pred %s does not match gt['ipd'] %s" % (tuple(pred_batch.shape), tuple(gt.shape)))
+        return _MSELoss.apply(pred_batch.float(), gt.float())
 
     def configure_optimizers(self):
         """The optimizer (Adam, lr 1e-3; the ExponentialLR decay is applied by ``on_train_epoch_end``) lives in
         the HIP training engine; Lightning gets the ``EngineOptimizer`` shim so that its step counter, checkpoints
-        and ``max_steps`` work (see the class)."""
+        and ``max_steps`` work (see the class).  ``fused_engine=False``: the reference's own dictionary (main.py:269-279)."""
+        if not self.fused_engine:
+            optimizer = torch.optim.Adam(self.arch.parameters(), lr=0.001)
+            lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.8988, last_epoch=-1)
+            return {'optimizer': optimizer, 'lr_scheduler': {'scheduler': lr_scheduler, 'monitor': 'valid/loss'}}
         return EngineOptimizer(self)
 
     def on_train_epoch_end(self):

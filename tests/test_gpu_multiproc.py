@@ -117,6 +117,73 @@ def test_two_processes_on_one_gpu_match_single_process(tmp_path):
     assert abs(0.5 * (losses[0] + losses[1]) - loss) < 1e-5 * max(1.0, abs(loss))   # mean of shard losses = batch loss
 
 
+def _ddp_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "fn-ssl_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import predict_step as ps
+    from fnssl import ops, train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sig, gt = _data()
+    net = _make(dev).train()
+    net.dropout_seed = 3                                           # pair_offset None: rank * pairs (equal shards)
+    ddp = DDP(net, device_ids=[0])
+    opt = torch.optim.Adam(ddp.parameters(), lr=1e-3)
+    lo, hi = train.shard_utterances(2, rank, world)
+    x = ops.preprocess(torch.from_numpy(sig[lo:hi]).to(dev), "MM", layout=1)
+    opt.zero_grad()
+    loss = ps._MSELoss.apply(ddp(x), torch.from_numpy(gt[lo:hi]).to(dev))    # main.py:153-154 under strategy="ddp"
+    loss.backward()                                                # DDP's reducer all-reduces (averages) the .grads
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    np.save(os.path.join(out_dir, "ddp_grad_rank%d.npy" % rank), flat.cpu().numpy())
+    opt.step()
+    np.save(os.path.join(out_dir, "ddp_theta_rank%d.npy" % rank),
+            torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy())
+    np.save(os.path.join(out_dir, "ddp_loss_rank%d.npy" % rank), np.array([float(loss)]))
+    dist.destroy_process_group()
+
+
+def test_ddp_over_the_autograd_route_matches_single_process(tmp_path):
+    """The reference's multi-GPU mechanism as written (Lightning strategy="ddp", main.py:286-288): DistributedDataParallel
+    around the drop-in FN_SSL, train-mode forward with a grad_fn (fnssl/autograd.py), loss.backward() — DDP's own bucket
+    all-reduce averages the gradients.  Two ranks x one utterance each == one process on both utterances: same averaged
+    gradient (2e-5 of the largest entry), same parameters after a torch.optim.Adam step."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm device")
+    import torch.multiprocessing as mp
+    import predict_step as ps
+    from fnssl import ops
+    world = 2
+    mp.spawn(_ddp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    dev = torch.device("cuda:0")
+    sig, gt = _data()
+    net = _make(dev).train()
+    net.dropout_seed = 3
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    loss = ps._MSELoss.apply(net(ops.preprocess(torch.from_numpy(sig).to(dev), "MM", layout=1)), torch.from_numpy(gt).to(dev))
+    loss.backward()
+    g1 = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+    opt.step()
+    theta = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy()
+    g = [np.load(os.path.join(str(tmp_path), "ddp_grad_rank%d.npy" % r)) for r in range(world)]
+    th = [np.load(os.path.join(str(tmp_path), "ddp_theta_rank%d.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(g[0], g[1])                      # DDP leaves the same averaged gradient on every rank
+    np.testing.assert_array_equal(th[0], th[1])
+    scale = np.abs(g1).max()
+    assert np.abs(g[0] - g1).max() <= 2e-5 * scale, (np.abs(g[0] - g1).max(), scale)
+    big = np.abs(g1) > 1e-4 * scale
+    assert_close(th[0][big], theta[big], 0, 2e-6, "parameters after one DDP step (2 ranks vs 1)")
+    losses = [np.load(os.path.join(str(tmp_path), "ddp_loss_rank%d.npy" % r))[0] for r in range(world)]
+    assert abs(0.5 * (losses[0] + losses[1]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+
+
 def test_bench_self_launches_n_ranks(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE must itself start 2 ranks (torch.distributed.run, one process per
     GPU).  This box has ONE GPU, so (a) without the test hook the call must exit non-zero, not fall back to one rank;

@@ -260,7 +260,11 @@ def test_lightning_module_uses_manual_optimization(monkeypatch):
                 self.exp_avg, self.exp_avg_sq = torch.zeros(5), torch.zeros(5)
                 self.step_count, self.lr = 0, 1e-3
 
-            def step(self, x, gt, sync_loss=True):
+            def equal_shard_pair_offset(self, nbp):    # rank * pairs: no collective, no host sync per step
+                return 0
+
+            def step(self, x, gt, sync_loss=True, pair_offset=None):
+                assert pair_offset == 0, "the drop-in training_step passes the offset (no all_gather + .item() per step)"
                 self.step_count += 1
                 self.exp_avg += 1.0
                 return torch.tensor([0.25 / self.step_count])
@@ -286,6 +290,15 @@ def test_lightning_module_uses_manual_optimization(monkeypatch):
         m3 = ps.MyModel(device="cpu")
         m3._train_engine = FakeEngine()
         assert m3.training_step(batch, 0)["loss"].shape == ()
+        # fused_engine=False = the reference's route (main.py:149-157, 269-279): AUTOMATIC optimisation (Lightning calls
+        # backward() on the returned loss, which carries the graph of fnssl.autograd), torch Adam + ExponentialLR
+        m4 = ps.MyModel(device="cpu", fused_engine=False)
+        assert m4.automatic_optimization is True
+        cfg = m4.configure_optimizers()
+        assert isinstance(cfg["optimizer"], torch.optim.Adam) and cfg["optimizer"].defaults["lr"] == 0.001
+        assert isinstance(cfg["lr_scheduler"]["scheduler"], torch.optim.lr_scheduler.ExponentialLR)
+        assert cfg["lr_scheduler"]["scheduler"].gamma == 0.8988 and cfg["lr_scheduler"]["monitor"] == "valid/loss"
+        assert {id(p) for g in cfg["optimizer"].param_groups for p in g["params"]} == {id(p) for p in m4.arch.parameters()}
     finally:
         sys.modules.pop("predict_step", None)
 
@@ -349,3 +362,36 @@ def test_lstm_workspace_covers_the_cluster_hand_off_area():
     assert ws(769, 128, 1) - ws(768, 128, 1) >= per128
     assert ws(16384, 64, 1) < 16384 // 16 * 2 * 4 * 1024                     # H = 64: cell state only
     assert ws(0, 256, 1) == 0
+
+
+def test_train_mode_forward_has_no_cpu_fallback_and_flat_layout_matches_named_parameters():
+    """The autograd route (fnssl/autograd.py) is HIP-only like everything else: a CPU tensor in train mode raises instead
+    of silently running nn.LSTM; the flat layout / layer table it shares with TrainEngine follows named_parameters."""
+    import torch
+    import Model
+    from fnssl import autograd as ag
+    from fnssl import train
+    net = Model.FN_SSL().train()
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        net(torch.zeros(1, 4, 16, 24))
+    blk = Model.FNblock(256, is_online=True).train()
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        blk(torch.zeros(1, 2, 3, 256), None, torch.zeros(2, 3, 256))
+    named = [(k, tuple(p.shape)) for k, p in net.named_parameters()]
+    offset, total = train.flat_layout(named)
+    assert total == 1 + sum(p.numel() for p in net.parameters()) == 1 + 2511362
+    off = 1
+    for k, shape in named:
+        assert offset[k] == (off, shape)
+        off += int(np.prod(shape))
+    layers = train.build_layers(True)
+    assert [(L.name, L.mode, L.hidden, L.ndir, L.c0, L.c2, L.c0g) for L in layers[:2]] == \
+        [("block_1.fullLstm", "full", 128, 2, 4, 0, 0), ("block_1.narrLstm", "narrow", 256, 1, 256, 4, 256)]
+    assert [L.ndir for L in train.build_layers(False)] == [2] * 6
+    assert ag.base_seed(5, 2) == (5 * 1000003 + 2 * 8191) & 0xFFFFFFFF
+    net.force_dropout_base = 77
+    assert ag._next_base(net) == 77 and net.dropout_calls == 1
+    # the forward-only drop-ins still refuse train mode
+    from IPDnet.FixedAarryIPDnet import IPDnet
+    with pytest.raises(RuntimeError, match="eval"):
+        IPDnet().train()(torch.zeros(1, 4, 256, 24))

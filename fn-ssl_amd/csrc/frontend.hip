@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -625,7 +626,7 @@ int fnssl_stft_ex(const float* sig, int nb, int ns, int nch, long long sb, long 
   p.sb = sb; p.sn = sn; p.sc = sc;
   p.spec = reinterpret_cast<float2*>(spec);
   p.magsum = magsum;
-  if (magsum && nch <= kRowsMaxCh && rows_lds_bytes(nch, 0) <= 160 * 1024 && !getenv("FNSSL_STFT_PER_FRAME"))
+  if (magsum && nch <= kRowsMaxCh && rows_lds_bytes(nch, 0) <= 160 * 1024 && !fnssl::tune(FNSSL_TUNE_STFT_PER_FRAME))
     return launch_rows<0>(p, "stft", fnssl::as_stream(stream));
   // fallback (no magnitude sums wanted, or more channels than the frame image holds): one wave per (b, c, t)
   const long long nframes = (long long)nb * nch * nt;

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 
 #include "lstm_static.h"
 #include "lstm_bf16.h"
@@ -298,8 +299,10 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
 #ifdef FNSSL_BUILD_ABLATE
   p.ablate = env_int("FNSSL_ABLATE", 1, 255);   // timing experiments: twin kernels that skip work (wrong results)
+  const bool abl_static2 = env_int("FNSSL_ABL_STATIC2", 1, 1) != 0;
 #else
   p.ablate = 0;                                 // the shipping library contains no ablation twins (make ABLATE=1)
+  const bool abl_static2 = false;
 #endif
   p.dry = dry ? 1 : 0;
   p.fallback_count = d->fallback_count;
@@ -393,7 +396,7 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
     p.wgs_per_dir = (t1 - t0 + vr.NW - 1) / vr.NW;
     const int nwg = p.wgs_per_dir * d->ndir;
     ++nlaunch;
-    if (d->variant == 0 && !env_int("FNSSL_LSTM_NO_STATIC", 1, 1)) {
+    if (d->variant == 0 && !fnssl::tune(FNSSL_TUNE_LSTM_NO_STATIC)) {
       int rc = kNoStatic;
       if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
       if (H == 256) {
@@ -401,9 +404,9 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
         // is re-ordered into the workspace first (2 MB per direction, one tiny launch) — FNSSL_NO_STATIC2=1: A/B
         // — or, since round 4, the operand-ring kernel (lstm_static3.h: h_{t-1} streamed like x_t, no register spills, block
         // 1's 260-channel layer included); FNSSL_NO_STATIC3=1 keeps lstm_static2_kernel / the one-slice kernel: A/B
-        const bool s3 = !p.ablate && !env_int("FNSSL_NO_STATIC3", 1, 1) && (mode == kSum || mode == 0 || mode == (kHas2 | kSum)) &&
+        const bool s3 = !p.ablate && !fnssl::tune(FNSSL_TUNE_NO_STATIC3) && (mode == kSum || mode == 0 || mode == (kHas2 | kSum)) &&
                         ((d->c2 == 0 && !(mode & kHas2)) || (d->c2 == 4 && (mode & kHas2)));
-        const bool s2 = d->c2 == 0 && !(mode & ~kSum) && (!p.ablate || env_int("FNSSL_ABL_STATIC2", 1, 1)) && !env_int("FNSSL_NO_STATIC2", 1, 1);
+        const bool s2 = d->c2 == 0 && !(mode & ~kSum) && (!p.ablate || abl_static2) && !fnssl::tune(FNSSL_TUNE_NO_STATIC2);
         if (vr.NW == 12 && d->c0 == 256 && !p.carry && (s3 || s2)) {
           LstmParams p2 = p;
           const long long n4 = (long long)(H / 16) * p.quads_per_slice * 4 * 64;      // float4 per direction
@@ -429,7 +432,7 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
         }
         rc = launch_static_h256(p, mode, vr.NW, nwg, st);
       }
-      if (rc == kNoStatic && !env_int("FNSSL_NO_STATIC_IPDNET", 1, 1)) rc = launch_static_ipdnet(p, mode, H, vr.NW, nwg, st);
+      if (rc == kNoStatic && !fnssl::tune(FNSSL_TUNE_NO_STATIC_IPDNET)) rc = launch_static_ipdnet(p, mode, H, vr.NW, nwg, st);
       if (rc != kNoStatic) {
         report(FNSSL_LSTM_FAMILY_STATIC);
         return rc;
@@ -484,13 +487,13 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   };
   {
     const long long total = (long long)tasks * d->ndir;
-    if (const int f = env_int("FNSSL_LSTM_SPLIT", 1, 4)) {
+    if (const int f = fnssl::tune(FNSSL_TUNE_LSTM_SPLIT, 1, 4)) {
       if (f != 1) return launch_split(f == 3 ? 2 : f, 0, tasks, false);
     } else {
       // ring-free shape-specialised kernels (H = 256 layers of the network): 4 waves per group pay up to 6 groups
       // per CU (16 utterances: 13.9 -> 15.6 k frames/s); generic split kernels up to 2 groups per CU
       // (profiles/r01/d_batch_scan.txt)
-      const int s4 = env_int("FNSSL_SPLIT4_MAX_H256", 1, 64) ? env_int("FNSSL_SPLIT4_MAX_H256", 1, 64) : 6;   // tuning knob
+      const int s4 = fnssl::tune(FNSSL_TUNE_SPLIT4_MAX_H256, 1, 64) ? fnssl::tune(FNSSL_TUNE_SPLIT4_MAX_H256, 1, 64) : 6;   // tuning knob
       if (H == 256 && total <= (long long)s4 * ncu) {
         const int rc = launch_split(4, 0, tasks, true);
         if (rc != kNoStatic) return rc;

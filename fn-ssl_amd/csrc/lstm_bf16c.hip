@@ -2,13 +2,14 @@
 #include <cstdlib>
 
 #include "lstm_bf16c.h"
+#include "tuning.h"
 
 namespace fnssl_lstm {
 
 // true when a cluster kernel is built for the shape (and not switched off: FNSSL_NO_CLUSTER=1 keeps the pair-split
 // kernels of lstm_bf16p.h, which give the same bits — A/B, and the path of shapes / batches not covered here)
 bool bf16c_handles(const LstmParams& p, int H, int flags) {
-  if (getenv("FNSSL_NO_CLUSTER")) return false;
+  if (fnssl::tune(FNSSL_TUNE_NO_CLUSTER)) return false;
   // Measured on MI355X (profiles/r03/j_*, "small batches"): the narrow-band kernel wins at every batch (12.5 against 19.7 us
   // per step from 512 sequences up: no weight stream at all); the full-band kernels walk three parts per step (~18 us)
   // where one round of pair-split workgroups takes ~10, so they take over when the pair-split launch would need more
@@ -16,10 +17,10 @@ bool bf16c_handles(const LstmParams& p, int H, int flags) {
   const long long pair_wgs = (long long)((p.nseq + 63) / 64) * p.ndir;
   const bool past_one_round = pair_wgs > fnssl::device_cus();
   if (H == 128 && p.c0 == 16 && p.c2 == 0 && flags == kW_F0)   // block 1's full-band layer: 16 fp32 feature channels
-    return past_one_round && !getenv("FNSSL_NO_CLUSTER_B1");
+    return past_one_round && !fnssl::tune(FNSSL_TUNE_NO_CLUSTER_B1);
   if (p.c0 != 256 || p.c2 != 16 || flags != kW_F2) return false;
   if (H == 256) return true;
-  if (H == 128) return past_one_round && !getenv("FNSSL_NO_CLUSTER_H128");
+  if (H == 128) return past_one_round && !fnssl::tune(FNSSL_TUNE_NO_CLUSTER_H128);
   return false;
 }
 
@@ -69,7 +70,7 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   cp.parity_stride = (unsigned)((size_t)ncl * cluster_parity_bytes(H));
   cp.cl_per_dir = cl_per_dir;
   // placement is a speed matter only; the knob puts the members of a cluster on DIFFERENT XCDs so that tests can show it
-  cp.spread = getenv("FNSSL_CLUSTER_SPREAD") ? 1 : 0;
+  cp.spread = fnssl::tune(FNSSL_TUNE_CLUSTER_SPREAD) ? 1 : 0;
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
   // status word + tags, and the parity-1 operand records (step 0 reads h_{-1} = 0 from them)

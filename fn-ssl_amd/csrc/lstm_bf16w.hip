@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "lstm_bf16p.h"
+#include "tuning.h"
 
 namespace fnssl_lstm {
 
@@ -48,7 +49,7 @@ int launch_bf16p(const LstmParams& p, int H, int flags, int nwg, hipStream_t st)
     }
   }
 #endif
-  const bool drain = env_int("FNSSL_BF16P_DRAIN", 1, 1) != 0;   // vmcnt(0) at every ring barrier, all shapes
+  const bool drain = fnssl::tune(FNSSL_TUNE_BF16P_DRAIN) != 0;   // vmcnt(0) at every ring barrier, all shapes
   TRYP(128, 1, 0, kW_F0)
   TRYP(256, 16, 1, kW_F2)
   TRYP(128, 16, 1, kW_F2)
@@ -78,7 +79,7 @@ int forward_bf16w(LstmParams p, int H, int flags, hipStream_t st, int* family) {
     }
   }
   int rc;
-  if (!getenv("FNSSL_BF16W_SOLO") || guarded) {
+  if (!fnssl::tune(FNSSL_TUNE_BF16W_SOLO) || guarded) {
     if (family && !guarded) *family = FNSSL_LSTM_FAMILY_BF16_PAIR;
     // Two 32-sequence groups per workgroup.  lstm_bf16p_kernel takes NG groups (template), and 3 / 4 / 5 were built and
     // measured at config 3 (profiles/r03/h_bf16p_groups_per_workgroup.txt) in the hope of turning the full-band layers'

@@ -1,5 +1,6 @@
 // Host side of the cluster-resident BPTT kernel (lstm_bwdc.h): geometry, workspace carve-up, launch.
 #include "common.h"
+#include "tuning.h"
 
 #include "lstm_bwdc.h"
 
@@ -15,7 +16,7 @@ size_t bwdc_bytes(int nseq, int ndir) {
 // the waves of a cluster get a group (config 4, block 1: 2 members, 9.4 groups per cluster — 10.7 against 13.4 ms on the
 // split kernels; fewer: the split kernels fill the chip better).  FNSSL_BWD_NO_CLUSTER=1 turns it off.
 bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
-  if (H != 128 || env_int("FNSSL_BWD_NO_CLUSTER", 1, 1)) return false;
+  if (H != 128 || fnssl::tune(FNSSL_TUNE_BWD_NO_CLUSTER)) return false;
   const int ncu = fnssl::device_cus();
   const int per_xcd = ncu / 8;
   cp.members = p.co_pad / 64;
@@ -25,7 +26,7 @@ bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
   if (clusters % p.ndir) return false;
   cp.clusters_per_dir = clusters / p.ndir;
   cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
-  const int min_groups = env_int("FNSSL_BWD_CLUSTER_MIN_GROUPS", 1, 1 << 20);
+  const int min_groups = fnssl::tune(FNSSL_TUNE_BWD_CLUSTER_MIN_GROUPS, 1, 1 << 20);
   return cp.groups_per_cluster >= (min_groups ? min_groups : 8);
 }
 
@@ -35,16 +36,16 @@ int backward_cluster(const BwdParams& p, BwdClusterParams cp, void* ws, hipStrea
   cp.tags = cp.status + 64;
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
-  cp.rotate = !env_int("FNSSL_BWD_CLUSTER_NO_ROTATE", 1, 1);
-  cp.no_prefetch = env_int("FNSSL_BWDC_NO_PREFETCH", 1, 1);
-  cp.simd_token = !env_int("FNSSL_BWDC_NO_TOKEN", 1, 1);
+  cp.rotate = !fnssl::tune(FNSSL_TUNE_BWD_CLUSTER_NO_ROTATE);
+  cp.no_prefetch = fnssl::tune(FNSSL_TUNE_BWDC_NO_PREFETCH);
+  cp.simd_token = !fnssl::tune(FNSSL_TUNE_BWDC_NO_TOKEN);
   if (p.dry) return FNSSL_OK;
   const size_t tag_bytes = (size_t)cp.clusters_per_dir * p.ndir * cp.groups_per_cluster * 16 * sizeof(unsigned);
   FNSSL_HIP(hipMemsetAsync(ws, 0, 256 + tag_bytes, st));
 #ifdef FNSSL_BUILD_ABLATE
   if ((cp.ablate = env_int("FNSSL_BWDC_ABLATE", 1, 1 << 20)) != 0) return launch_bwdc_k<kBwdcWaves, true>(p, cp, st);
 #endif
-  if (env_int("FNSSL_BWDC_WAVES16", 1, 1)) return launch_bwdc_k<16, false, 4>(p, cp, st);   // the first shape: 16 waves, 4-deep ring
+  if (fnssl::tune(FNSSL_TUNE_BWDC_WAVES16)) return launch_bwdc_k<16, false, 4>(p, cp, st);   // the first shape: 16 waves, 4-deep ring
   return launch_bwdc_k<kBwdcWaves>(p, cp, st);
 }
 

@@ -671,6 +671,9 @@ constexpr Variant kVariants[kNumVariants + 1] = {
     {15, 2, 1},   // 11
 };
 
+#ifdef FNSSL_BUILD_ABLATE
+// `make ABLATE=1` builds only (libfnssl_hip_abl.so: timing twins that skip work): their knobs are environment variables.
+// The shipping library reads NO environment variable — it does not even contain this function — see tuning.h.
 inline int env_int(const char* name, int lo, int hi) {
   if (const char* e = getenv(name)) {
     const int v = atoi(e);
@@ -678,12 +681,13 @@ inline int env_int(const char* name, int lo, int hi) {
   }
   return 0;
 }
+#endif
 
-// tuning override for experiments: FNSSL_LSTM_VARIANT_H256=3 etc. (0 = none)
+// tuning override for experiments: fnssl_tuning.knob[FNSSL_TUNE_LSTM_VARIANT_H256] = 3 etc. (0 = none)
 inline int default_variant_override(int H) {
-  char name[40];
-  snprintf(name, sizeof(name), "FNSSL_LSTM_VARIANT_H%d", H);
-  return env_int(name, 1, kNumVariants);
+  if (H == 128) return fnssl::tune(FNSSL_TUNE_LSTM_VARIANT_H128, 1, kNumVariants);
+  if (H == 256) return fnssl::tune(FNSSL_TUNE_LSTM_VARIANT_H256, 1, kNumVariants);
+  return 0;
 }
 
 inline int default_variant(int H) {
@@ -711,7 +715,7 @@ inline void choose_chunk(int qps, const Variant& v, int& chq, int& pad, int spli
       }
   chq = best_c;
   pad = best_p;
-  if (const int f = env_int("FNSSL_LSTM_CHQ", 1, cap)) {   // experiments: force a chunk size
+  if (const int f = fnssl::tune(FNSSL_TUNE_LSTM_CHQ, 1, cap)) {   // experiments: force a chunk size
     chq = f;
     pad = (f - qps % f) % f;
   }

@@ -1,6 +1,7 @@
 // (H = 128) Instantiations of lstm_split_static_kernel for the layer shapes of the FN-SSL training step (reserve-saving
 // forward at 2 or 4 waves per 16-sequence group).
 #include "lstm_split_static.h"
+#include "tuning.h"
 
 namespace fnssl_lstm {
 
@@ -18,7 +19,7 @@ namespace fnssl_lstm {
 
 int launch_split_static_h128(const LstmParams& p, int H, int nw, int split, int mode, int max_chq, int nwg, hipStream_t st) {
   if (max_chq <= 0) max_chq = 1 << 20;
-  if (!env_int("FNSSL_FWD_RING", 1, 1)) {
+  if (!fnssl::tune(FNSSL_TUNE_FWD_RING)) {
   }
   // narrow-band H = 256: 33 quads per slice (34 with the 4 data channels of block 1)
   // H = 128: full-band (25 quads; block 1: 10) and the offline narrow-band layers (25 / 26)

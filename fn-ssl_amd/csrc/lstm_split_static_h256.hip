@@ -1,6 +1,7 @@
 // (H = 256) Instantiations of lstm_split_static_kernel for the layer shapes of the FN-SSL training step (reserve-saving
 // forward at 2 or 4 waves per 16-sequence group).
 #include "lstm_split_static.h"
+#include "tuning.h"
 
 namespace fnssl_lstm {
 
@@ -23,7 +24,7 @@ namespace fnssl_lstm {
 
 int launch_split_static_h256(const LstmParams& p, int H, int nw, int split, int mode, int max_chq, int nwg, hipStream_t st) {
   if (max_chq <= 0) max_chq = 1 << 20;
-  if (!env_int("FNSSL_FWD_RING", 1, 1)) {
+  if (!fnssl::tune(FNSSL_TUNE_FWD_RING)) {
     TRYI(0, kSum)
     TRYI(1, kHas2 | kSum)
     TRYI(0, 0)

@@ -290,11 +290,19 @@ constexpr int kNoStatic = -100;
 // query): the caller runs the per-wave / pair-split kernels instead, unguarded.
 constexpr int kNoCluster = -101;
 
-// Test / tuning knobs of the cluster kernels' bounded waits: FNSSL_CLUSTER_SPIN_LIMIT (spins before a wave gives up),
-// FNSSL_CLUSTER_TEST_STALL=m (member m of cluster 0 exits at once, as if it never became resident).
+// Knobs of the cluster kernels' bounded waits (fnssl_tuning): CLUSTER_SPIN_LIMIT (spins before a wave gives up),
+// CLUSTER_TEST_STALL = m + 1 (fault injection: member m of cluster 0 exits at once, as if it never became resident).
 inline unsigned cluster_spin_limit() {
-  const int v = env_int("FNSSL_CLUSTER_SPIN_LIMIT", 1, 1 << 30);
+  const int v = fnssl::tune(FNSSL_TUNE_CLUSTER_SPIN_LIMIT, 1, 1 << 30);
   return v ? (unsigned)v : (1u << 20);
+}
+// compute units the cluster kernels may count on: the device's minus what the caller keeps busy elsewhere (RESERVED_CUS:
+// RCCL's all-reduce kernels under an overlapped backward), in whole XCD-uniform steps (a multiple of 8 CUs)
+inline int cluster_cus() {
+  const int ncu = fnssl::device_cus();
+  int r = fnssl::tune(FNSSL_TUNE_RESERVED_CUS, 1, ncu);
+  r = (r + 7) / 8 * 8;
+  return r >= ncu ? 0 : ncu - r;
 }
 // blocks the device can hold at once for this kernel (occupancy query x CUs) >= grid?  One query per call: cheap (host only).
 inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int grid) {
@@ -305,10 +313,7 @@ inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int g
   }
   return (long long)per_cu * fnssl::device_cus() >= grid;
 }
-inline int cluster_test_stall() {
-  const char* e = getenv("FNSSL_CLUSTER_TEST_STALL");
-  return e ? atoi(e) : -1;
-}
+inline int cluster_test_stall() { return fnssl::tune(FNSSL_TUNE_CLUSTER_TEST_STALL, 1, 1 << 20) - 1; }
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static2_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static2.h, pair-interleaved stream

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "lstm_kernel.h"
+#include "tuning.h"
 
 namespace fnssl_lstm {
 
@@ -288,7 +289,7 @@ int launch_bwd(int nw, int split, const BwdParams& p, int nwg, hipStream_t st) {
       case 8: return launch_bwd_k<H, 8, 4>(p, nwg, st);
       case 12: return launch_bwd_k<H, 12, 4>(p, nwg, st);
     }
-  } else if (split == 4 && !env_int("FNSSL_BWD_RING", 1, 1)) {
+  } else if (split == 4 && !fnssl::tune(FNSSL_TUNE_BWD_RING)) {
     // 4 waves per group: weights straight from L2 (narrow-band BPTT 31.8 -> 26.0 ms at config 4; with 2 waves
     // per group the LDS ring is as fast, r01 f_train_layers)
     if (nw == 4) return launch_bwd_k<H, 4, 1, 4, true>(p, nwg, st);

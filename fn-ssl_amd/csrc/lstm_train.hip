@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "tuning.h"
 
 #include "lstm_train.h"
 #include "lstm_split_static.h"
@@ -46,7 +47,7 @@ static int plan_rounds(int tasks, int ndir, int max_split, int split4_groups_per
     split = 4;
   else if (total * 2 <= 12LL * ncu)
     split = 2;
-  if (const int f = env_int("FNSSL_TRAIN_SPLIT", 1, 4)) split = f == 3 ? 2 : f;
+  if (const int f = fnssl::tune(FNSSL_TUNE_TRAIN_SPLIT, 1, 4)) split = f == 3 ? 2 : f;
   if (split > max_split) split = max_split;
   if (split > 1) {
     // (one group per workgroup — 512 four-wave workgroups, two per CU, which drift apart — was measured at config 4:
@@ -80,7 +81,7 @@ int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
     p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
     // H = 256 with four waves per group (config 4's narrow-band layers: two groups per CU): both groups of a CU against one
     // stream of weight records (lstm_fwd2.h)
-    if (H == 256 && gm.split == 4 && gm.nw == 8 && p.c0 == 256 && !(mode & ~kHas2) && !env_int("FNSSL_NO_FWD2", 1, 1)) {
+    if (H == 256 && gm.split == 4 && gm.nw == 8 && p.c0 == 256 && !(mode & ~kHas2) && !fnssl::tune(FNSSL_TUNE_NO_FWD2)) {
       const bool has2 = (mode & kHas2) != 0;
       if ((!has2 && p.quads_per_slice == 33) || (has2 && p.c2 == 4 && p.quads_per_slice == 34)) {
         p.wgs_per_dir = (gm.t1 - gm.t0 + 1) / 2;
@@ -90,7 +91,7 @@ int forward_save(LstmParams p, int H, int mode, hipStream_t st) {
     }
     const Variant vr{gm.nw, (gm.split > 1 && gm.nw == 8) ? 8 : 4, 1};   // staging registers as in launch_save_m
     const int nwg = p.wgs_per_dir * p.ndir;
-    if (gm.split > 1 && !env_int("FNSSL_TRAIN_NO_STATIC", 1, 1)) {   // shape-specialised kernels first
+    if (gm.split > 1 && !fnssl::tune(FNSSL_TUNE_TRAIN_NO_STATIC)) {   // shape-specialised kernels first
       const int rc = launch_split_static(p, H, gm.nw, gm.split, mode | kSave, lds_chunk_cap(nwg, gm.split), nwg, st);
       if (rc != kNoStatic) return rc;
     }
@@ -253,7 +254,7 @@ static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dr
     p.wgs_per_dir = (gm.t1 - gm.t0 + groups_per_wg - 1) / groups_per_wg;
     // H = 256 with four waves per group (config 4's narrow-band layers: two groups per CU): both groups of a CU against one
     // stream of weight records (lstm_bwd2.h)
-    if (H == 256 && gm.split == 4 && gm.nw == 8 && nso % 4 == 0 && !env_int("FNSSL_NO_BWD2", 1, 1)) {
+    if (H == 256 && gm.split == 4 && gm.nw == 8 && nso % 4 == 0 && !fnssl::tune(FNSSL_TUNE_NO_BWD2)) {
       p.wgs_per_dir = (gm.t1 - gm.t0 + 1) / 2;
       return launch_bwd2_k<256>(p, p.wgs_per_dir * p.ndir, st);
     }

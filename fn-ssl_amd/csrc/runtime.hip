@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace fnssl {
 
@@ -26,6 +27,66 @@ int device_cus() {
 
 
 static thread_local char g_err[512] = "";
+
+// ---- tuning: one slot per thread, plus the descriptor of the call in progress -------------------------------------
+namespace {
+thread_local fnssl_tuning g_thread_tuning = {sizeof(fnssl_tuning), {0}};
+thread_local const fnssl_tuning* g_call_tuning = nullptr;
+const char* const kTuneNames[] = {
+    "LSTM_NO_STATIC",
+    "NO_STATIC3",
+    "NO_STATIC2",
+    "NO_STATIC_IPDNET",
+    "LSTM_SPLIT",
+    "SPLIT4_MAX_H256",
+    "LSTM_VARIANT_H128",
+    "LSTM_VARIANT_H256",
+    "LSTM_CHQ",
+    "NO_F32_CLUSTER",
+    "NO_F32C_B1",
+    "TRAIN_NO_F32_CLUSTER",
+    "F32C_NO_ROTATE",
+    "F32C_PRIO",
+    "NO_CLUSTER",
+    "NO_CLUSTER_B1",
+    "NO_CLUSTER_H128",
+    "CLUSTER_SPREAD",
+    "BF16P_DRAIN",
+    "BF16W_SOLO",
+    "BWD_NO_CLUSTER",
+    "BWD_CLUSTER_MIN_GROUPS",
+    "BWD_CLUSTER_NO_ROTATE",
+    "BWDC_NO_PREFETCH",
+    "BWDC_NO_TOKEN",
+    "BWDC_WAVES16",
+    "FWD_RING",
+    "BWD_RING",
+    "TRAIN_SPLIT",
+    "TRAIN_NO_STATIC",
+    "NO_FWD2",
+    "NO_BWD2",
+    "SN_SCALAR",
+    "STFT_PER_FRAME",
+    "CLUSTER_SPIN_LIMIT",
+    "CLUSTER_TEST_STALL",
+    "RESERVED_CUS",
+    "NO_F32_SMALL"};
+constexpr int kTuneNamed = (int)(sizeof(kTuneNames) / sizeof(kTuneNames[0]));
+static_assert(kTuneNamed <= FNSSL_TUNE_COUNT, "more knob names than slots");
+static_assert(kTuneNamed == FNSSL_TUNE_NO_F32_SMALL + 1, "knob names out of step with include/fnssl.h");
+}  // namespace
+
+const fnssl_tuning& tuning() { return g_call_tuning ? *g_call_tuning : g_thread_tuning; }
+
+TuningScope::TuningScope(const fnssl_tuning* t) : prev_(g_call_tuning), active_(false) {
+  if (t && t->struct_bytes == sizeof(fnssl_tuning)) {
+    g_call_tuning = t;
+    active_ = true;
+  }
+}
+TuningScope::~TuningScope() {
+  if (active_) g_call_tuning = prev_;
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -70,6 +131,27 @@ TimedLaunch::~TimedLaunch() {
 }
 
 }  // namespace fnssl
+
+extern "C" int fnssl_tuning_set(const fnssl_tuning* t) {
+  if (!t) {
+    fnssl::g_thread_tuning = fnssl_tuning{sizeof(fnssl_tuning), {0}};
+    return FNSSL_OK;
+  }
+  FNSSL_REQUIRE(t->struct_bytes == sizeof(fnssl_tuning), "tuning_set: struct_bytes %u, this library's fnssl_tuning has %zu",
+                t->struct_bytes, sizeof(fnssl_tuning));
+  fnssl::g_thread_tuning = *t;
+  return FNSSL_OK;
+}
+
+extern "C" int fnssl_tuning_get(fnssl_tuning* t) {
+  FNSSL_REQUIRE(t != nullptr, "tuning_get: NULL");
+  *t = fnssl::g_thread_tuning;
+  return FNSSL_OK;
+}
+
+extern "C" const char* fnssl_tuning_name(int index) {
+  return index >= 0 && index < fnssl::kTuneNamed ? fnssl::kTuneNames[index] : nullptr;
+}
 
 namespace {
 typedef float peak_v4f __attribute__((ext_vector_type(4)));

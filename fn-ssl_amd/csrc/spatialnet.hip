@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -1842,7 +1843,7 @@ int fnssl_sn_encoder(const float* x, long long x_sb, long long x_sc, long long x
     const bool bf = precision == FNSSL_PRECISION_BF16;
     FNSSL_REQUIRE(!bf || (kk <= 160 && off32), "sn_encoder: FNSSL_PRECISION_BF16 needs cin * 5 <= 160 (cin %d) and 32-bit offsets",
                   cin);
-    if ((bf || !getenv("FNSSL_SN_SCALAR")) && kk <= 160 && off32) {
+    if ((bf || !fnssl::tune(FNSSL_TUNE_SN_SCALAR)) && kk <= 160 && off32) {
 #define FNSSL_SN_ENC_P(KP, BF, PIPE)                                                                                \
   do {                                                                                                              \
     const size_t lds = (size_t)(w_lds_floats<KP, H, BF>() + H) * sizeof(float);                                     \
@@ -1895,7 +1896,7 @@ int fnssl_sn_fconv(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
                         2.0 * nframes * nf * H * CG * KF);
   // below 16 bins there is no matrix-pipe kernel: the product stays exact fp32 in both modes (include/fnssl.h)
   const bool bf = precision == FNSSL_PRECISION_BF16 && nf >= 16;
-  const bool mfma = (bf || !getenv("FNSSL_SN_SCALAR")) && nf >= 16;
+  const bool mfma = (bf || !fnssl::tune(FNSSL_TUNE_SN_SCALAR)) && nf >= 16;
   const size_t lds = (size_t)(NG * (bf ? w_lds_floats<64, 16, true>() : w_lds_floats<64, 16, false>()) + 4 * H +
                               (256 + 4 * (256 >> lg)) * 100) * sizeof(float);
   const long long cus = fnssl::device_cus();
@@ -1941,7 +1942,7 @@ int fnssl_sn_full(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_s
   fnssl::TimedLaunch tl("sn_full", s, 2.0 * nframes * nf * (2.0 * H * HS + (double)HS * nf));
   // the matrix-pipe kernel exists for 16, 64 and 128 bins; elsewhere the products stay exact fp32 in both modes
   const bool bf = precision == FNSSL_PRECISION_BF16 && (nf == 16 || nf == 64 || nf == 128);
-  const bool mfma = (bf || !getenv("FNSSL_SN_SCALAR")) && (nf == 16 || nf == 64 || nf == 128);
+  const bool mfma = (bf || !fnssl::tune(FNSSL_TUNE_SN_SCALAR)) && (nf == 16 || nf == 64 || nf == 128);
   if (mfma) {
     const long long cus = fnssl::device_cus();
     const unsigned grid = (unsigned)(nblk < cus ? nblk : cus);
@@ -1998,7 +1999,7 @@ int fnssl_sn_mamba(const fnssl_btf_view* x, int nb, int nt, int nf, const fnssl_
   const MambaWs m = carve_mamba(static_cast<float*>(workspace), npts);
   hipStream_t s = fnssl::as_stream(stream);
   const bool bf = precision == FNSSL_PRECISION_BF16;
-  const bool mfma = bf || !getenv("FNSSL_SN_SCALAR");   // A/B (fp32 only): the scalar-operand kernels
+  const bool mfma = bf || !fnssl::tune(FNSSL_TUNE_SN_SCALAR);   // A/B (fp32 only): the scalar-operand kernels
   {
     fnssl::TimedLaunch tl("sn_mamba_in", s, 2.0 * npts * H * 2 * E);
     if (mfma) {
@@ -2100,7 +2101,7 @@ int fnssl_sn_head(const fnssl_btf_view* x, int nb, int nt2, int nfc, const float
   const long long npts = (long long)nb * nt2 * nfc;
   hipStream_t s = fnssl::as_stream(stream);
   fnssl::TimedLaunch tl("sn_head", s, 2.0 * npts * 16 * (DO * H + DO * DO));
-  if (!getenv("FNSSL_SN_SCALAR")) {
+  if (!fnssl::tune(FNSSL_TUNE_SN_SCALAR)) {
     const size_t lds = (size_t)(16 * 6 * 256 + 256) * sizeof(float);
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sn_head_mfma_kernel),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

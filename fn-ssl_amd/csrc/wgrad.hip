@@ -394,7 +394,11 @@ int fnssl_lstm_weight_grads(const fnssl_wgrad_desc* d, void* stream) {
   p.mtiles = p.M / kTM;
   p.ntiles = p.nt0 + p.nt2 + p.nth;
   p.slabs = plan_slabs(p.rows, p.mtiles, p.ntiles, &p.rows_per_slab);
-  p.timed = getenv("FNSSL_WGRAD_TIMED") != nullptr;
+#ifdef FNSSL_BUILD_ABLATE
+  p.timed = getenv("FNSSL_WGRAD_TIMED") != nullptr;   // per-phase cycle counters: make ABLATE=1 only
+#else
+  p.timed = false;
+#endif
   const size_t need = fnssl_lstm_weight_grads_workspace_bytes(p.rows, H, nd, d->c0, d->c2);
   if (!d->workspace || d->workspace_bytes < need) {
     fnssl::set_error("lstm_weight_grads: workspace %zu < %zu bytes", d->workspace_bytes, need);

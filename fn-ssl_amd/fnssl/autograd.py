@@ -257,12 +257,8 @@ class FNblockTrainFunction(torch.autograd.Function):
                     train.combine(dfb, plain=du)                                               # through x + fb_skip
                     du = (dfb,)
                 if ctx.needs_input_grad[0]:
-                    if len(dv) + len(du) > 3:
-                        s = torch.empty((nb, nt, nf, CH), dtype=torch.float32, device=dev)
-                        train.combine(s, plain=du)
-                        du = (s,)
                     dx = torch.empty((nb, nt, nf, CH), dtype=torch.float32, device=dev)
-                    train.combine(dx, plain=dv + du)                                           # both uses of x
+                    train.combine(dx, masked=dv, plain=du)       # both uses of x (no seed: the "masked" slots are plain sums)
                 if dfb is not None:
                     dfb = dfb.view(nb * nt, nf, CH)
         ctx.saved = ctx.bw = None

@@ -16,6 +16,9 @@
  *   - return 0 on success, <0 on error (FNSSL_E_*); `fnssl_last_error()` gives
  *     a thread-local message.  Nothing throws across the ABI;
  *   - thread-safe for concurrent calls on distinct streams; one process per GPU.
+ *   - the library reads NO environment variable: kernel-family overrides, A/B knobs and the fault-injection
+ *     hook travel in a caller-owned `fnssl_tuning` (below) — per calling thread, or per call through the
+ *     `tuning` field of the LSTM / network descriptors.
  *   - "pack" functions are host-only (no GPU needed) and write HOST memory.
  */
 #ifndef FNSSL_H_
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 17
+#define FNSSL_ABI_VERSION 18
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -45,6 +48,65 @@ extern "C" {
 
 int fnssl_abi_version(void);
 const char* fnssl_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Tuning: explicit and caller-owned (the library reads no environment)       */
+/* ------------------------------------------------------------------------- */
+
+/* Knob indices.  0 is every knob's default; all of them select between kernels that produce the SAME bits
+ * (A/B references, launch geometries) except the fault-injection hook, which the fallback tests use. */
+#define FNSSL_TUNE_LSTM_NO_STATIC 0           /* per-wave LSTM rounds: the generic run-time-loop kernels instead of the shape-specialised ones */
+#define FNSSL_TUNE_NO_STATIC3 1               /* H = 256 narrow-band layers: the two-slice kernel (lstm_static2.h) instead of the operand-ring kernel */
+#define FNSSL_TUNE_NO_STATIC2 2               /* ... and the one-slice kernel (lstm_static.h) instead of lstm_static2.h */
+#define FNSSL_TUNE_NO_STATIC_IPDNET 3         /* IPDnet layer shapes on the generic kernels */
+#define FNSSL_TUNE_LSTM_SPLIT 4               /* 1 / 2 / 4: force the waves-per-group split of small launches */
+#define FNSSL_TUNE_SPLIT4_MAX_H256 5          /* largest groups-per-CU count that still takes 4 waves per group at H = 256 (default 6) */
+#define FNSSL_TUNE_LSTM_VARIANT_H128 6        /* force a launch geometry (kernel variants) for H = 128 */
+#define FNSSL_TUNE_LSTM_VARIANT_H256 7        /* ... for H = 256 */
+#define FNSSL_TUNE_LSTM_CHQ 8                 /* force the weight-ring chunk (quads) */
+#define FNSSL_TUNE_NO_F32_CLUSTER 9           /* H = 128 full-band layers on the per-wave rounds instead of the cluster-resident kernel (lstm_f32c.h) */
+#define FNSSL_TUNE_NO_F32C_B1 10              /* ... block 1's layer only */
+#define FNSSL_TUNE_TRAIN_NO_F32_CLUSTER 11    /* ... the training forward only */
+#define FNSSL_TUNE_F32C_NO_ROTATE 12          /* cluster kernel: leftover groups stay with one wave */
+#define FNSSL_TUNE_F32C_PRIO 13               /* 9 = no issue priorities in the cluster kernel */
+#define FNSSL_TUNE_NO_CLUSTER 14              /* bf16 IPDnet layers on the pair-split kernels instead of the cluster-resident ones (lstm_bf16c.h) */
+#define FNSSL_TUNE_NO_CLUSTER_B1 15           /* ... block 1's narrow-band layer only */
+#define FNSSL_TUNE_NO_CLUSTER_H128 16         /* ... the H = 128 layers only */
+#define FNSSL_TUNE_CLUSTER_SPREAD 17          /* members of a bf16 cluster on different XCDs (placement is speed only) */
+#define FNSSL_TUNE_BF16P_DRAIN 18             /* pair-split bf16 kernels: drained ring barriers on every shape */
+#define FNSSL_TUNE_BF16W_SOLO 19              /* wide bf16 layers: one wave per group instead of the pair split */
+#define FNSSL_TUNE_BWD_NO_CLUSTER 20          /* H = 128 BPTT on the split kernels instead of the cluster-resident kernel (lstm_bwdc.h) */
+#define FNSSL_TUNE_BWD_CLUSTER_MIN_GROUPS 21  /* smallest groups-per-cluster count the cluster BPTT takes (default 8) */
+#define FNSSL_TUNE_BWD_CLUSTER_NO_ROTATE 22   /* cluster BPTT: leftover groups stay with one wave */
+#define FNSSL_TUNE_BWDC_NO_PREFETCH 23        /* cluster BPTT: phase-A operands requested in their own group-step */
+#define FNSSL_TUNE_BWDC_NO_TOKEN 24           /* cluster BPTT: no per-SIMD matrix-phase token */
+#define FNSSL_TUNE_BWDC_WAVES16 25            /* cluster BPTT: the 16-wave / 4-deep-ring shape */
+#define FNSSL_TUNE_FWD_RING 26                /* training forward, 4 waves per group: weights through the LDS ring instead of direct streams */
+#define FNSSL_TUNE_BWD_RING 27                /* BPTT, 4 waves per group: the same */
+#define FNSSL_TUNE_TRAIN_SPLIT 28             /* 1 / 2 / 4: force the waves-per-group split of the training kernels */
+#define FNSSL_TUNE_TRAIN_NO_STATIC 29         /* training forward on the generic kernels */
+#define FNSSL_TUNE_NO_FWD2 30                 /* narrow-band training forward: 4 waves per group instead of two groups per wave set (lstm_fwd2.h) */
+#define FNSSL_TUNE_NO_BWD2 31                 /* narrow-band BPTT: the same (lstm_bwd2.h) */
+#define FNSSL_TUNE_SN_SCALAR 32               /* IPDnet2 fp32: scalar-operand kernels instead of the matrix-pipe ones */
+#define FNSSL_TUNE_STFT_PER_FRAME 33          /* front end: one wave per frame instead of the persistent row kernel */
+#define FNSSL_TUNE_CLUSTER_SPIN_LIMIT 34      /* bounded-wait length of the cluster kernels' hand-offs (default 2^20 spins, about 1.5 s) */
+#define FNSSL_TUNE_CLUSTER_TEST_STALL 35      /* FAULT INJECTION: m + 1 = member m of cluster 0 never shows up (the give-up / guarded-fallback tests) */
+#define FNSSL_TUNE_RESERVED_CUS 36            /* compute units the caller keeps busy with other work (RCCL's all-reduce kernels under an overlapped backward): the cluster-resident kernels size their co-resident grids for device CUs minus this */
+#define FNSSL_TUNE_NO_F32_SMALL 37            /* few-sequence fp32 launches (one utterance, a streaming chunk) on the split kernels instead of the slice-resident cluster kernel (lstm_f32s.h) */
+#define FNSSL_TUNE_COUNT 48               /* room for more without changing the struct */
+
+typedef struct fnssl_tuning {
+  unsigned struct_bytes;                 /* sizeof(fnssl_tuning) of the caller's build */
+  int knob[FNSSL_TUNE_COUNT];
+} fnssl_tuning;
+
+/* The calling THREAD's tuning (copied; NULL = all defaults).  Calls made by this thread use it unless their
+ * descriptor carries its own.  Nothing is shared between threads. */
+int fnssl_tuning_set(const fnssl_tuning* t);
+int fnssl_tuning_get(fnssl_tuning* t);
+/* Name of knob `index` ("NO_STATIC3", ...; NULL past the last): lets a host binding map its own configuration
+ * source onto the indices (fnssl/_lib.py maps FNSSL_<name> environment variables, on the Python side). */
+const char* fnssl_tuning_name(int index);
 
 /* ------------------------------------------------------------------------- */
 /* Front end                                                                 */
@@ -169,6 +231,8 @@ typedef struct {
    * cluster-resident kernel gave up on a hand-off and was re-run by the per-wave / pair-split kernels (see
    * fnssl_lstm_forward).  Read it asynchronously whenever convenient: results are correct either way.      */
   unsigned* fallback_count;
+  /* optional per-call tuning (NULL: the calling thread's, fnssl_tuning_set) */
+  const fnssl_tuning* tuning;
 } fnssl_lstm_desc;
 
 #define FNSSL_PRECISION_FP32 0
@@ -288,6 +352,11 @@ typedef struct {
   const float* wpack_bwd[2];
   void* workspace;
   size_t workspace_bytes;
+  /* optional DEVICE counter (caller-owned, caller-zeroed; NULL to disable): incremented once per call whose
+   * cluster-resident BPTT kernel gave up on a hand-off and was re-run by the split kernels of the same call */
+  unsigned* fallback_count;
+  /* optional per-call tuning (NULL: the calling thread's, fnssl_tuning_set) */
+  const fnssl_tuning* tuning;
 } fnssl_lstm_bwd_desc;
 
 int fnssl_lstm_backward(const fnssl_lstm_bwd_desc* d, void* stream);
@@ -568,6 +637,7 @@ typedef struct {
   int input_size;         /* 4                                      */
   int is_online;          /* narrow-band: 1 = uni-dir H=256, 0 = bi-dir H=128 */
   unsigned* fallback_count;   /* optional DEVICE counter handed to every layer (fnssl_lstm_desc.fallback_count); NULL: none */
+  const fnssl_tuning* tuning; /* optional per-call tuning handed to every layer (NULL: the calling thread's) */
 } fnssl_net;
 
 size_t fnssl_forward_workspace_bytes(int nb, int nf, int nt, int is_online, int chunk_pairs);

@@ -80,8 +80,8 @@ def test_train_mode_forward_backward_adam_reproduce_the_reference_golden(dev, ca
     assert in_batch.grad is None                                  # documented: the feature gradient is not produced
     want_loss, grads, new_sd, _, want_pred = T.train_step(sd, x, gt, seed, 256, bool(online))
     assert_close(pred.detach().cpu().numpy(), want_pred, 1e-4, 1e-5, "train-mode forward (dropout on)")
-    assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss)
-    assert abs(float(loss) - float(g["c%d_loss" % case])) <= 1e-5 * abs(want_loss)
+    assert abs(float(loss.detach()) - want_loss) <= 1e-5 * abs(want_loss)
+    assert abs(float(loss.detach()) - float(g["c%d_loss" % case])) <= 1e-5 * abs(want_loss)
     names = [str(s) for s in g["c%d_names" % case]]
     got = {k: p.grad for k, p in net.named_parameters()}
     assert names == list(got.keys())
@@ -125,7 +125,7 @@ def test_autograd_route_equals_fused_engine(dev):
         loss = ps._MSELoss.apply(net_a(to_dev(x, dev)), to_dev(gt, dev))
         loss.backward()
         assert net_a.last_dropout_base == ag.base_seed(7, step) == eng.last_seed
-        assert abs(float(loss) - le) <= 1e-6 * abs(le)
+        assert abs(float(loss.detach()) - le) <= 1e-6 * abs(le)
         ge = eng.gradients()
         for k, p in net_a.named_parameters():
             if step == 1:

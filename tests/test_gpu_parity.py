@@ -360,9 +360,13 @@ def test_fnssl_block_by_block_equals_fused(dev):
 def test_fnssl_requires_eval_and_device(dev):
     import Model as at_model
     net = at_model.FN_SSL().to(dev)
+    # train mode (a fresh nn.Module's default) = the autograd route (tests/test_gpu_autograd.py); the streaming entry is
+    # inference only
+    assert net(torch.zeros(1, 4, 16, 12, device=dev)).grad_fn is not None
     with pytest.raises(RuntimeError, match="eval"):
-        net(torch.zeros(1, 4, 16, 12, device=dev))
+        net.forward_stream(torch.zeros(1, 4, 16, 12, device=dev))
     net.eval()
+    assert net(torch.zeros(1, 4, 16, 12, device=dev)).grad_fn is None
     with pytest.raises(RuntimeError, match="ROCm device tensor"):
         net(torch.zeros(1, 4, 16, 12))
     with pytest.raises(RuntimeError, match="expected"):

@@ -122,6 +122,7 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
       d.workspace = lws;
       d.workspace_bytes = pl.lstm_ws;
       d.fallback_count = net->fallback_count;
+      d.tuning = net->tuning;
       int rc = fnssl_lstm_forward(&d, stream);
       if (rc != FNSSL_OK) return rc;
       // ---- narrow-band LSTM over time, one sequence per (pair, bin) ------------
@@ -152,6 +153,7 @@ int fnssl_forward(const fnssl_net* net, const float* x0, int nb, int nf, int nt,
       e.workspace = lws;
       e.workspace_bytes = pl.lstm_ws;
       e.fallback_count = net->fallback_count;
+      e.tuning = net->tuning;
       rc = fnssl_lstm_forward(&e, stream);
       if (rc != FNSSL_OK) return rc;
     }

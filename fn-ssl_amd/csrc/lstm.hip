@@ -230,6 +230,7 @@ int fnssl_lstm_cluster_status(const void* workspace, size_t workspace_bytes, int
 // the kernel family and its number of launches
 static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, int* family, int* rounds) {
   FNSSL_REQUIRE(d, "lstm_forward: null descriptor");
+  fnssl::TuningScope tuning_of_this_call(d->tuning);
   const int H = d->hidden;
   FNSSL_REQUIRE(H == 16 || H == 32 || H == 64 || H == 128 || H == 256,
                 "lstm_forward: hidden size %d unsupported (16/32/64/128/256)", H);

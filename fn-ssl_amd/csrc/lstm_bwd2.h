@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kXsBytes = G * NVB * 1024;
   if (p.guard && __hip_atomic_load(p.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // uniform for the grid
+  if (p.guard && p.fallback_count && blockIdx.x == 0 && threadIdx.x == 0 && p.task0 == 0) atomicAdd(p.fallback_count, 1u);
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, g4 = lane >> 4;
   const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -339,10 +339,17 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
     // three times as long — and then stood in their memory round trips together, the pipe idle (profiles/r04/
     // i_bwdc_phase_times*: matrix phase 45 k cycles for 16.4 k of MFMAs, 30 k cycles of waits per group-step on top).
     // With the token a wave's matrix phase runs alone at the pipe's rate and the others' waits hide behind it.
+    bool owned = false;    // a wave that runs out of its wait (or sees the launch aborting) goes on WITHOUT the token and must
+                           // not release one another wave holds
     if (cp.simd_token) {   // (two waves per SIMD at a time, as a counting semaphore: 19.0 against 18.1 ms)
       for (unsigned spins = 0; spins < cp.spin_limit; ++spins) {
         const unsigned old = __hip_atomic_exchange(token, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // all lanes: one word
-        if (__builtin_amdgcn_ballot_w64(old == 0u) != 0) break;   // some lane saw it free: the wave owns it now
+        if (__builtin_amdgcn_ballot_w64(old == 0u) != 0) {   // some lane saw it free: the wave owns it now
+          owned = true;
+          break;
+        }
+        // the launch is draining (another wave gave up on a hand-off): do not sit out the whole limit
+        if ((spins & 63u) == 63u && __hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
         __builtin_amdgcn_s_sleep(2);
       }
     }
@@ -374,7 +381,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
       if constexpr (V + XD == NVB - 1) prefetch_next();   // (behind the matrix phase instead: 19.5 against 18.1 ms)
     });
     __builtin_amdgcn_s_setprio(0);
-    if (cp.simd_token) __hip_atomic_store(token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (owned) __hip_atomic_store(token, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int ob = qq * hq + 16 * m;                          // first channel of this 16-channel block
@@ -413,8 +420,9 @@ int launch_bwdc_k(const BwdParams& p, const BwdClusterParams& cp, hipStream_t st
   const size_t lds = (size_t)(4 * 128 / 16) * 4096 + 64;        // 32 quads = 128 KiB, + the SIMD tokens
   auto k = lstm_bwdc_kernel<NW_, ABLRT, XD_>;
   FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int nwg = fnssl::device_cus();
+  const int nwg = 8 * cp.clusters_per_xcd * cp.members;   // block b: XCD b & 7, index b >> 3 inside it
   if (!cluster_grid_fits(reinterpret_cast<const void*>(k), NW_ * 64, lds, nwg)) return kNoCluster;
+  if (p.dry) return FNSSL_OK;   // fnssl_lstm_backward_plan: the family is reported only after the occupancy check, like the forward's
   hipLaunchKernelGGL(k, dim3(nwg), dim3(NW_ * 64), lds, st, p, cp);
   FNSSL_CHECK_LAUNCH("lstm_bwdc_kernel");
   return FNSSL_OK;

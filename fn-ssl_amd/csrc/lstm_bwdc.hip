@@ -17,7 +17,13 @@ size_t bwdc_bytes(int nseq, int ndir) {
 // split kernels; fewer: the split kernels fill the chip better).  FNSSL_BWD_NO_CLUSTER=1 turns it off.
 bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
   if (H != 128 || fnssl::tune(FNSSL_TUNE_BWD_NO_CLUSTER)) return false;
-  const int ncu = fnssl::device_cus();
+  // the kernel's addressing (lstm_bwdc.h locate()) takes a group's first sequence as its lowest address and lets a group
+  // cross at most one outer index: the same preconditions f32c_handles() checks.  A permuted / time-major view or
+  // q_inner < 16 goes to the split kernels, whose 64-bit address search takes any layout.
+  auto grows = [&](long long so, long long si) { return si >= 0 && so >= (long long)(p.q_inner - 1) * si; };
+  if (p.q_inner < 16 || !grows(p.dh.so, p.dh.si) || !grows(p.da_so, p.da_si) || (p.c0g != 0 && !grows(p.dx_so, p.dx_si)))
+    return false;
+  const int ncu = cluster_cus();   // device CUs minus fnssl_tuning RESERVED_CUS (RCCL's kernels under an overlapped backward)
   const int per_xcd = ncu / 8;
   cp.members = p.co_pad / 64;
   if (ncu % 8 || cp.members < 1 || cp.members > 8 || cp.members > per_xcd) return false;
@@ -39,9 +45,8 @@ int backward_cluster(const BwdParams& p, BwdClusterParams cp, void* ws, hipStrea
   cp.rotate = !fnssl::tune(FNSSL_TUNE_BWD_CLUSTER_NO_ROTATE);
   cp.no_prefetch = fnssl::tune(FNSSL_TUNE_BWDC_NO_PREFETCH);
   cp.simd_token = !fnssl::tune(FNSSL_TUNE_BWDC_NO_TOKEN);
-  if (p.dry) return FNSSL_OK;
   const size_t tag_bytes = (size_t)cp.clusters_per_dir * p.ndir * cp.groups_per_cluster * 16 * sizeof(unsigned);
-  FNSSL_HIP(hipMemsetAsync(ws, 0, 256 + tag_bytes, st));
+  if (!p.dry) FNSSL_HIP(hipMemsetAsync(ws, 0, 256 + tag_bytes, st));   // (dry: the launchers stop after their occupancy check)
 #ifdef FNSSL_BUILD_ABLATE
   if ((cp.ablate = env_int("FNSSL_BWDC_ABLATE", 1, 1 << 20)) != 0) return launch_bwdc_k<kBwdcWaves, true>(p, cp, st);
 #endif

@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tuning.h"
 
 // HIP's __fadd_rn/__fmul_rn inline to plain fadd/fmul, which clang would still contract into
 // fma; every fused multiply-add in this file is written explicitly (__fmaf_rn), so turn the

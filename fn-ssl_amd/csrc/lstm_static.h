@@ -311,7 +311,7 @@ inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int g
     (void)hipGetLastError();
     return false;
   }
-  return (long long)per_cu * fnssl::device_cus() >= grid;
+  return (long long)per_cu * cluster_cus() >= grid;
 }
 inline int cluster_test_stall() { return fnssl::tune(FNSSL_TUNE_CLUSTER_TEST_STALL, 1, 1 << 20) - 1; }
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);

@@ -38,6 +38,7 @@ struct BwdParams {
   int quads_per_slice, chq, pad;
   // guarded fallback launch behind lstm_bwdc_kernel (lstm_bwdc.h): runs only if *guard != 0 (LstmParams.guard)
   const unsigned* guard = nullptr;
+  unsigned* fallback_count = nullptr;   // optional device counter: block 0 of a guarded launch that does run counts the call
   int dry = 0;                 // host only (fnssl_lstm_backward_plan): no launch
 };
 
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(NW * 64) lstm_bwd_kernel(const BwdParams p) {
   static_assert(NS % SPLIT == 0 && NW % SPLIT == 0, "split geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.guard && __hip_atomic_load(p.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // uniform for the grid
+  if (p.guard && p.fallback_count && blockIdx.x == 0 && threadIdx.x == 0 && p.task0 == 0) atomicAdd(p.fallback_count, 1u);
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

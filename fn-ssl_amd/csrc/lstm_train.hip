@@ -175,6 +175,7 @@ int fnssl_lstm_backward_status(const void* workspace, size_t workspace_bytes, in
 
 static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dry, int* family) {
   FNSSL_REQUIRE(d, "lstm_backward: null descriptor");
+  fnssl::TuningScope tuning_of_this_call(d->tuning);
   const int H = d->hidden;
   FNSSL_REQUIRE(H == 128 || H == 256, "lstm_backward: hidden size %d unsupported (128/256)", H);
   FNSSL_REQUIRE(d->ndir == 1 || d->ndir == 2, "lstm_backward: ndir must be 1 or 2");
@@ -226,6 +227,7 @@ static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dr
   p.ntasks = (d->nseq + 15) / 16;
   p.quads_per_slice = bwd_quads_per_slice(H);
   p.dry = dry;
+  p.fallback_count = d->fallback_count;
   hipStream_t st = dry ? nullptr : fnssl::as_stream(stream);
   const double flops = 2.0 * 4 * H * (double)(d->c0g + H) * d->nseq * (double)d->nsteps * d->ndir;
   fnssl::TimedLaunch tl(dry ? nullptr : H == 128 ? "lstm_bwd_h128" : "lstm_bwd_h256", st, flops);

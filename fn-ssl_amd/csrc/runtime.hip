@@ -1,4 +1,5 @@
 // Error string, ABI version and the per-kernel HIP-event timing registry.
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -28,9 +29,15 @@ int device_cus() {
 
 static thread_local char g_err[512] = "";
 
-// ---- tuning: one slot per thread, plus the descriptor of the call in progress -------------------------------------
+// ---- tuning: the process default (set explicitly through the ABI, never from the environment), plus the descriptor of
+// the call in progress.  Readers work on a per-thread snapshot that is refreshed when the default's version changes, so a
+// call never takes a lock per knob and PyTorch's autograd worker threads see what the main thread set.
 namespace {
+std::mutex g_tuning_mu;
+fnssl_tuning g_default_tuning = {sizeof(fnssl_tuning), {0}};
+std::atomic<unsigned> g_tuning_version{1};
 thread_local fnssl_tuning g_thread_tuning = {sizeof(fnssl_tuning), {0}};
+thread_local unsigned g_thread_version = 0;
 thread_local const fnssl_tuning* g_call_tuning = nullptr;
 const char* const kTuneNames[] = {
     "LSTM_NO_STATIC",
@@ -76,7 +83,16 @@ static_assert(kTuneNamed <= FNSSL_TUNE_COUNT, "more knob names than slots");
 static_assert(kTuneNamed == FNSSL_TUNE_NO_F32_SMALL + 1, "knob names out of step with include/fnssl.h");
 }  // namespace
 
-const fnssl_tuning& tuning() { return g_call_tuning ? *g_call_tuning : g_thread_tuning; }
+const fnssl_tuning& tuning() {
+  if (g_call_tuning) return *g_call_tuning;
+  const unsigned v = g_tuning_version.load(std::memory_order_acquire);
+  if (v != g_thread_version) {
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    g_thread_tuning = g_default_tuning;
+    g_thread_version = g_tuning_version.load(std::memory_order_relaxed);
+  }
+  return g_thread_tuning;
+}
 
 TuningScope::TuningScope(const fnssl_tuning* t) : prev_(g_call_tuning), active_(false) {
   if (t && t->struct_bytes == sizeof(fnssl_tuning)) {
@@ -133,19 +149,47 @@ TimedLaunch::~TimedLaunch() {
 }  // namespace fnssl
 
 extern "C" int fnssl_tuning_set(const fnssl_tuning* t) {
-  if (!t) {
-    fnssl::g_thread_tuning = fnssl_tuning{sizeof(fnssl_tuning), {0}};
-    return FNSSL_OK;
-  }
-  FNSSL_REQUIRE(t->struct_bytes == sizeof(fnssl_tuning), "tuning_set: struct_bytes %u, this library's fnssl_tuning has %zu",
-                t->struct_bytes, sizeof(fnssl_tuning));
-  fnssl::g_thread_tuning = *t;
+  FNSSL_REQUIRE(!t || t->struct_bytes == sizeof(fnssl_tuning), "tuning_set: struct_bytes %u, this library's fnssl_tuning has %zu",
+                t ? t->struct_bytes : 0u, sizeof(fnssl_tuning));
+  std::lock_guard<std::mutex> lk(fnssl::g_tuning_mu);
+  fnssl::g_default_tuning = t ? *t : fnssl_tuning{sizeof(fnssl_tuning), {0}};
+  fnssl::g_tuning_version.fetch_add(1, std::memory_order_release);
   return FNSSL_OK;
 }
 
 extern "C" int fnssl_tuning_get(fnssl_tuning* t) {
   FNSSL_REQUIRE(t != nullptr, "tuning_get: NULL");
-  *t = fnssl::g_thread_tuning;
+  std::lock_guard<std::mutex> lk(fnssl::g_tuning_mu);
+  *t = fnssl::g_default_tuning;
+  return FNSSL_OK;
+}
+
+namespace {
+// What another tenant's persistent kernels do to the CUs (RCCL's all-reduce kernels under an overlapped backward): each
+// workgroup claims `lds` bytes of LDS (160 KiB = the whole CU) and idles until *stop != 0 or the time limit.
+__global__ void __launch_bounds__(64) occupy_kernel(const unsigned* stop, long long max_ticks) {
+  extern __shared__ char occ_smem[];
+  if (threadIdx.x == 0) occ_smem[0] = 1;   // the allocation is real
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < max_ticks) {
+    if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
+}
+}  // namespace
+
+extern "C" int fnssl_occupy_cus(int nblocks, int lds_bytes, const unsigned* stop, int max_ms, void* stream) {
+  FNSSL_REQUIRE(nblocks > 0 && nblocks <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && max_ms > 0 && max_ms <= 60000,
+                "occupy_cus: nblocks %d, lds %d B, limit %d ms", nblocks, lds_bytes, max_ms);
+  if (lds_bytes > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  int rate_khz = 100000;   // wall_clock64 ticks: the constant "wall clock" counter, 100 MHz on gfx9
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev);
+  if (rate_khz <= 0) rate_khz = 100000;
+  hipLaunchKernelGGL(occupy_kernel, dim3(nblocks), dim3(64), (size_t)lds_bytes, fnssl::as_stream(stream), stop,
+                     (long long)max_ms * rate_khz);
+  FNSSL_CHECK_LAUNCH("occupy_kernel");
   return FNSSL_OK;
 }
 

@@ -1,13 +1,13 @@
 // The caller-owned tuning (include/fnssl.h: fnssl_tuning) as the kernels' host code sees it.  The library reads no
-// environment variable: every knob comes from the calling thread's slot (fnssl_tuning_set) or from the descriptor of
-// the call in progress (TuningScope).  Timing-ablation knobs exist only in `make ABLATE=1` builds and stay there.
+// environment variable: every knob comes from the process default (fnssl_tuning_set) or from the descriptor of the
+// call in progress (TuningScope).  Timing-ablation knobs exist only in `make ABLATE=1` builds and stay there.
 #pragma once
 
 #include "../../include/fnssl.h"
 
 namespace fnssl {
 
-const fnssl_tuning& tuning();   // the call's (innermost TuningScope) or else the thread's
+const fnssl_tuning& tuning();   // the call's (innermost TuningScope) or else this thread's snapshot of the process default
 
 // knob value, 0 = default
 inline int tune(int index) { return tuning().knob[index]; }

@@ -8,6 +8,15 @@ verifies that exactly one HIP runtime is mapped.
 
 There is no fallback: if the shared object is missing this raises, and every
 op in ``fnssl.ops`` refuses non-ROCm tensors.
+
+Tuning.  The library reads no environment variable; kernel-family overrides and
+A/B knobs travel in a caller-owned ``fnssl_tuning`` (include/fnssl.h).  This
+binding is where ``FNSSL_<KNOB>`` environment variables are parsed — ONCE, when
+the library is loaded, and again whenever ``refresh_tuning()`` is called (the
+A/B legs of bench.py and the tests call it after changing ``os.environ``) — and
+handed to the library with ``fnssl_tuning_set`` (the process default).
+``tuning(**knobs)`` is the explicit form: a context manager that sets knobs for
+the calls made inside it.
 """
 from __future__ import annotations
 
@@ -22,7 +31,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 # `make ABLATE=1` build with the timing-ablation twins) — never a different implementation, never a fallback
 LIB_PATH = os.environ.get("FNSSL_LIB_PATH", LIB_PATH)
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 CH_MODE = {"M": 0, "MM": 1}
 # kernel families fnssl_lstm_plan reports (include/fnssl.h: FNSSL_LSTM_FAMILY_*)
 LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2", 4: "split", 5: "split_static", 6: "f32_cluster",
@@ -30,7 +39,7 @@ LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2", 4: "split", 5: "split_st
 
 # every symbol include/fnssl.h declares
 SYMBOLS = [
-    "fnssl_abi_version", "fnssl_last_error", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
+    "fnssl_abi_version", "fnssl_last_error", "fnssl_tuning_set", "fnssl_tuning_get", "fnssl_tuning_name", "fnssl_occupy_cus", "fnssl_num_frames", "fnssl_num_pairs", "fnssl_stft",
     "fnssl_num_frames_ex", "fnssl_stft_ex", "fnssl_array_frontend",
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_workspace_bytes_ex", "fnssl_lstm_plan_rounds", "fnssl_lstm_plan", "fnssl_lstm_forward", "fnssl_lstm_cluster_status", "fnssl_head", "fnssl_linear",
@@ -50,6 +59,14 @@ SYMBOLS = [
     "fnssl_sn_layernorm", "fnssl_sn_encoder", "fnssl_sn_fconv", "fnssl_sn_full", "fnssl_sn_mamba_workspace_bytes",
     "fnssl_sn_mamba", "fnssl_sn_head", "fnssl_sn_forward_workspace_bytes", "fnssl_sn_state_floats", "fnssl_sn_forward",
 ]
+
+
+TUNE_COUNT = 48
+
+
+class Tuning(C.Structure):
+    """fnssl_tuning: knob[i] = 0 is every knob's default (names: ``tuning_names()``)."""
+    _fields_ = [("struct_bytes", C.c_uint), ("knob", C.c_int * TUNE_COUNT)]
 
 
 class View(C.Structure):
@@ -72,6 +89,7 @@ class LstmDesc(C.Structure):
         ("precision", C.c_int),
         ("f32_mask", C.c_int),
         ("fallback_count", C.c_void_p),
+        ("tuning", C.POINTER(Tuning)),
     ]
 
 
@@ -85,6 +103,8 @@ class LstmBwdDesc(C.Structure):
         ("hidden", C.c_int), ("ndir", C.c_int), ("nseq", C.c_int), ("q_inner", C.c_int), ("nsteps", C.c_int),
         ("wpack_bwd", C.c_void_p * 2),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("fallback_count", C.c_void_p),
+        ("tuning", C.POINTER(Tuning)),
     ]
 
 
@@ -107,6 +127,7 @@ class Net(C.Structure):
         ("doa_wt", C.c_void_p), ("doa_b", C.c_void_p),
         ("input_size", C.c_int), ("is_online", C.c_int),
         ("fallback_count", C.c_void_p),
+        ("tuning", C.POINTER(Tuning)),
     ]
 
 
@@ -169,6 +190,11 @@ def load():
     vp, i, ll, sz, f = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_float
     lib.fnssl_abi_version.restype = i
     lib.fnssl_last_error.restype = C.c_char_p
+    lib.fnssl_tuning_set.argtypes = [C.POINTER(Tuning)]
+    lib.fnssl_tuning_get.argtypes = [C.POINTER(Tuning)]
+    lib.fnssl_tuning_name.argtypes = [i]
+    lib.fnssl_tuning_name.restype = C.c_char_p
+    lib.fnssl_occupy_cus.argtypes = [i, i, vp, i, vp]
     lib.fnssl_num_frames.argtypes = [i]
     lib.fnssl_num_pairs.argtypes = [i, i]
     lib.fnssl_stft.argtypes = [vp, i, i, i, ll, ll, ll, vp, vp, vp]
@@ -274,7 +300,104 @@ def load():
         raise RuntimeError("fnssl: ABI version mismatch (library %d, binding %d)"
                            % (lib.fnssl_abi_version(), ABI_VERSION))
     _lib = lib
+    refresh_tuning()
     return lib
+
+
+# --------------------------------------------------------------------------- #
+# tuning: FNSSL_<KNOB> environment variables are a PYTHON-side convenience
+# --------------------------------------------------------------------------- #
+_tune_index = None
+# knobs the old getenv()-style switches treated as "set = on" whatever the value
+_PRESENCE = {"NO_F32_CLUSTER", "NO_F32C_B1", "TRAIN_NO_F32_CLUSTER", "F32C_NO_ROTATE", "NO_CLUSTER", "NO_CLUSTER_B1",
+             "NO_CLUSTER_H128", "CLUSTER_SPREAD", "BF16W_SOLO", "SN_SCALAR", "STFT_PER_FRAME"}
+# knobs whose environment spelling differs from FNSSL_<name>
+_ENV_ALIAS = {"LSTM_NO_STATIC": "FNSSL_LSTM_NO_STATIC"}
+
+
+def tuning_names():
+    """knob name -> index, as the loaded library reports them (fnssl_tuning_name)."""
+    global _tune_index
+    if _tune_index is None:
+        lib = _lib
+        if lib is None:
+            raise RuntimeError("fnssl: load() first")
+        idx, k = {}, 0
+        while True:
+            n = lib.fnssl_tuning_name(k)
+            if n is None:
+                break
+            idx[n.decode()] = k
+            k += 1
+        _tune_index = idx
+    return _tune_index
+
+
+def tuning_from_env(environ=None) -> Tuning:
+    """The Tuning an environment describes: FNSSL_<KNOB>=<int> (flags: any value / "1")."""
+    environ = os.environ if environ is None else environ
+    t = Tuning()
+    t.struct_bytes = C.sizeof(Tuning)
+    for name, k in tuning_names().items():
+        v = environ.get(_ENV_ALIAS.get(name, "FNSSL_" + name))
+        if v is None:
+            continue
+        try:
+            iv = int(v)
+        except ValueError:
+            iv = 1
+        if name in _PRESENCE:
+            iv = 1
+        if name == "CLUSTER_TEST_STALL":
+            iv = iv + 1 if iv >= 0 else 0          # the knob stores member + 1 (0 = no fault injection)
+        t.knob[k] = iv
+    return t
+
+
+def refresh_tuning(environ=None):
+    """Re-read the FNSSL_* environment variables into the library's default tuning (fnssl_tuning_set)."""
+    if _lib is None:
+        return
+    t = tuning_from_env(environ)
+    if _lib.fnssl_tuning_set(C.byref(t)) != 0:
+        raise RuntimeError("fnssl: tuning_set failed: %s" % _lib.fnssl_last_error().decode("utf-8", "replace"))
+
+
+def make_tuning(base: Tuning = None, **knobs) -> Tuning:
+    """A Tuning with the given knobs (lower- or upper-case names) on top of ``base`` (default: the thread's current)."""
+    load()
+    t = Tuning()
+    if base is None:
+        _lib.fnssl_tuning_get(C.byref(t))
+    else:
+        C.memmove(C.byref(t), C.byref(base), C.sizeof(Tuning))
+    t.struct_bytes = C.sizeof(Tuning)
+    names = tuning_names()
+    for k, v in knobs.items():
+        if k.upper() not in names:
+            raise KeyError("fnssl: unknown tuning knob %r (known: %s)" % (k, ", ".join(sorted(names))))
+        t.knob[names[k.upper()]] = int(v)
+    return t
+
+
+class tuning:
+    """``with _lib.tuning(no_static3=1, cluster_spin_limit=20000): ...`` — the calls inside the block use
+    these knobs on top of the current ones; the previous tuning is restored on exit."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        load()
+        self.prev = Tuning()
+        _lib.fnssl_tuning_get(C.byref(self.prev))
+        t = make_tuning(self.prev, **self.knobs)
+        check(_lib.fnssl_tuning_set(C.byref(t)), "tuning_set")
+        return t
+
+    def __exit__(self, *exc):
+        _lib.fnssl_tuning_set(C.byref(self.prev))
+        return False
 
 
 def check(rc: int, what: str = ""):

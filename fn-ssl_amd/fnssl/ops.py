@@ -318,6 +318,33 @@ def _conform(t):
 
 
 _ws_cache = {}
+_fb_counters = {}
+
+
+def fallback_counter(device):
+    """The per-device int32 counter every LSTM call of this binding hands to the library unless the caller passes its own
+    (fnssl_lstm_desc.fallback_count / fnssl_lstm_bwd_desc.fallback_count): launches whose cluster-resident kernel gave up on
+    a hand-off and were recomputed by the guarded fallback kernels of the same call.  Results are correct either way; a
+    non-zero count means the device could not keep a cluster's member workgroups resident (shared, partitioned or busy
+    device) and throughput numbers taken meanwhile are not the kernels'."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    c = _fb_counters.get(device.index)
+    if c is None:
+        c = torch.zeros(1, dtype=torch.int32, device=device)
+        _fb_counters[device.index] = c
+    return c
+
+
+def cluster_fallbacks(device=None, reset: bool = False) -> int:
+    """Value of ``fallback_counter(device)`` (SYNCHRONISES the device: measurement code calls it outside timed regions)."""
+    c = fallback_counter(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    n = int(c.item())
+    if reset:
+        c.zero_()
+    return n
+
 
 
 def _workspace(nbytes: int, device, tag: str):
@@ -342,12 +369,14 @@ def release_workspaces():
 
 @on_device
 def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0, skip=None, out_sum=None,
-               reserve=None, carry_workspace=None, carry=False, bf16=False, wide=False, fallback_count=None, plan_only=False):
+               reserve=None, carry_workspace=None, carry=False, bf16=False, wide=False, fallback_count=None, plan_only=False,
+               tuning=None):
     """One (bi)LSTM layer over strided views.
 
     ``fallback_count`` (optional 1-element int32 device tensor, caller-zeroed): counts the layers whose cluster-resident
     kernel gave up on a hand-off and were recomputed by the guarded fallback kernels of the same call (results are
-    correct either way).  ``plan_only=True`` launches nothing and returns ``(family, rounds)`` — the kernel family
+    correct either way).  ``tuning`` (a ``_lib.Tuning``, e.g. ``_lib.make_tuning(reserved_cus=16)``): this call's knobs
+    instead of the process default (fnssl_lstm_desc.tuning).  ``plan_only=True`` launches nothing and returns ``(family, rounds)`` — the kernel family
     ``fnssl_lstm_forward`` takes for exactly this call (``_lib.LSTM_FAMILY`` names), see ``lstm_plan``.
 
     mode 'full': sequences are (b, t) rows, steps run over f; 'narrow': sequences (b, f), steps over t.
@@ -434,11 +463,14 @@ def lstm_layer(mode: str, x0, x1, x2, packed, hidden: int, out, variant: int = 0
     if reserve is not None:
         _need_dev(reserve)
         d.reserve, d.reserve_bytes = reserve.data_ptr(), reserve.numel() * 4
-    if fallback_count is not None:
-        if not isinstance(fallback_count, torch.Tensor) or not fallback_count.is_cuda or fallback_count.dtype != torch.int32 \
-                or fallback_count.numel() < 1:
-            raise RuntimeError("fnssl.lstm_layer: fallback_count must be an int32 device tensor")
-        d.fallback_count = fallback_count.data_ptr()
+    if fallback_count is None:
+        fallback_count = fallback_counter(out.device)
+    if not isinstance(fallback_count, torch.Tensor) or not fallback_count.is_cuda or fallback_count.dtype != torch.int32 \
+            or fallback_count.numel() < 1:
+        raise RuntimeError("fnssl.lstm_layer: fallback_count must be an int32 device tensor")
+    d.fallback_count = fallback_count.data_ptr()
+    if tuning is not None:
+        d.tuning = C.pointer(tuning)
     if plan_only:
         fam, rounds = C.c_int(0), C.c_int(0)
         check(lib.fnssl_lstm_plan(C.byref(d), C.byref(fam), C.byref(rounds)), "lstm_plan")
@@ -515,13 +547,15 @@ def pack_lstm_bwd_host(w_ih, w_hh, c0g: int) -> np.ndarray:
 
 @on_device
 def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: int, plan_only: bool = False,
-                  status: bool = False):
+                  status: bool = False, fallback_count=None, tuning=None):
     """Back-propagation through time of one (bi)LSTM layer.
 
     dh: upstream gradient, logical [nb, nt, nf, ndir*hidden]; da (written): logical [nb, nt, nf, ndir*4*hidden]
     pre-activation gate gradients; dx (written, or None when c0g == 0): logical [nb, nt, nf, ndir*c0g], one slab
     per direction.  ``mode`` as in lstm_layer.  ``plan_only``: launch nothing, return the kernel family name the call
-    would take (fnssl_lstm_backward_plan); ``status``: also return the cluster kernel's status word (synchronises)."""
+    would take (fnssl_lstm_backward_plan); ``status``: also return the cluster kernel's status word (synchronises).
+    ``fallback_count`` (int32 device tensor, caller-zeroed): incremented when the cluster-resident BPTT kernel gave up on a
+    hand-off and the split kernels of the same call recomputed the layer; ``tuning``: this call's knobs (a ``_lib.Tuning``)."""
     _need_dev(reserve, dh, da, dx, *packed_bwd)
     ndir = len(packed_bwd)
     nb, nt, nf = dh.shape[:3]
@@ -549,6 +583,13 @@ def lstm_backward(mode: str, reserve, dh, da, dx, packed_bwd, hidden: int, c0g: 
     lib = _lib.load()
     ws = _workspace(lib.fnssl_lstm_bwd_workspace_bytes(d.nseq, hidden, ndir), dh.device, "lstm_bwd")
     d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    if fallback_count is None:
+        fallback_count = fallback_counter(dh.device)
+    if not isinstance(fallback_count, torch.Tensor) or not fallback_count.is_cuda or fallback_count.dtype != torch.int32:
+        raise RuntimeError("fnssl.lstm_backward: fallback_count must be an int32 device tensor")
+    d.fallback_count = fallback_count.data_ptr()
+    if tuning is not None:
+        d.tuning = C.pointer(tuning)
     if plan_only:
         fam = C.c_int(0)
         check(lib.fnssl_lstm_backward_plan(C.byref(d), C.byref(fam)), "lstm_backward_plan")
@@ -779,7 +820,7 @@ class DeviceNet:
         # layers whose cluster-resident kernel gave up on a hand-off and were recomputed by the guarded fallback kernels of
         # the same call (fnssl_lstm_forward): counted on the device, read back asynchronously (4 bytes per forward, no
         # synchronisation) and reported one forward later as a RuntimeWarning — results are correct either way
-        self.fallbacks = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.fallbacks = fallback_counter(self.device) if self.device.type == "cuda" else torch.zeros(1, dtype=torch.int32)
         self._fb_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else None
         self._fb_event, self._fb_seen = None, 0
         net.fallback_count = self.fallbacks.data_ptr()
@@ -832,6 +873,16 @@ class DeviceNet:
 # --------------------------------------------------------------------------- #
 # measurement hooks
 # --------------------------------------------------------------------------- #
+@on_device
+def occupy_cus(nblocks: int, stop, max_ms: int = 2000, lds_bytes: int = 160 * 1024, stream=None):
+    """Diagnostic (fnssl_occupy_cus): ``nblocks`` workgroups, each holding ``lds_bytes`` of LDS (default: a whole CU), idle on
+    ``stream`` (default: the current one) until ``stop[0]`` (an int32 tensor in pinned host or device memory) is non-zero or
+    ``max_ms`` pass — what RCCL's persistent all-reduce kernels do to the CUs under an overlapped backward."""
+    s = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    check(_lib.load().fnssl_occupy_cus(int(nblocks), int(lds_bytes), C.c_void_p(stop.data_ptr()), int(max_ms), s), "occupy_cus")
+
+
+
 def timing_enable(on: bool):
     check(_lib.load().fnssl_timing_enable(1 if on else 0), "timing_enable")
 

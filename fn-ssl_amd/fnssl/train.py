@@ -179,8 +179,14 @@ class TrainGraph:
     gradient is ACCUMULATED into; ``layer_done(prefix)`` is called when every gradient under ``prefix`` is final.
     ``seeds``: six 32-bit dropout seeds (``layer_seed``) or None = dropout off (the eval-mode graph)."""
 
-    def __init__(self, layers, alloc):
+    def __init__(self, layers, alloc, fallbacks=None, bwd_tuning=None):
         self.layers, self.alloc = layers, alloc
+        # optional int32 device counter handed to every LSTM call: layers whose cluster-resident kernel gave up on a
+        # hand-off and were recomputed by the guarded fallback kernels of the same call (correct, but slow)
+        self.fallbacks = fallbacks
+        # optional per-call tuning of the BACKWARD's LSTM kernels (``_lib.make_tuning(reserved_cus=16)``: the compute units
+        # RCCL's all-reduce kernels hold while the BPTT of the layers below runs)
+        self.bwd_tuning = bwd_tuning
         self.Lf = [layers[0], layers[2], layers[4]]
         self.Ln = [layers[1], layers[3], layers[5]]
 
@@ -221,11 +227,12 @@ class TrainGraph:
             F[k] = self._natural("F%d" % k, lf, nbp, nt, nf, 2 * H_FULL)
             res[lf.name] = self.alloc("R" + lf.name, (ops.lstm_reserve_floats(nbp * nt, lf.hidden, 2, nf),))
             if k == 1:
-                ops.lstm_layer("full", XF, None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+                ops.lstm_layer("full", XF, None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name], fallback_count=self.fallbacks)
             else:
                 U[k] = self._natural("U%d" % k, lf, nbp, nt, nf, CH)
                 combine(U[k], plain=(Xk, F[k - 1]))                                   # x + fb_skip  (:36-37)
-                ops.lstm_layer("full", U[k], None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name])
+                ops.lstm_layer("full", U[k], None, None, fw[lf.name], lf.hidden, F[k], reserve=res[lf.name],
+                               fallback_count=self.fallbacks)
             V[k] = self._natural("V%d" % k, ln, nbp, nt, nf, CH)
             if k == 1:
                 combine(V[k], masked=(F[k],), seed32=sd(0), b0=b0)                   # dropout_full (:40)
@@ -234,7 +241,7 @@ class TrainGraph:
             N[k] = self._natural("N%d" % k, ln, nbp, nt, nf, ln.ndir * ln.hidden)
             res[ln.name] = self.alloc("R" + ln.name, (ops.lstm_reserve_floats(nbp * nf, ln.hidden, ln.ndir, nt),))
             ops.lstm_layer("narrow", V[k], None, XN if k == 1 else None, fw[ln.name], ln.hidden, N[k],
-                           reserve=res[ln.name])
+                           reserve=res[ln.name], fallback_count=self.fallbacks)
             Xk = self._natural("X", ln, nbp, nt, nf, CH)
             combine(Xk, masked=(N[k],), seed32=sd(2 * k - 1), b0=b0)                # dropout_narr (:48)
         X4 = Xk.permute(0, 2, 1, 3)                                                  # storage [b, f, t, 256]
@@ -250,6 +257,7 @@ class TrainGraph:
         sd = (lambda i: None) if seeds is None else (lambda i: seeds[i])
         XF, XN, res, U, F, V, N, X4, pred = (saved[k] for k in ("XF", "XN", "res", "U", "F", "V", "N", "X4", "pred"))
         lib = _lib.load()
+        bk = {"fallback_count": self.fallbacks, "tuning": self.bwd_tuning}
         wname, bname = "emb2ipd.weight", "emb2ipd.bias"
         ws = self.alloc("ws_small", (max(lib.fnssl_head_backward_workspace_bytes() // 4, 256),))
         G = self.alloc("G", (nbp, nf, nt, CH))                                       # dL/dX4, N storage
@@ -266,7 +274,7 @@ class TrainGraph:
             combine(DN, masked=gx, seed32=sd(2 * k - 1), b0=b0)                      # dropout_narr backward
             dA = self._natural("dA", ln, nbp, nt, nf, ln.ndir * 4 * ln.hidden)
             DV = self._natural("DV%d" % (k & 1), ln, nbp, nt, nf, ln.ndir * CH)
-            ops.lstm_backward("narrow", res[ln.name], DN, dA, DV, bw[ln.name], ln.hidden, CH)
+            ops.lstm_backward("narrow", res[ln.name], DN, dA, DV, bw[ln.name], ln.hidden, CH, **bk)
             self._weight_grads(ln, dA, V[k], XN if k == 1 else None, N[k], gview, layer_done)
             dv = tuple(DV[..., d * CH:(d + 1) * CH] for d in range(ln.ndir))        # one slab per direction
             DF = self._natural("DF", lf, nbp, nt, nf, 2 * H_FULL)
@@ -274,7 +282,7 @@ class TrainGraph:
             dA = self._natural("dA", lf, nbp, nt, nf, 2 * 4 * H_FULL)
             if k > 1:
                 DU = self._natural("DU%d" % (k & 1), lf, nbp, nt, nf, 2 * CH)
-                ops.lstm_backward("full", res[lf.name], DF, dA, DU, bw[lf.name], lf.hidden, CH)
+                ops.lstm_backward("full", res[lf.name], DF, dA, DU, bw[lf.name], lf.hidden, CH, **bk)
                 self._weight_grads(lf, dA, U[k], None, F[k], gview, layer_done)
                 du = (DU[..., :CH], DU[..., CH:])
                 if len(dv) + 2 > 3:          # offline narrow-band: 2 + 2 operands -> fold the full-band pair first
@@ -284,7 +292,7 @@ class TrainGraph:
                 gx = dv + du                 # dL/dX_k = dV_k + dU_k  (both uses of x: nb_skip and the full-band input)
                 dfb = du                     # dL/dF_{k-1} through fb_skip
             else:
-                ops.lstm_backward("full", res[lf.name], DF, dA, None, bw[lf.name], lf.hidden, 0)
+                ops.lstm_backward("full", res[lf.name], DF, dA, None, bw[lf.name], lf.hidden, 0, **bk)
                 self._weight_grads(lf, dA, XF, None, F[k], gview, layer_done)
 
 
@@ -330,6 +338,12 @@ class TrainEngine:
         self.maps = build_index_maps(self.layers, self.offset, dev)
         self.loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = {}
+        # LSTM launches (forward and backward) whose cluster-resident kernel gave up and were recomputed by the guarded
+        # fallback kernels: a device counter, never read on the step path (``cluster_fallbacks()`` synchronises)
+        self.fallbacks = ops.fallback_counter(dev)
+        # compute units RCCL's all-reduce kernels hold while the BPTT of the lower layers runs (the per-layer asynchronous
+        # all-reduce): with more than one rank the backward's cluster kernels size their co-resident grids for the rest
+        self.reserved_cus = 16
 
     # ------------------------------------------------------------------ distributed plumbing
     def _world_rank(self):
@@ -420,11 +434,22 @@ class TrainEngine:
     def _layer_done(self, prefix):
         self._reduce_async(prefix)
 
+    def _backward_tuning(self):
+        """Per-call tuning of the backward's LSTM kernels: RESERVED_CUS when gradients are all-reduced under the BPTT."""
+        world, _ = self._world_rank()
+        if world <= 1 or not self.reserved_cus:
+            return None
+        return _lib.make_tuning(reserved_cus=self.reserved_cus)      # on top of the current default knobs
+
+    def cluster_fallbacks(self) -> int:
+        """LSTM launches so far that fell back from a cluster-resident kernel to the per-wave / split kernels (synchronises)."""
+        return int(self.fallbacks.item())
+
     def _chunk(self, x, gt, b0, n_total, fw, bw, seeds):
         """Forward + loss + backward of pairs [b0, b0 + nbp) (x [nbp, 4, nf, nt]); accumulates grads and the loss."""
         nbp, _, nf, nt = x.shape
         npair = gt.shape[3]
-        graph = TrainGraph(self.layers, self._buf)
+        graph = TrainGraph(self.layers, self._buf, self.fallbacks, self._backward_tuning())
         pred, saved = graph.forward(x, fw, seeds, b0, self.pview)
         nt2 = pred.shape[1]
         lib = _lib.load()

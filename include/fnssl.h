@@ -17,8 +17,8 @@
  *     a thread-local message.  Nothing throws across the ABI;
  *   - thread-safe for concurrent calls on distinct streams; one process per GPU.
  *   - the library reads NO environment variable: kernel-family overrides, A/B knobs and the fault-injection
- *     hook travel in a caller-owned `fnssl_tuning` (below) — per calling thread, or per call through the
- *     `tuning` field of the LSTM / network descriptors.
+ *     hook travel in a caller-owned `fnssl_tuning` (below) — the process default set through
+ *     fnssl_tuning_set(), or per call through the `tuning` field of the LSTM / network descriptors.
  *   - "pack" functions are host-only (no GPU needed) and write HOST memory.
  */
 #ifndef FNSSL_H_
@@ -100,13 +100,21 @@ typedef struct fnssl_tuning {
   int knob[FNSSL_TUNE_COUNT];
 } fnssl_tuning;
 
-/* The calling THREAD's tuning (copied; NULL = all defaults).  Calls made by this thread use it unless their
- * descriptor carries its own.  Nothing is shared between threads. */
+/* The process DEFAULT tuning (copied; NULL = all defaults): used by every call whose descriptor carries none.  It is
+ * process-wide so that worker threads (PyTorch's autograd engine runs backward() on its own thread) see what the main
+ * thread configured; set it while no call is in flight on another thread — the per-call `tuning` field of the LSTM /
+ * network descriptors is the form that is safe to vary between concurrent calls. */
 int fnssl_tuning_set(const fnssl_tuning* t);
 int fnssl_tuning_get(fnssl_tuning* t);
 /* Name of knob `index` ("NO_STATIC3", ...; NULL past the last): lets a host binding map its own configuration
  * source onto the indices (fnssl/_lib.py maps FNSSL_<name> environment variables, on the Python side). */
 const char* fnssl_tuning_name(int index);
+
+/* Diagnostic (tests of the cluster kernels' co-residency): `nblocks` workgroups of 64 threads, each claiming `lds_bytes`
+ * of LDS (160 KiB = a whole CU), idle on `stream` until *stop (DEVICE-visible word, e.g. pinned host memory; may be
+ * NULL) is non-zero or `max_ms` have passed — what RCCL's persistent all-reduce kernels do to the CUs while the
+ * backward pass they overlap with runs.  Returns at once; never synchronises. */
+int fnssl_occupy_cus(int nblocks, int lds_bytes, const unsigned* stop, int max_ms, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Front end                                                                 */

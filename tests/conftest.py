@@ -42,3 +42,33 @@ def assert_close(got, want, rtol, atol, what=""):
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError("%s: %d/%d out of tol (rtol %g atol %g); worst at %s got %r want %r; max abs err %g"
                              % (what, int(bad.sum()), bad.size, rtol, atol, i, got[i], want[i], float(err.max())))
+
+
+@pytest.fixture(autouse=True)
+def _fnssl_tuning_follows_env(monkeypatch):
+    """The library reads no environment variable (include/fnssl.h: fnssl_tuning); fnssl/_lib.py parses FNSSL_<KNOB>
+    variables when it loads the library and on ``refresh_tuning()``.  The tests flip knobs with ``monkeypatch.setenv`` in
+    the middle of a test, so: re-read the environment at the start of every test (the previous test's monkeypatch has been
+    undone by then) and after every setenv / delenv of an FNSSL_* variable."""
+    from fnssl import _lib
+
+    def sync():
+        if _lib._lib is not None:
+            _lib.refresh_tuning()
+
+    sync()
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        orig_set(name, value, prepend)
+        if name.startswith("FNSSL_"):
+            sync()
+
+    def delenv(name, raising=True):
+        orig_del(name, raising)
+        if name.startswith("FNSSL_"):
+            sync()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.setenv, monkeypatch.delenv = orig_set, orig_del

@@ -257,6 +257,7 @@ def test_split_static_training_forward_equals_generic(dev, mode, H, bidir, c0, c
     for no_static in ("0", "1"):
         os.environ["FNSSL_TRAIN_NO_STATIC"] = no_static
         os.environ["FNSSL_TRAIN_NO_F32_CLUSTER"] = "1"       # (this test is about the split kernels; the cluster kernel has its own)
+        ops._lib.refresh_tuning()
         try:
             out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
             reserve = torch.full((ops.lstm_reserve_floats(nseq, H, ndir, nsteps),), float("nan"), device=dev)
@@ -265,6 +266,7 @@ def test_split_static_training_forward_equals_generic(dev, mode, H, bidir, c0, c
         finally:
             os.environ.pop("FNSSL_TRAIN_NO_STATIC", None)
             os.environ.pop("FNSSL_TRAIN_NO_F32_CLUSTER", None)
+            ops._lib.refresh_tuning()
     assert not torch.isnan(res[0][0]).any()
     assert torch.equal(res[0][0], res[1][0]), "h"
     assert torch.equal(torch.nan_to_num(res[0][1], nan=-7.0), torch.nan_to_num(res[1][1], nan=-7.0)), "reserve"

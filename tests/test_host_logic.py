@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.fnssl_abi_version() == _lib.ABI_VERSION == 17
+    assert lib.fnssl_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_shape_helpers_match_reference_formulas():
@@ -395,3 +395,66 @@ def test_train_mode_forward_has_no_cpu_fallback_and_flat_layout_matches_named_pa
     from IPDnet.FixedAarryIPDnet import IPDnet
     with pytest.raises(RuntimeError, match="eval"):
         IPDnet().train()(torch.zeros(1, 4, 256, 24))
+
+
+def test_library_reads_no_environment_and_tuning_is_explicit(monkeypatch):
+    """include/fnssl.h: "the library reads NO environment variable".  (a) the shipping .so does not even import getenv;
+    (b) fnssl_tuning round-trips through the ABI, rejects a struct of another size, names every knob the header defines;
+    (c) FNSSL_<KNOB> variables are parsed on the PYTHON side (fnssl/_lib.py) — at load and on refresh_tuning() — with the
+    old switches' semantics (presence flags, member + 1 for the fault-injection hook); (d) a worker thread sees the
+    process default (PyTorch's autograd engine runs backward() on its own thread)."""
+    import ctypes as C
+    import re
+    import subprocess
+    import threading
+    from fnssl import _lib
+    lib = _lib.load()
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "getenv" not in und and "secure_getenv" not in und
+    hdr = open(os.path.join(ROOT, "include", "fnssl.h")).read()
+    declared = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define FNSSL_TUNE_([A-Z0-9_]+) (\d+)", hdr)}
+    count = declared.pop("COUNT")
+    assert count == _lib.TUNE_COUNT and C.sizeof(_lib.Tuning) == 4 + 4 * count
+    assert _lib.tuning_names() == declared and lib.fnssl_tuning_name(len(declared)) is None
+    # (b)
+    t = _lib.make_tuning(no_static3=1, cluster_spin_limit=20000)
+    assert lib.fnssl_tuning_set(C.byref(t)) == 0
+    back = _lib.Tuning()
+    assert lib.fnssl_tuning_get(C.byref(back)) == 0
+    assert back.knob[declared["NO_STATIC3"]] == 1 and back.knob[declared["CLUSTER_SPIN_LIMIT"]] == 20000
+    bad = _lib.Tuning()
+    bad.struct_bytes = 12
+    assert lib.fnssl_tuning_set(C.byref(bad)) != 0 and b"struct_bytes" in lib.fnssl_last_error()
+    with pytest.raises(KeyError):
+        _lib.make_tuning(no_such_knob=1)
+    # (d)
+    seen = {}
+
+    def worker():
+        w = _lib.Tuning()
+        lib.fnssl_tuning_get(C.byref(w))
+        seen["v"] = w.knob[declared["NO_STATIC3"]]
+
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert seen["v"] == 1
+    # (c)
+    for k in list(os.environ):
+        if k.startswith("FNSSL_"):
+            monkeypatch.delenv(k)
+    _lib.refresh_tuning()
+    lib.fnssl_tuning_get(C.byref(back))
+    assert not any(back.knob)
+    env = {"FNSSL_NO_F32_CLUSTER": "0", "FNSSL_CLUSTER_TEST_STALL": "3", "FNSSL_LSTM_VARIANT_H256": "4", "FNSSL_NO_STATIC2": "1",
+           "FNSSL_LSTM_NO_STATIC": "1", "UNRELATED": "1"}
+    e = _lib.tuning_from_env(env)
+    assert e.knob[declared["NO_F32_CLUSTER"]] == 1          # getenv()-style switch: set = on, whatever the value
+    assert e.knob[declared["CLUSTER_TEST_STALL"]] == 4      # member 3 -> 3 + 1 (0 = no fault injection)
+    assert e.knob[declared["LSTM_VARIANT_H256"]] == 4 and e.knob[declared["NO_STATIC2"]] == 1
+    assert e.knob[declared["LSTM_NO_STATIC"]] == 1
+    with _lib.tuning(bwd_no_cluster=1):
+        lib.fnssl_tuning_get(C.byref(back))
+        assert back.knob[declared["BWD_NO_CLUSTER"]] == 1
+    lib.fnssl_tuning_get(C.byref(back))
+    assert back.knob[declared["BWD_NO_CLUSTER"]] == 0

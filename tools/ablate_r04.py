@@ -83,16 +83,21 @@ if "f32c" in which:
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out, skip=x, out_sum=osum)
     for _ in range(2):
         os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
         print("f32c rotate     %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
         os.environ["FNSSL_F32C_NO_ROTATE"] = "1"
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
         print("f32c no-rotate  %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
     os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     if ABL_LIB:
         M = 8 | 16 | 64                  # every load except the tags
         sweep("f32c", "FNSSL_F32C_ABL", [512, 512 | 511, 512 | M | 32 | 4 | 256, 1, 511 - 1, 0], fn, fl)
     os.environ["FNSSL_NO_F32_CLUSTER"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     print("rounds   %8.2f ms" % timed(fn), flush=True)
     os.environ.pop("FNSSL_NO_F32_CLUSTER")
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     del x, out, osum
     torch.cuda.empty_cache()
 
@@ -104,10 +109,13 @@ if "f32c_b1" in which:
     fn = lambda: ops.lstm_layer("full", x, None, None, w, 128, out)
     for _ in range(2):
         os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
         print("b1 rotate     %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
         os.environ["FNSSL_F32C_NO_ROTATE"] = "1"
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
         print("b1 no-rotate  %s" % " ".join("%.2f" % timed(fn) for _ in range(2)), flush=True)
     os.environ.pop("FNSSL_F32C_NO_ROTATE", None)
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     if ABL_LIB:
         sweep("f32c_b1", "FNSSL_F32C_ABL", [512, 1, 2, 511, 0], fn, fl)
     del x, out
@@ -117,6 +125,7 @@ if "static2" in which:
     # bits: 1 no x loads, 2 cheap gates, 4 no stores, 8 no ring barrier, 16 no c / skip loads, 32 no h reload,
     #       64 no LDS record reads, 128 no weight staging
     os.environ["FNSSL_ABL_STATIC2"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     F = torch.randn((nb, nt, nf, 256), generator=g, device=dev) * 0.3
     out = torch.empty((nb, nf, nt, 256), device=dev).permute(0, 2, 1, 3)
     osum = torch.empty((nb, nf, nt, 256), device=dev).permute(0, 2, 1, 3)

@@ -23,5 +23,6 @@ dx = torch.empty((nb, nt, nf, 2 * c0g), device=dev)
 ops.lstm_backward("full", reserve, dh, da, dx, bw, H, c0g)
 torch.cuda.synchronize()
 os.environ["FNSSL_BWDC_ABLATE"] = sys.argv[1] if len(sys.argv) > 1 else "512"
+(lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
 ops.lstm_backward("full", reserve, dh, da, dx, bw, H, c0g)
 torch.cuda.synchronize()

@@ -52,25 +52,39 @@ for c0g in (256, 0):
                                                                   ops.lstm_backward("full", reserve, dh, da, dx, bw, H, c0g, plan_only=True)), flush=True)
 
     os.environ["FNSSL_BWD_NO_CLUSTER"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     line("split kernels")
     del os.environ["FNSSL_BWD_NO_CLUSTER"]
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     os.environ["FNSSL_BWD_CLUSTER_MIN_GROUPS"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     line("cluster kernel")
     os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     line("cluster kernel, no rotation")
     del os.environ["FNSSL_BWD_CLUSTER_NO_ROTATE"]
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     os.environ["FNSSL_BWDC_NO_PREFETCH"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     line("cluster kernel, operands requested when needed")
     del os.environ["FNSSL_BWDC_NO_PREFETCH"]
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     os.environ["FNSSL_BWDC_NO_TOKEN"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     line("cluster kernel, no SIMD token")
     del os.environ["FNSSL_BWDC_NO_TOKEN"]
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     os.environ["FNSSL_BWDC_WAVES16"] = "1"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     line("cluster kernel, 16 waves, 4-deep ring")
     del os.environ["FNSSL_BWDC_WAVES16"]
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     if ABL_LIB:
         for m in (128, 256, 384, 2, 4, 8, 1 | 8 | 16 | 32 | 64):
             os.environ["FNSSL_BWDC_ABLATE"] = str(m)
+            (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
             line("cluster kernel, ablate %d" % m)
         del os.environ["FNSSL_BWDC_ABLATE"]
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     del os.environ["FNSSL_BWD_CLUSTER_MIN_GROUPS"]
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py

@@ -23,8 +23,10 @@ def run(x0, x2, cluster, reps=1):
     nb, nt, nf, _ = x0.shape
     if cluster:
         os.environ.pop("FNSSL_NO_CLUSTER", None)
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     else:
         os.environ["FNSSL_NO_CLUSTER"] = "1"
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     if LAYER == "narrow":
         out = torch.full((nb, nf, nt, H), float("nan"), device=dev, dtype=torch.bfloat16).permute(0, 2, 1, 3)
     else:

@@ -39,12 +39,15 @@ a = torch.randn((4096, 4096), device=dev)
 for kind in ("narrow", "full", "full1"):
     run, key = layer(kind)
     os.environ.pop("FNSSL_CLUSTER_SPREAD", None)
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     ref = run(); torch.cuda.synchronize()
     for label in ("alone", "spread over XCDs", "beside a competing stream"):
         if label == "spread over XCDs":
             os.environ["FNSSL_CLUSTER_SPREAD"] = "1"
+            (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
         else:
             os.environ.pop("FNSSL_CLUSTER_SPREAD", None)
+            (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
         bad = 0
         t0 = time.perf_counter()
         for i in range(N):

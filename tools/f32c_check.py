@@ -20,8 +20,10 @@ def run(x, w, summed, cluster, reps=1):
     nb, nt, nf, _ = x.shape
     if cluster:
         os.environ.pop("FNSSL_NO_F32_CLUSTER", None)
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     else:
         os.environ["FNSSL_NO_F32_CLUSTER"] = "1"
+        (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     out = torch.full((nb, nt, nf, 2 * H), float("nan"), device=dev)
     skip = (torch.arange(nb * nt * nf * 2 * H, device=dev, dtype=torch.float32).reshape(out.shape) % 7) * 0.125 if summed else None
     osum = torch.full_like(out, float("nan")) if summed else None

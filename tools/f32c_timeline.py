@@ -20,6 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     fn(); fn()
     torch.cuda.synchronize()
     os.environ["FNSSL_F32C_ABL"] = sys.argv[2] if len(sys.argv) > 2 else "512"
+    (lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
     print("KERNEL_CALL_MS %.3f" % e0.elapsed_time(e1), flush=True)

@@ -12,6 +12,7 @@ dev = torch.device("cuda:0")
 nb, nf, nt = int(os.environ.get("NB", 64)), 256, int(os.environ.get("NT", 300))
 POISON = os.environ.get("POISON", "1") == "1"
 os.environ["FNSSL_IPDNET_ONE_STREAM"] = "1"
+(lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
 sd = W.make_ipdnet_state(4500, 16, 256, 2, True)
 net = M.IPDnet(input_size=16, hidden_size=256, max_track=2, is_online=True).eval()
 net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})

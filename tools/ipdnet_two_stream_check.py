@@ -15,10 +15,12 @@ net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
 net.to(dev).bfloat16()
 x = torch.randn((nb, 16, nf, nt), device=dev).bfloat16().float()
 os.environ["FNSSL_IPDNET_ONE_STREAM"] = "1"
+(lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
 ones = [net(x) for _ in range(3)]
 torch.cuda.synchronize()
 print("one-stream runs equal:", [bool(torch.equal(ones[0], o)) for o in ones])
 del os.environ["FNSSL_IPDNET_ONE_STREAM"]
+(lambda m: m and m.refresh_tuning())(__import__("sys").modules.get("fnssl._lib"))   # FNSSL_* knobs are parsed by fnssl/_lib.py
 os.environ.setdefault("FNSSL_IPDNET_STREAMS", "2")      # part-batches on separate streams are opt-in since the cluster kernels
 outs = [net(x) for _ in range(8)]
 torch.cuda.synchronize()

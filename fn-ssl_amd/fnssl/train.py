@@ -344,6 +344,7 @@ class TrainEngine:
         # compute units RCCL's all-reduce kernels hold while the BPTT of the lower layers runs (the per-layer asynchronous
         # all-reduce): with more than one rank the backward's cluster kernels size their co-resident grids for the rest
         self.reserved_cus = 16
+        self.reserve_always = False      # tests: reserve with one rank too
 
     # ------------------------------------------------------------------ distributed plumbing
     def _world_rank(self):
@@ -437,7 +438,7 @@ class TrainEngine:
     def _backward_tuning(self):
         """Per-call tuning of the backward's LSTM kernels: RESERVED_CUS when gradients are all-reduced under the BPTT."""
         world, _ = self._world_rank()
-        if world <= 1 or not self.reserved_cus:
+        if not self.reserved_cus or (world <= 1 and not self.reserve_always):
             return None
         return _lib.make_tuning(reserved_cus=self.reserved_cus)      # on top of the current default knobs
 

@@ -265,12 +265,22 @@ class FN_SSL(nn.Module):
                      "h": [None, None, None], "shape": (nb, nf), "frames": 0}
         elif state["shape"] != (nb, nf):
             raise RuntimeError("FN_SSL.forward_stream: batch / bins changed between chunks")
+        from fnssl import train as _train                           # combine(): fused element-wise sums
         cur = ops.nchw_to_seq(x)                                    # [nb, T, nf, C]
         fb_prev = None
         for k, blk in enumerate(blocks):
             full_w, narr_w = blk._streams(dev)
             f = torch.empty((nb, T, nf, 2 * blk.full_hidden_size), dtype=torch.float32, device=dev)
-            ops.lstm_layer("full", cur, None if blk.is_first else fb_prev, None, full_w, blk.full_hidden_size, f)
+            # The residual sums (Model.py:36-37, 44-45) are formed by one element-wise kernel each (a 12-frame chunk is a few
+            # MB) so that the LSTM calls see ONE evenly spaced input tensor and take the slice-resident cluster kernels: a
+            # chunk is 5 - 10 sequence groups, which the several-waves-per-group kernels serve by streaming the whole weight
+            # matrix from L2 per group and step (29 -> ~8 ms per chunk, tools/latency_bench.py).  Same fp32 add either way.
+            if blk.is_first:
+                ops.lstm_layer("full", cur, None, None, full_w, blk.full_hidden_size, f)
+            else:
+                u = torch.empty((nb, T, nf, f.shape[3]), dtype=torch.float32, device=dev)
+                _train.combine(u, plain=(cur, fb_prev))                                     # x + fb_skip  :36-37
+                ops.lstm_layer("full", u, None, None, full_w, blk.full_hidden_size, f)
             nbuf = torch.empty((nb, nf, T + 1, blk.narr_hidden_size), dtype=torch.float32, device=dev)
             started = state["h"][k] is not None
             if started:
@@ -278,9 +288,11 @@ class FN_SSL(nn.Module):
             out = nbuf[:, :, 1:].permute(0, 2, 1, 3)                # logical [nb, T, nf, Hn]
             if blk.is_first:
                 ops.lstm_layer("narrow", f, None, cur, narr_w, blk.narr_hidden_size, out,
-                               carry_workspace=state["ws"][k], carry=started)
+                               carry_workspace=state["ws"][k], carry=started)                    # cat  :42-43
             else:
-                ops.lstm_layer("narrow", f, cur, None, narr_w, blk.narr_hidden_size, out,
+                v = torch.empty((nb, nf, T, f.shape[3]), dtype=torch.float32, device=dev).permute(0, 2, 1, 3)
+                _train.combine(v, plain=(f, cur))                                                 # + nb_skip  :44-45
+                ops.lstm_layer("narrow", v, None, None, narr_w, blk.narr_hidden_size, out,
                                carry_workspace=state["ws"][k], carry=started)
             state["h"][k] = nbuf[:, :, T].clone()
             cur, fb_prev = out, f

@@ -41,7 +41,7 @@ extern template int launch_split_h<256>(int, const LstmParams&, int, int, hipStr
 int forward_save(LstmParams p, int H, int mode, hipStream_t st);   // lstm_train.hip
 int forward_bf16(LstmParams p, int H, hipStream_t st);             // lstm_bf16.hip
 bool f32c_handles(const LstmParams& p, int H, int mode);           // lstm_f32c.hip
-int forward_f32c(LstmParams p, int mode, hipStream_t st);          // FNSSL_OK, kNoCluster (not co-resident: caller takes the rounds) or an error
+int forward_f32c(LstmParams p, int H, int mode, hipStream_t st);          // FNSSL_OK, kNoCluster (not co-resident: caller takes the rounds) or an error
 }  // namespace fnssl_lstm
 
 // ---- launch planner (host) -------------------------------------------------------------------------------------
@@ -162,8 +162,8 @@ static size_t pair_stream_bytes(int hidden, int ndir) {
 
 // the hand-off area of the cluster-resident bf16 kernel (lstm_bf16c.h) lives behind that: status word, tags, operand records
 // (bf16 "wide" calls: tags + two parities of operand records, ~513 B per sequence; fp32 calls: the cluster kernel of
-//  lstm_f32c.h hands h_t over through the output tensor and needs the status word + 8 tag words per 16-sequence group
-//  and direction, rounded up per cluster: ~2 B per sequence)
+//  lstm_f32c.h hands h_t over through the output tensor and needs the status word + one tag word per member (H / 16) per
+//  16-sequence group and direction, rounded up per cluster: 2 - 4 B per sequence)
 static size_t cluster_bytes(int nseq, int hidden, int ndir, int precision) {
   if (hidden != 256 && hidden != 128) return 0;
   if (precision == FNSSL_PRECISION_BF16W) {
@@ -172,7 +172,7 @@ static size_t cluster_bytes(int nseq, int hidden, int ndir, int precision) {
   }
   if (precision != FNSSL_PRECISION_FP32) return 256;
   const size_t groups = (size_t)(nseq + 15) / 16;
-  return 256 + (groups + 512) * ndir * 8 * sizeof(unsigned);   // (+512: the last cluster's groups are rounded up)
+  return 256 + (groups + 512) * ndir * (hidden / 16) * sizeof(unsigned);   // one tag word per (group, member); +512: the last cluster's groups are rounded up
 }
 
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap) {
@@ -359,7 +359,7 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
     // the full-band layers of a large enough shard: the cluster-resident kernel with the reserve stores (lstm_f32c.h), its
     // guarded fallback = the split kernels below
     if (d->variant == 0 && f32c_handles(p, H, mode)) {
-      const int rc = forward_f32c(p, mode, st);
+      const int rc = forward_f32c(p, H, mode, st);
       if (rc == FNSSL_OK) {
         report(FNSSL_LSTM_FAMILY_F32_CLUSTER);
         if (dry) return FNSSL_OK;
@@ -377,7 +377,7 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   // — followed, in the same call, by the rounds below as its GUARDED fallback (they return at once unless the cluster
   // kernel recorded a hand-off it gave up on: include/fnssl.h, fnssl_lstm_forward)
   if (d->variant == 0 && !(mode & kHas1) && f32c_handles(p, H, mode)) {
-    const int rc = forward_f32c(p, mode, st);
+    const int rc = forward_f32c(p, H, mode, st);
     if (rc == FNSSL_OK) {
       report(FNSSL_LSTM_FAMILY_F32_CLUSTER);
       if (rounds) *rounds = 1;

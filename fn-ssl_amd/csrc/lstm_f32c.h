@@ -17,6 +17,13 @@
 //
 // Arithmetic: per group and slice the MFMA chain is lstm_static_kernel's — accumulators start from the bias quad, input
 // quads, recurrent quads, k-ordered — and the gate math is the same code: results are bit-identical.
+//
+// Round 5: the same kernel for H = 256 (HH: the uni-directional narrow-band layers of the online model — 16 hidden slices
+// over clusters of 16 CUs, 33 / 34 quads = 132 / 136 KiB of LDS per member, the concatenated 4 data channels of block 1 as
+// a remainder quad read from src2) and for FEW groups (f32c_handles: one utterance = 6 groups per cluster): with a weight
+// slice resident in LDS a step costs the member's own matrix work plus one hand-off, where the several-waves-per-group
+// kernels stream the whole 1 - 2 MB matrix from L2 per group and step (one 4-mic utterance: 21 -> ~4 ms per narrow-band
+// layer, tools/latency_bench.py).
 #pragma once
 
 #include "lstm_static.h"
@@ -26,7 +33,7 @@ namespace fnssl_lstm {
 constexpr int kF32cWaves = 16;   // four per SIMD (measured: 100.8 against 102.3 ms per layer with 12 = three per SIMD); 225 groups = 14 each + 1
 
 struct F32ClusterParams {
-  unsigned* tags;       // [direction][cluster][group in cluster][member 8], zeroed before the launch
+  unsigned* tags;       // [direction][cluster][group in cluster][member H / 16], zeroed before the launch
   unsigned* status;     // one word, zeroed before the launch: 0 = fine, else the code of the first wave that gave up
   int clusters_per_dir;
   int groups_per_cluster;
@@ -39,26 +46,32 @@ struct F32ClusterParams {
                         // order, a static rank per wave and a staggered start were measured as well: equal or worse.
 };
 
-// NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad (block 1); MODE: 0 or kSum
+// HH: hidden size (128: clusters of 8; 256: clusters of 16, NW_ <= 8 — the row of h_{t-1} alone is 64 registers);
+// NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad — of src0 (block 1's full-band layer, NV0
+// = 0) or, with MODE & kHas2, of the concatenated src2 behind the NV0 blocks of src0 (block 1's narrow-band layer);
+// MODE: kSum / kHas2 / kSave bits
 // ABLRT = true: timing-ablation twin (make ABLATE=1 only, wrong results) driven by the bits of FNSSL_F32C_ABL at run time:
 //   1 one group's addressing for all, 2 cheap gates, 4 no tag waits, 8 no input loads, 16 no recurrent-operand loads,
 //   32 no stores, 64 no cell-state / residual loads, 128 no LDS record reads in the quads, 256 no tag loads / publishes
-template <int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
+template <int HH, int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
 __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
-  constexpr int H = 128, NS = H / 16, NW = NW_;
+  constexpr int H = HH, NS = H / 16, NW = NW_;
   constexpr bool SUM = (MODE & kSum) != 0, SAVE = (MODE & kSave) != 0;   // SAVE: training forward (gates + cell state -> reserve)
+  constexpr bool CAT = (MODE & kHas2) != 0;                              // the remainder quad comes from src2
   constexpr int QPS = 1 + NV0 + NS0 + NS;
   // DRIFT: a wave starts the recurrent part of its k-th group of a step only when EVERY member has finished its
   // (k - DRIFT)-th: the eight members then read a group's input rows within a few group-times of each other and the seven
   // later ones find them in the XCD's L2 (4 MB for four clusters) instead of fetching them again from memory
   constexpr int XD = NW_ > 12 ? 4 : 8;   // input ring: block v is requested XD - 1 quads (~3.6 k cycles) before its use — the other members have pushed it out of L2
-  static_assert(!(NV0 && NS0) && (NV0 == 0 || NV0 % XD == 0), "block-only or remainder-only input");
+  static_assert((CAT ? NS0 == 1 : !(NV0 && NS0)) && (NV0 == 0 || NV0 % XD == 0) && (H == 128 || H == 256),
+                "blocks of src0, or its remainder alone, or blocks of src0 + the remainder quad of src2");
+  static_assert(H == 128 || NW_ <= 8, "H = 256: at most two waves per SIMD (register budget)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ABL = ABLRT ? p.ablate : 0;
 
   const int b = blockIdx.x;
-  const int m = (b >> 3) & 7;                                 // member = hidden slice
-  const int cl = ((b >> 6) << 3) + (b & 7);                   // cluster (members share blockIdx & 7: one XCD, for speed only)
+  const int m = (b >> 3) % NS;                                // member = hidden slice
+  const int cl = ((b >> 3) / NS) * 8 + (b & 7);               // cluster (members share blockIdx & 7: one XCD, for speed only)
   if (cl >= cp.clusters_per_dir * p.ndir) return;
   const int dir = cl / cp.clusters_per_dir;
   const int ck = cl - dir * cp.clusters_per_dir;
@@ -87,7 +100,11 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   auto rec = [&](int q, int j) { return *reinterpret_cast<const v4f*>(lds_rd + (q * 4 + j) * 1024); };
 
   const unsigned st0 = (unsigned)(p.src0.st * 4), sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
-  unsigned* const tag_cl = cp.tags + (size_t)cl * cp.groups_per_cluster * 8;
+  const unsigned st2 = CAT ? (unsigned)(p.src2.st * 4) : 0u;
+  // streaming (uni-directional layers): the host passes out - out_st, h_{-1} is the row before the chunk's first output row
+  // and c_{-1} sits in the cell-state scratch, where every kernel family leaves it in the same [group][slice][lane] layout
+  const unsigned cy = (unsigned)p.carry;
+  unsigned* const tag_cl = cp.tags + (size_t)cl * cp.groups_per_cluster * NS;
   const v4f zero4 = v4f{0.f, 0.f, 0.f, 0.f};
 
   // Deferred tag store of the previous group-step: sc1 payload stores -> s_waitcnt vmcnt(0) (every earlier vector memory
@@ -107,7 +124,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   // ---- a group-step's addressing and its early requests (first input blocks, cell state, residual operand, tags) are
   // set up ONE group-step ahead, under the previous group-step's recurrent part: nothing of it is waited for at the top
   struct Grp {
-    unsigned vo0, voo, vok, voo2;
+    unsigned vo0, voo, vok, voo2, vo2 = 0;
     bool valid;
     int task, step;
   };
@@ -115,7 +132,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   // group-step every ~6 us per SIMD): the launcher has checked that offsets grow with the sequence index (so >= (q_inner - 1)
   // si, q_inner >= 16), so the wave's minimum is its first sequence, whose (qo, qi) the wave carries along incrementally;
   // a lane's distance from it is d si, plus (so - q_inner si) if the group crosses into the next outer index.
-  auto locate = [&](int task, int qo0, int qi0, Grp& gr, rsrc_t& rx0, rsrc_t& ro, rsrc_t& rsk, rsrc_t& ro2) {
+  auto locate = [&](int task, int qo0, int qi0, Grp& gr, rsrc_t& rx0, rsrc_t& ro, rsrc_t& rsk, rsrc_t& ro2, rsrc_t& rx2) {
     const int q0 = task * 16;
     gr.valid = q0 + n < p.nseq;
     const int d = q0 + n < p.nseq ? n : p.nseq - 1 - q0;
@@ -125,7 +142,8 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       voff = (unsigned)(delta * 4) + (unsigned)(extra * 4);
       return make_rsrc(base + ((long long)qo0 * so + (long long)qi0 * si));
     };
-    rx0 = one(p.src0.p, p.src0.so, p.src0.si, NS0 ? g : 4 * g, gr.vo0);
+    rx0 = one(p.src0.p, p.src0.so, p.src0.si, (NS0 && !CAT) ? g : 4 * g, gr.vo0);
+    if constexpr (CAT) rx2 = one(p.src2.p, p.src2.so, p.src2.si, g, gr.vo2);
     ro = one(p.out, p.out_so, p.out_si, dir * H + 4 * g, gr.voo);
     gr.vok = gr.voo2 = 0;
     rsk = SUM ? one(p.skip.p, p.skip.so, p.skip.si, dir * H + 4 * g, gr.vok) : rx0;
@@ -170,7 +188,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   const bool single = g0 + w + NW >= g1;                      // one group per wave: its c_t is not written yet when the next
                                                               // group-step's requests go out, so c is requested at the top
   Grp cur, nxt;
-  rsrc_t rx0, ro, rsk, ro2, nrx0, nro, nrsk, nro2;
+  rsrc_t rx0, ro, rsk, ro2, rx2, nrx0, nro, nrsk, nro2, nrx2;
   v4f xr[XD];
   float xs0 = 0.f;
   v4f cprev = zero4, skipv = zero4;
@@ -178,52 +196,52 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   auto request = [&](const Grp& gr, rsrc_t qx0, rsrc_t qsk, bool with_c) {   // early requests of group-step gr
     const unsigned tt = tt_of(gr.step);
     if (!(ABL & 8)) {
-      if constexpr (NV0 > 0)
-        static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
-      else
-        xs0 = bld1(qx0, gr.vo0, tt * st0);
+      if constexpr (NV0 > 0) static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
+      if constexpr (NS0 > 0 && !CAT) xs0 = bld1(qx0, gr.vo0, tt * st0);
     }
     if (SUM && !(ABL & 64)) skipv = bld4(qsk, gr.vok, tt * stk + 64 * m);
-    if (gr.step > 0) {
-      if (!(ABL & 256)) tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gr.step > 0 || cy) {
+      if (gr.step > 0 && !(ABL & 256))
+        tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * NS + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (with_c && !(ABL & 64)) cprev = bld4_l2(rc_of(gr.task), vlane, m * 1024);
     }
     if (DRIFT > 0 && !(ABL & 256) && gr.task - DRIFT * NW >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
-      tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NW - g0) * 8 + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NW - g0) * NS + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   cur.task = g0 + w;
   cur.step = 0;
   const int qo_first = (cur.task * 16) / p.q_inner, qi_first = cur.task * 16 - qo_first * p.q_inner;
   int qo0 = qo_first, qi0 = qi_first;                         // (qo, qi) of the first sequence of the NEXT group to locate
-  locate(cur.task, qo0, qi0, cur, rx0, ro, rsk, ro2);
+  locate(cur.task, qo0, qi0, cur, rx0, ro, rsk, ro2, rx2);
   request(cur, rx0, rsk, true);
+  if constexpr (CAT) xs0 = bld1(rx2, cur.vo2, tt_of(0) * st2);
 
   for (;;) {
     const int step = cur.step, task = cur.task;
     const unsigned tt = tt_of(step);
-    const unsigned o0 = tt * st0, oo = tt * sto;
-    const unsigned op = (rev ? tt + 1 : tt - 1) * sto;         // row of h_{step - 1}
+    const unsigned o0 = tt * st0, oo = (tt + cy) * sto;
+    const unsigned op = (rev ? tt + 1 : tt - 1 + cy) * sto;    // row of h_{step - 1}
     const rsrc_t rc = rc_of(task);
-    unsigned* const tag_g = tag_cl + (size_t)(task - g0) * 8;
-    if (single && step > 0 && !(ABL & 64)) cprev = bld4_l2(rc, vlane, m * 1024);
+    unsigned* const tag_g = tag_cl + (size_t)(task - g0) * NS;
+    if (single && (step > 0 || cy) && !(ABL & 64)) cprev = bld4_l2(rc, vlane, m * 1024);
     // (a leftover group's c_{t-1} was written by ANOTHER wave of this member, which may be behind: it is loaded in fetch_h,
     //  once the tags show that every member — this one included — has finished the group's previous step)
     const bool late_c = task >= g0 + FULL;
-    v4f cprev_cur = step > 0 ? cprev : zero4;
+    v4f cprev_cur = (step > 0 || cy) ? cprev : zero4;
     const v4f skip_cur = skipv;
 
-    // h_{step - 1} of the whole row: every member's slice, once all 8 tags show it
+    // h_{step - 1} of the whole row: every member's slice, once all NS tags show it
     v4f hold[NS];
     auto fetch_h = [&]() {
       if (DRIFT > 0 && !(ABL & 4) && !dead && task - DRIFT * NW >= g0) {
-        unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NW - g0) * 8;
+        unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NW - g0) * NS;
         dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagd < (unsigned)step + 1) == 0; },
-                             [&]() { tagd = __hip_atomic_load(tag_d + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 8, 0x40000u);
+                             [&]() { tagd = __hip_atomic_load(tag_d + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 8, 0x40000u);
       }
-      if (step > 0 && !(ABL & 16)) {
-        if (!(ABL & 4) && !dead)
+      if ((step > 0 || cy) && !(ABL & 16)) {
+        if (step > 0 && !(ABL & 4) && !dead)
           dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagv < (unsigned)step) == 0; },
-                               [&]() { tagv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 16, 0x30000u);
+                               [&]() { tagv = __hip_atomic_load(tag_g + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 16, 0x30000u);
         if (late_c && !(ABL & 64)) cprev_cur = bld4_l2(rc, vlane, m * 1024);
 #pragma unroll
         for (int s = 0; s < NS; ++s) hold[s] = bld4_l2(ro, cur.voo, op + 64 * s);
@@ -279,6 +297,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
         quad(ic<1 + V>{}, xb.x, xb.y, xb.z, xb.w);
         if constexpr (V + XD < NV0) if (!(ABL & 8)) xr[V % XD] = bld4(rx0, cur.vo0, o0 + 64 * (V + XD));
       });
+      if constexpr (NS0 > 0) quad1(ic<1 + NV0>{}, xs0);          // the 4 concatenated data channels (src2) behind the blocks
     } else {
       pub_flush();
       fetch_h();
@@ -305,6 +324,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       if (ABL & 1) {   // timing ablation (wrong results): every group-step uses the first group's addressing
         nxt.vo0 = cur.vo0; nxt.voo = cur.voo; nxt.vok = cur.vok; nxt.voo2 = cur.voo2; nxt.valid = cur.valid;
         nrx0 = rx0; nro = ro; nrsk = rsk; nro2 = ro2;
+        if constexpr (CAT) {
+          nxt.vo2 = cur.vo2;
+          nrx2 = rx2;
+        }
       } else {
         if (seq_next) {                                       // next group of this wave: 16 NW sequences further
           qi0 += 16 * NW;
@@ -319,9 +342,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
           qo0 = qo_first;
           qi0 = qi_first;
         }
-        locate(nxt.task, qo0, qi0, nxt, nrx0, nro, nrsk, nro2);
+        locate(nxt.task, qo0, qi0, nxt, nrx0, nro, nrsk, nro2, nrx2);
       }
       request(nxt, nrx0, nrsk, !single && nxt.task < g0 + FULL);
+      if constexpr (CAT) xs0 = bld1(nrx2, nxt.vo2, tt_of(nxt.step) * st2);
     }
     static_for<NS>([&](auto sp) {
       constexpr int SP = decltype(sp)::value;
@@ -367,6 +391,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     ro = nro;
     rsk = nrsk;
     ro2 = nro2;
+    if constexpr (CAT) rx2 = nrx2;
   }
   pub_flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,15 +402,16 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   }
 }
 
-template <int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
+template <int HH, int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
 int launch_f32c_k(const LstmParams& p, const F32ClusterParams& cp, hipStream_t st) {
-  constexpr int QPS = 1 + NV0 + NS0 + 8;
+  constexpr int NS = HH / 16;
+  constexpr int QPS = 1 + NV0 + NS0 + NS;
   const size_t lds = (size_t)QPS * 4096;
-  auto k = lstm_f32c_kernel<NV0, NS0, MODE, ABLRT, DRIFT, NW_>;
+  auto k = lstm_f32c_kernel<HH, NV0, NS0, MODE, ABLRT, DRIFT, NW_>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int ncl = cp.clusters_per_dir * p.ndir;
-  const int nwg = 64 * ((ncl + 7) / 8);
+  const int nwg = 8 * NS * ((ncl + 7) / 8);                  // block b: XCD b & 7, member (b >> 3) % NS, cluster ((b >> 3) / NS) * 8 + (b & 7)
   // every member of every cluster must be resident at once: the grid may not exceed what the device says it can hold
   // (the waits are bounded and the call carries a guarded fallback anyway — this only avoids a launch that cannot work)
   if (!cluster_grid_fits(reinterpret_cast<const void*>(k), NW_ * 64, lds, nwg)) return kNoCluster;

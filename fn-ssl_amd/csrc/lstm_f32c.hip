@@ -1,4 +1,4 @@
-// Cluster-resident fp32 LSTM kernel (lstm_f32c.h): instantiations for FN-SSL's H = 128 full-band layers and the launcher.
+// Cluster-resident fp32 LSTM kernel (lstm_f32c.h): instantiations for FN-SSL's layer shapes and the launcher.
 #include <cstdlib>
 
 #include "lstm_f32c.h"
@@ -6,57 +6,99 @@
 
 namespace fnssl_lstm {
 
-// Full-chip launches of the two full-band shapes of the network (block 1: 4 input channels; blocks 2-3: 256, fused
-// residual output).  FNSSL_NO_F32_CLUSTER=1 keeps lstm_static_kernel's rounds (same bits): A/B.
-bool f32c_handles(const LstmParams& p, int H, int mode) {
-  if (fnssl::tune(FNSSL_TUNE_NO_F32_CLUSTER)) return false;
-  if (H != 128 || p.carry || p.c2 != 0 || p.ablate) return false;
-  if (p.reserve && mode != 0) return false;   // training forward: no fused residual
-  // (block 1's layer, 4 input channels = 144 MFMAs per group-step, gains little — 35.7 against 36.2 ms;
-  //  FNSSL_NO_F32C_B1=1 keeps it on the rounds: A/B)
-  if (!(p.c0 == 256 && (mode == kSum || mode == 0)) && !(p.c0 == 4 && mode == 0 && !fnssl::tune(FNSSL_TUNE_NO_F32C_B1))) return false;
-  // the kernel's addressing takes a group's first sequence as its lowest address
-  auto grows = [&](long long so, long long si) { return si >= 0 && so >= (long long)(p.q_inner - 1) * si; };
-  if (p.q_inner < 16 || !grows(p.src0.so, p.src0.si) || !grows(p.out_so, p.out_si) ||
-      ((mode & kSum) && !grows(p.skip.so, p.skip.si)))
-    return false;
-  const int ncu = fnssl::device_cus();
-  if (ncu < 8 * p.ndir) return false;
-  // inference: at least what one full round of three waves per SIMD would cover (below that the planner's rounds / split
-  // kernels are tuned); training forward (reserve): from two groups per wave of every cluster — config 4's shard has 1200
-  // groups on 1024 SIMDs, which the 2-waves-per-group kernels run as 3 wave-times for 2.34 (0.52 of the roof), while here
-  // the groups beyond two per wave rotate over the waves step by step (lstm_f32c.h): balanced over the launch
-  const long long groups = (long long)p.ntasks * p.ndir;
-  if (p.reserve) return !fnssl::tune(FNSSL_TUNE_TRAIN_NO_F32_CLUSTER) && groups >= 2LL * kF32cWaves * (ncu / 8);
-  return groups >= 12LL * ncu;
+constexpr int kF32cWavesH256 = 8;   // H = 256: two waves per SIMD (the row of h_{t-1} alone is 64 registers)
+
+// Which calls the cluster-resident kernel takes (NO_F32_CLUSTER keeps the per-wave rounds / split kernels, same bits: A/B).
+//   H = 128: the full-band layers (block 1: 4 input channels; blocks 2-3: 256, optionally with the fused residual output)
+//            and the offline model's narrow-band layers of blocks 2-3 (same shape) — at ANY size since round 5: with a
+//            handful of groups (one utterance, a streaming chunk) the several-waves-per-group kernels stream the whole
+//            0.8 MB matrix from L2 per group and step, here a step costs one member's matrix work plus a hand-off
+//            (one 4-mic utterance: 25.1 -> 11.7 ms for the three layers; 4 utterances: 40.3 -> 30.1; from 16 utterances on
+//            it was the cluster kernel already: tools/latency_bench.py, profiles/r05/);
+//   H = 256: the online model's narrow-band layers (clusters of 16) while the launch is SMALL (up to 6 groups per CU, where
+//            the 4-waves-per-group kernels ran until round 4); full-chip launches stay on lstm_static3_kernel's rounds
+//            (0.89 of the roof: a wave that owns its groups for the whole recurrence needs no hand-off at all).
+// every tensor of the call has its sequences evenly spaced: sequence q at q * si
+static bool f32c_uniform(const LstmParams& p, int mode) {
+  auto even = [&](long long so, long long si) { return si >= 0 && so == (long long)p.q_inner * si; };
+  return even(p.src0.so, p.src0.si) && even(p.out_so, p.out_si) && (!(mode & kSum) || even(p.skip.so, p.skip.si)) &&
+         (!(mode & kHas2) || even(p.src2.so, p.src2.si));
 }
 
-int forward_f32c(LstmParams p, int mode, hipStream_t st) {
-  const int ncu = fnssl::device_cus();
+bool f32c_handles(const LstmParams& p, int H, int mode) {
+  if (fnssl::tune(FNSSL_TUNE_NO_F32_CLUSTER)) return false;
+  if ((H != 128 && H != 256) || p.ablate) return false;
+  if (H == 128) {
+    if (p.c2 != 0 || p.carry) return false;
+    if (p.reserve && mode != 0) return false;   // training forward: no fused residual
+    // (block 1's layer, 4 input channels = 144 MFMAs per group-step, gains little at full-chip size — 35.7 against 36.2 ms;
+    //  NO_F32C_B1 keeps it on the rounds: A/B)
+    if (!(p.c0 == 256 && (mode == kSum || mode == 0)) && !(p.c0 == 4 && mode == 0 && !fnssl::tune(FNSSL_TUNE_NO_F32C_B1))) return false;
+  } else {
+    if (p.reserve || p.ndir != 1 || p.c0 != 256 || fnssl::tune(FNSSL_TUNE_NO_F32_SMALL)) return false;
+    const bool plain = p.c2 == 0 && (mode == 0 || mode == kSum), cat = p.c2 == 4 && (mode == kHas2 || mode == (kHas2 | kSum));
+    if (!plain && !cat) return false;
+  }
+  // the kernel's addressing takes a group's first sequence as its lowest address and lets a group cross ONE outer index
+  // (q_inner >= 16) — or the sequences are evenly spaced in every tensor (so == q_inner * si: a 12-frame streaming chunk's
+  // full-band layers, q_inner = 12), which forward_f32c() runs as one outer index
+  auto grows = [&](long long so, long long si) { return si >= 0 && so >= (long long)(p.q_inner - 1) * si; };
+  if (!f32c_uniform(p, mode) &&
+      (p.q_inner < 16 || !grows(p.src0.so, p.src0.si) || !grows(p.out_so, p.out_si) ||
+       ((mode & kSum) && !grows(p.skip.so, p.skip.si)) || ((mode & kHas2) && !grows(p.src2.so, p.src2.si))))
+    return false;
+  const int ncu = cluster_cus();
+  if (ncu < (H / 16) * p.ndir) return false;
+  const long long groups = (long long)p.ntasks * p.ndir;
+  if (const int mg = fnssl::tune(FNSSL_TUNE_F32C_MIN_GROUPS, 1, 1 << 30)) {
+    if (groups < mg) return false;
+  }
+  // training forward (reserve): from two groups per wave of every cluster — config 4's shard has 1200 groups on 1024 SIMDs,
+  // which the 2-waves-per-group kernels run as 3 wave-times for 2.34 (0.52 of the roof), while here the groups beyond two
+  // per wave rotate over the waves step by step (lstm_f32c.h): balanced over the launch
+  if (p.reserve) return !fnssl::tune(FNSSL_TUNE_TRAIN_NO_F32_CLUSTER) && groups >= 2LL * kF32cWaves * (ncu / 8);
+  if (H == 256) {
+    const int s4 = fnssl::tune(FNSSL_TUNE_SPLIT4_MAX_H256, 1, 64) ? fnssl::tune(FNSSL_TUNE_SPLIT4_MAX_H256, 1, 64) : 6;
+    return groups <= (long long)s4 * ncu;
+  }
+  return !fnssl::tune(FNSSL_TUNE_NO_F32_SMALL) || groups >= 12LL * ncu;
+}
+
+int forward_f32c(LstmParams p, int H, int mode, hipStream_t st) {
+  if (f32c_uniform(p, mode)) p.q_inner = p.nseq;   // one outer index: no group ever crosses (any q_inner, e.g. 12 frames)
+  const int ncu = cluster_cus();
+  const int members = H / 16;
   F32ClusterParams cp;
-  cp.clusters_per_dir = (ncu / 8) / p.ndir;
+  cp.clusters_per_dir = (ncu / members) / p.ndir;
   cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
   cp.status = reinterpret_cast<unsigned*>(p.cluster_ws);
   cp.tags = reinterpret_cast<unsigned*>(p.cluster_ws + 256);
   cp.spin_limit = cluster_spin_limit();
   cp.stall_member = cluster_test_stall();
-  cp.rotate = (kF32cWaves & (kF32cWaves - 1)) == 0 && !fnssl::tune(FNSSL_TUNE_F32C_NO_ROTATE);   // A/B knob, same bits
+  cp.rotate = !fnssl::tune(FNSSL_TUNE_F32C_NO_ROTATE);   // A/B knob, same bits (wave counts are powers of two)
   cp.prio_mode = fnssl::tune(FNSSL_TUNE_F32C_PRIO, 9, 9) ? 0 : 2;   // see F32ClusterParams
-  const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * 8 * sizeof(unsigned);
+  const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * members * sizeof(unsigned);
   if (!p.dry) FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));
+  if (H == 256) {
+    constexpr int W = kF32cWavesH256;
+    if (mode == (kHas2 | kSum)) return launch_f32c_k<256, 16, 1, kHas2 | kSum, false, 2, W>(p, cp, st);
+    if (mode == kHas2) return launch_f32c_k<256, 16, 1, kHas2, false, 2, W>(p, cp, st);
+    if (mode == kSum) return launch_f32c_k<256, 16, 0, kSum, false, 2, W>(p, cp, st);
+    return launch_f32c_k<256, 16, 0, 0, false, 2, W>(p, cp, st);
+  }
 #ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
   if (const int abl = env_int("FNSSL_F32C_ABL", 1, 1023)) {
     p.ablate = abl;
-    if (mode == kSum) return launch_f32c_k<16, 0, kSum, true>(p, cp, st);
-    if (p.c0 == 4) return launch_f32c_k<0, 1, 0, true>(p, cp, st);
+    if (mode == kSum) return launch_f32c_k<128, 16, 0, kSum, true>(p, cp, st);
+    if (p.c0 == 4) return launch_f32c_k<128, 0, 1, 0, true>(p, cp, st);
   }
   p.ablate = 0;
 #endif
-  if (p.reserve) return p.c0 == 4 ? launch_f32c_k<0, 1, kSave>(p, cp, st) : launch_f32c_k<16, 0, kSave>(p, cp, st);
-  if (p.c0 == 4) return launch_f32c_k<0, 1, 0>(p, cp, st);
+  if (p.reserve) return p.c0 == 4 ? launch_f32c_k<128, 0, 1, kSave>(p, cp, st) : launch_f32c_k<128, 16, 0, kSave>(p, cp, st);
+  if (p.c0 == 4) return launch_f32c_k<128, 0, 1, 0>(p, cp, st);
   // (drift bounds of 1 / 3 / 4 group-steps and 12 waves per member were measured in round 3: +0.5 / 0.0 / +1.2 ms, +1.5 ms)
-  if (mode == kSum) return launch_f32c_k<16, 0, kSum>(p, cp, st);
-  return launch_f32c_k<16, 0, 0>(p, cp, st);
+  if (mode == kSum) return launch_f32c_k<128, 16, 0, kSum>(p, cp, st);
+  return launch_f32c_k<128, 16, 0, 0>(p, cp, st);
 }
 
 }  // namespace fnssl_lstm

@@ -77,10 +77,11 @@ const char* const kTuneNames[] = {
     "CLUSTER_SPIN_LIMIT",
     "CLUSTER_TEST_STALL",
     "RESERVED_CUS",
-    "NO_F32_SMALL"};
+    "NO_F32_SMALL",
+    "F32C_MIN_GROUPS"};
 constexpr int kTuneNamed = (int)(sizeof(kTuneNames) / sizeof(kTuneNames[0]));
 static_assert(kTuneNamed <= FNSSL_TUNE_COUNT, "more knob names than slots");
-static_assert(kTuneNamed == FNSSL_TUNE_NO_F32_SMALL + 1, "knob names out of step with include/fnssl.h");
+static_assert(kTuneNamed == FNSSL_TUNE_F32C_MIN_GROUPS + 1, "knob names out of step with include/fnssl.h");
 }  // namespace
 
 const fnssl_tuning& tuning() {

@@ -93,6 +93,7 @@ const char* fnssl_last_error(void);
 #define FNSSL_TUNE_CLUSTER_TEST_STALL 35      /* FAULT INJECTION: m + 1 = member m of cluster 0 never shows up (the give-up / guarded-fallback tests) */
 #define FNSSL_TUNE_RESERVED_CUS 36            /* compute units the caller keeps busy with other work (RCCL's all-reduce kernels under an overlapped backward): the cluster-resident kernels size their co-resident grids for device CUs minus this */
 #define FNSSL_TUNE_NO_F32_SMALL 37            /* few-sequence fp32 launches (one utterance, a streaming chunk) on the split kernels instead of the slice-resident cluster kernel (lstm_f32s.h) */
+#define FNSSL_TUNE_F32C_MIN_GROUPS 38        /* smallest (groups x directions) count the fp32 cluster kernels take for inference (default: see lstm_f32c.hip) */
 #define FNSSL_TUNE_COUNT 48               /* room for more without changing the struct */
 
 typedef struct fnssl_tuning {

@@ -1206,6 +1206,74 @@ def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, 
     assert_close(got, want, RTOL, ATOL, "fp32 cluster kernel vs oracle")
 
 
+@pytest.mark.parametrize("mode,H,nb,nt,nf,c2,summed", [
+    ("narrow", 256, 6, 20, 256, 0, True),      # one 4-mic utterance: 96 groups = 6 per cluster of 16 CUs (blocks 2-3, fused residual)
+    ("narrow", 256, 6, 20, 256, 4, True),      # block 1: [256 | 4] = the concatenated data channels as a remainder quad of src2
+    ("narrow", 256, 1, 37, 256, 4, False),     # one 2-mic utterance: ONE group per cluster, last block's shape (no residual)
+    ("narrow", 256, 3, 13, 250, 0, False),     # ragged: 750 sequences = 46 groups + 14 sequences, groups cross pairs
+    ("full", 128, 1, 249, 256, 0, True),       # one 2-mic utterance, full-band: 16 groups per direction = one per cluster
+    ("full", 128, 6, 40, 256, 0, False),       # 240 sequences: 15 groups per direction, fewer than clusters
+])
+def test_few_sequence_launches_take_the_slice_resident_cluster_kernel_and_equal_the_split_kernels(dev, monkeypatch, mode, H, nb, nt, nf, c2, summed):
+    """Round 5: the reference's real predict shapes (one recording, Learner.py:219-272) are a handful of 16-sequence groups.
+    They now run on the cluster-resident kernel (lstm_f32c.h, generalised to H = 256 / clusters of 16 and to the
+    concatenated 4-channel segment) instead of the several-waves-per-group kernels that stream the whole weight matrix
+    from L2 per group and step: bit-identical h (and fused residual output), twice, status word 0, no fallback; a few
+    sequences against the oracle."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    bidir = mode == "full"
+    ndir = 2 if bidir else 1
+    c0 = 256
+    sd = lstm_state(c0 + c2, H, bidir, 5900 + nb + c2)
+    sfx = ("", "_reverse") if bidir else ("",)
+    w = [ops.pack_lstm(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, c2, dev)
+         for s_ in sfx]
+    g = torch.Generator(device="cpu").manual_seed(5901 + nf + nt)
+    x0 = (torch.randn((nb, nt, nf, c0), generator=g) * 0.5).to(dev)
+    x2 = (torch.randn((nb, nt, nf, c2), generator=g) * 0.5).to(dev) if c2 else None
+    skip = (torch.randn((nb, nt, nf, ndir * H), generator=g) * 0.5).to(dev) if summed else None
+
+    def buf():
+        if mode == "full":
+            return torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+        return torch.full((nb, nf, nt, ndir * H), float("nan"), device=dev).permute(0, 2, 1, 3)      # narrow-band storage
+
+    def run(plan=False):
+        out = buf()
+        osum = buf() if summed else None
+        r = ops.lstm_layer(mode, x0, None, x2, w, H, out, skip=skip, out_sum=osum, plan_only=plan)
+        return r if plan else (out, osum)
+
+    for k in ("FNSSL_NO_F32_SMALL", "FNSSL_NO_F32_CLUSTER"):
+        monkeypatch.delenv(k, raising=False)
+    ops.cluster_fallbacks(dev, reset=True)
+    assert run(plan=True) == ("f32_cluster", 1), run(plan=True)
+    a, asum = run()
+    a2, _ = run()
+    with torch.cuda.device(dev):
+        assert ops.lstm_cluster_status(nb * (nt if mode == "full" else nf), H, ndir, dev) == 0
+    assert ops.cluster_fallbacks(dev) == 0
+    monkeypatch.setenv("FNSSL_NO_F32_SMALL", "1")
+    fam, _ = run(plan=True)
+    assert fam in ("split", "split_static", "static", "generic"), fam
+    b, bsum = run()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, a2), "cluster kernel differs from the split kernels / is not repeatable"
+    if summed:
+        assert torch.equal(asum, bsum) and torch.equal(asum, a + skip)
+    xin = torch.cat((x0, x2), dim=-1) if c2 else x0
+    if mode == "full":
+        rows = [(0, 0), (nb - 1, nt - 1)]
+        seq = np.stack([xin[b_, t_].cpu().numpy() for b_, t_ in rows])
+        got = np.stack([a[b_, t_].cpu().numpy() for b_, t_ in rows])
+    else:
+        rows = [(0, 0), (nb - 1, nf - 1), (nb // 2, 17)]
+        seq = np.stack([xin[b_, :, f_].cpu().numpy() for b_, f_ in rows])
+        got = np.stack([a[b_, :, f_].cpu().numpy() for b_, f_ in rows])
+    assert_close(got, O.lstm(seq, sd, "L.", bidir), RTOL, ATOL, "few-sequence cluster kernel vs oracle")
+
+
 @pytest.mark.parametrize("kind", ["f32", "bf16"])
 def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch, kind):
     """A member workgroup that never shows up (FNSSL_CLUSTER_TEST_STALL: what a CU-masked, shared or busy device does to

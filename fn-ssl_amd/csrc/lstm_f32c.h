@@ -24,6 +24,13 @@
 // slice resident in LDS a step costs the member's own matrix work plus one hand-off, where the several-waves-per-group
 // kernels stream the whole 1 - 2 MB matrix from L2 per group and step (one 4-mic utterance: 21 -> ~4 ms per narrow-band
 // layer, tools/latency_bench.py).
+//
+// Gate split (GS = 4), for launches of a FEW groups per cluster (one 2-mic utterance, a 12-frame streaming chunk: one group
+// per cluster, i.e. one wave per CU): the four waves of a "slot" — one per SIMD — share a group and each runs the MFMA chain
+// of ONE gate (component `gate` of every weight record: the very chain MFMA4 runs for that gate, so the bits are the same),
+// applies that gate's activation, and hands the activated gate to its three siblings through LDS (double-buffered 1-KiB
+// records, one sequence counter per slot); all four then form c_t and h_t redundantly and the gate-0 wave stores and
+// publishes.  A group-step's matrix phase shrinks from 4 x 16 x QPS MFMAs on one SIMD to 16 x QPS on each of four.
 #pragma once
 
 #include "lstm_static.h"
@@ -53,9 +60,11 @@ struct F32ClusterParams {
 // ABLRT = true: timing-ablation twin (make ABLATE=1 only, wrong results) driven by the bits of FNSSL_F32C_ABL at run time:
 //   1 one group's addressing for all, 2 cheap gates, 4 no tag waits, 8 no input loads, 16 no recurrent-operand loads,
 //   32 no stores, 64 no cell-state / residual loads, 128 no LDS record reads in the quads, 256 no tag loads / publishes
-template <int HH, int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
+template <int HH, int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves, int GS = 1>
 __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p, const F32ClusterParams cp) {
   constexpr int H = HH, NS = H / 16, NW = NW_;
+  constexpr int NWS = NW / GS;                                           // schedule lanes: waves, or 4-wave slots (gate split)
+  static_assert((GS == 1 || GS == 4) && NW % GS == 0 && (NWS & (NWS - 1)) == 0, "gate split: whole slots, a power of two of them");
   constexpr bool SUM = (MODE & kSum) != 0, SAVE = (MODE & kSave) != 0;   // SAVE: training forward (gates + cell state -> reserve)
   constexpr bool CAT = (MODE & kHas2) != 0;                              // the remainder quad comes from src2
   constexpr int QPS = 1 + NV0 + NS0 + NS;
@@ -66,6 +75,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   static_assert((CAT ? NS0 == 1 : !(NV0 && NS0)) && (NV0 == 0 || NV0 % XD == 0) && (H == 128 || H == 256),
                 "blocks of src0, or its remainder alone, or blocks of src0 + the remainder quad of src2");
   static_assert(H == 128 || NW_ <= 8, "H = 256: at most two waves per SIMD (register budget)");
+  static_assert(GS == 1 || (!SAVE && !ABLRT), "gate split: inference kernels only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ABL = ABLRT ? p.ablate : 0;
 
@@ -87,6 +97,8 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   const int lane = threadIdx.x & 63;
   const int n = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ws = GS == 1 ? w : (w >> 2);                      // schedule lane: the wave, or its slot
+  const int gate = GS == 1 ? 0 : (w & 3);                     // gate split: wave w of a slot sits on SIMD w & 3 and owns that gate
   const bool rev = dir == 1;
   const unsigned vlane = lane * 16;
 
@@ -95,9 +107,14 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     v4f* dst = reinterpret_cast<v4f*>(smem);
     for (int i = threadIdx.x; i < QPS * 4 * 64; i += NW * 64) dst[i] = src[i];
   }
+  // gate split: behind the weight slice, per slot two parities of four 1-KiB gate records, then one counter per slot
+  char* const xch = smem + QPS * 4096;
+  unsigned* const xcnt = reinterpret_cast<unsigned*>(xch + NWS * 2 * 4 * 1024);
+  if (GS > 1 && threadIdx.x < NWS) xcnt[threadIdx.x] = 0;
   __syncthreads();
   const char* const lds_rd = smem + lane * 16;
   auto rec = [&](int q, int j) { return *reinterpret_cast<const v4f*>(lds_rd + (q * 4 + j) * 1024); };
+  auto rec1 = [&](int q, int j) { return *reinterpret_cast<const float*>(lds_rd + (q * 4 + j) * 1024 + 4 * gate); };   // my gate's A operand
 
   const unsigned st0 = (unsigned)(p.src0.st * 4), sto = (unsigned)(p.out_st * 4), stk = SUM ? (unsigned)(p.skip.st * 4) : 0u;
   const unsigned st2 = CAT ? (unsigned)(p.src2.st * 4) : 0u;
@@ -154,7 +171,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     return make_rsrc(reinterpret_cast<const char*>(p.cscratch) + ((size_t)dir * (p.ntasks + 16) + task) * (NS * 1024));
   };
 
-  if (g0 + w >= g1) return;                                   // (a wave without a group: nobody waits for it)
+  if (g0 + ws >= g1) return;                                  // (a wave / slot without a group: nobody waits for it)
   unsigned long long clk0 = 0, rt0 = 0;                       // ablation twin, bit 512: the shader clock this kernel really runs at
   if (ABLRT && (ABL & 512)) {
     clk0 = __builtin_amdgcn_s_memtime();
@@ -164,7 +181,8 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   // bounded wait for `ready()`; refreshes through `reload()`; false = gave up
   auto bounded_wait = [&](auto ready, auto reload, int sleep, unsigned code) {
     for (unsigned spins = 0; !ready(); ++spins) {
-      if (sleep == 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(16);
+      // (gate split = the one-group-per-cluster regime: every step waits for its hand-off, so poll closely)
+      if (GS > 1) __builtin_amdgcn_s_sleep(1); else if (sleep == 8) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(16);
       reload();
       const bool out = spins > cp.spin_limit;
       if (out || (spins & 63) == 63) {
@@ -183,9 +201,9 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   // fullest SIMD 56.25 group-steps per step instead of 57 (1.3 %).  A group's state lives in memory (h in the output tensor,
   // c in the scratch area, both read past the L1), so which wave of the member takes it is free.
   const int NGR = g1 - g0;
-  const bool rot = cp.rotate && NGR >= 2 * NW;
-  const int FULL = rot ? (NGR / NW) * NW : NGR, LEFT = NGR - FULL;
-  const bool single = g0 + w + NW >= g1;                      // one group per wave: its c_t is not written yet when the next
+  const bool rot = cp.rotate && NGR >= 2 * NWS;
+  const int FULL = rot ? (NGR / NWS) * NWS : NGR, LEFT = NGR - FULL;
+  const bool single = GS == 1 && g0 + ws + NWS >= g1;                      // one group per wave: its c_t is not written yet when the next
                                                               // group-step's requests go out, so c is requested at the top
   Grp cur, nxt;
   rsrc_t rx0, ro, rsk, ro2, rx2, nrx0, nro, nrsk, nro2, nrx2;
@@ -203,13 +221,14 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     if (gr.step > 0 || cy) {
       if (gr.step > 0 && !(ABL & 256))
         tagv = __hip_atomic_load(tag_cl + (size_t)(gr.task - g0) * NS + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (with_c && !(ABL & 64)) cprev = bld4_l2(rc_of(gr.task), vlane, m * 1024);
+      if (GS == 1 && with_c && !(ABL & 64)) cprev = bld4_l2(rc_of(gr.task), vlane, m * 1024);
     }
-    if (DRIFT > 0 && !(ABL & 256) && gr.task - DRIFT * NW >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
-      tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NW - g0) * NS + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (DRIFT > 0 && !(ABL & 256) && gr.task - DRIFT * NWS >= g0)   // the members stay within DRIFT group-steps of each other (see fetch_h)
+      tagd = __hip_atomic_load(tag_cl + (size_t)(gr.task - DRIFT * NWS - g0) * NS + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  cur.task = g0 + w;
+  cur.task = g0 + ws;
   cur.step = 0;
+  unsigned iter = 0;                                          // gate split: group-steps this slot has finished
   const int qo_first = (cur.task * 16) / p.q_inner, qi_first = cur.task * 16 - qo_first * p.q_inner;
   int qo0 = qo_first, qi0 = qi_first;                         // (qo, qi) of the first sequence of the NEXT group to locate
   locate(cur.task, qo0, qi0, cur, rx0, ro, rsk, ro2, rx2);
@@ -226,15 +245,16 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     if (single && (step > 0 || cy) && !(ABL & 64)) cprev = bld4_l2(rc, vlane, m * 1024);
     // (a leftover group's c_{t-1} was written by ANOTHER wave of this member, which may be behind: it is loaded in fetch_h,
     //  once the tags show that every member — this one included — has finished the group's previous step)
-    const bool late_c = task >= g0 + FULL;
+    // (gate split: c_{t-1} was written by the slot's gate-0 wave — same rule for every group)
+    const bool late_c = GS > 1 || task >= g0 + FULL;
     v4f cprev_cur = (step > 0 || cy) ? cprev : zero4;
     const v4f skip_cur = skipv;
 
     // h_{step - 1} of the whole row: every member's slice, once all NS tags show it
     v4f hold[NS];
     auto fetch_h = [&]() {
-      if (DRIFT > 0 && !(ABL & 4) && !dead && task - DRIFT * NW >= g0) {
-        unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NW - g0) * NS;
+      if (DRIFT > 0 && !(ABL & 4) && !dead && task - DRIFT * NWS >= g0) {
+        unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NWS - g0) * NS;
         dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagd < (unsigned)step + 1) == 0; },
                              [&]() { tagd = __hip_atomic_load(tag_d + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 8, 0x40000u);
       }
@@ -254,14 +274,32 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     // ---- matrix phase: record j of quad Q + 1 is read from LDS right after the MFMAs that used record j of quad Q
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(2);
     v4f acc[4];
-    acc[0] = rec(0, 0);
-    acc[1] = rec(0, 1);
-    acc[2] = rec(0, 2);
-    acc[3] = rec(0, 3);
     v4f ra[4];
-    static_for<4>([&](auto j) { ra[j.value] = rec(1, j.value); });
+    v4f acc1 = zero4;                                          // gate split: my gate's accumulator
+    float rb[4] = {0.f, 0.f, 0.f, 0.f};                        // ... and its A operands of the next quad
+    if constexpr (GS == 1) {
+      acc[0] = rec(0, 0);
+      acc[1] = rec(0, 1);
+      acc[2] = rec(0, 2);
+      acc[3] = rec(0, 3);
+      static_for<4>([&](auto j) { ra[j.value] = rec(1, j.value); });
+    } else {
+      acc1 = rec(0, gate);
+      static_for<4>([&](auto j) { rb[j.value] = rec1(1, j.value); });
+    }
     auto quad = [&](auto qc, float b0, float b1, float b2, float b3) {
       constexpr int Q = decltype(qc)::value;
+      if constexpr (GS > 1) {   // one gate: the chain MFMA4 runs for component `gate`, record by record
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[0], b0, acc1, 0, 0, 0);
+        if constexpr (Q + 1 < QPS) rb[0] = rec1(Q + 1, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[1], b1, acc1, 0, 0, 0);
+        if constexpr (Q + 1 < QPS) rb[1] = rec1(Q + 1, 1);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[2], b2, acc1, 0, 0, 0);
+        if constexpr (Q + 1 < QPS) rb[2] = rec1(Q + 1, 2);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[3], b3, acc1, 0, 0, 0);
+        if constexpr (Q + 1 < QPS) rb[3] = rec1(Q + 1, 3);
+        return;
+      }
       // (the fences pin each LDS read right behind the MFMAs that used its register — 12 MFMAs before its own use; left
       //  alone the scheduler sinks the reads next to their uses and every second MFMA group waits out an LDS round trip)
       MFMA4(acc, ra[0], b0);
@@ -283,6 +321,11 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     };
     auto quad1 = [&](auto qc, float b0) {   // remainder quad: one record
       constexpr int Q = decltype(qc)::value;
+      if constexpr (GS > 1) {
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[0], b0, acc1, 0, 0, 0);
+        if constexpr (Q + 1 < QPS) static_for<4>([&](auto j) { rb[j.value] = rec1(Q + 1, j.value); });
+        return;
+      }
       MFMA4(acc, ra[0], b0);
       if constexpr (Q + 1 < QPS) static_for<4>([&](auto j) { ra[j.value] = rec(Q + 1, j.value); });
     };
@@ -305,17 +348,17 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     }
     // ---- the next group-step: where it is, and its early requests (the input ring is free now)
     bool seq_next = false;                                      // the next group is this one + NW (incremental addressing)
-    if (task < g0 + FULL && task + NW < g0 + FULL) {
-      nxt.task = task + NW;
+    if (task < g0 + FULL && task + NWS < g0 + FULL) {
+      nxt.task = task + NWS;
       nxt.step = step;
       seq_next = true;
     } else {
-      const int j = (w - step) & (NW - 1);                      // (NW is a power of two when rot; LEFT = 0 otherwise)
+      const int j = (ws - step) & (NWS - 1);                    // (NWS is a power of two; LEFT = 0 unless rot)
       if (task < g0 + FULL && j < LEFT) {
         nxt.task = g0 + FULL + j;
         nxt.step = step;
       } else {
-        nxt.task = g0 + w;
+        nxt.task = g0 + ws;
         nxt.step = step + 1;
       }
     }
@@ -330,7 +373,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
         }
       } else {
         if (seq_next) {                                       // next group of this wave: 16 NW sequences further
-          qi0 += 16 * NW;
+          qi0 += 16 * NWS;
           while (qi0 >= p.q_inner) {
             qi0 -= p.q_inner;
             ++qo0;
@@ -359,10 +402,39 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
       cn = acc[1] + cprev_cur + acc[0];
       hn = acc[3] + acc[2];
     } else {
-      const v4f ig = sigmoid4(acc[0]);
-      const v4f fg = sigmoid4(acc[1]);
-      const v4f gg = tanh4(acc[2]);
-      const v4f og = sigmoid4(acc[3]);
+      v4f ig, fg, gg, og;
+      if constexpr (GS == 1) {
+        ig = sigmoid4(acc[0]);
+        fg = sigmoid4(acc[1]);
+        gg = tanh4(acc[2]);
+        og = sigmoid4(acc[3]);
+      } else {
+        // my gate, activated -> LDS (parity of the slot's group-step count); counter += 1; wait for all four; read the row.
+        // Double buffering is enough: a wave that writes group-step i + 2's record has passed the wait of i + 1, for which
+        // every sibling had written i + 1's — i.e. had finished reading i's.
+        const v4f act = gate == 2 ? tanh4(acc1) : sigmoid4(acc1);
+        v4f* const xb = reinterpret_cast<v4f*>(xch + (size_t)((ws * 2 + (int)(iter & 1u)) * 4) * 1024);
+        xb[gate * 64 + lane] = act;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(xcnt + ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned want = 4u * (iter + 1u);
+        for (unsigned spins = 0;; ++spins) {
+          if (__hip_atomic_load(xcnt + ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+          // a sibling that gave up on a hand-off (or saw the launch draining) never arrives: follow it out
+          if (dead || ((spins & 63u) == 63u && __hip_atomic_load(cp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+              spins > cp.spin_limit) {
+            dead = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        ig = xb[lane];
+        fg = xb[64 + lane];
+        gg = xb[128 + lane];
+        og = xb[192 + lane];
+        ++iter;
+      }
       cn = cell4(fg, cprev_cur, ig, gg);
       hn = mul_rn4(og, tanh4(cn));
       if constexpr (SAVE) {   // what lstm_bwd_kernel reads back (lstm_kernel.h: reserve layout), my slice of this group and step
@@ -378,13 +450,17 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     }
     asm("" : "+v"(hn.x), "+v"(hn.y), "+v"(hn.z), "+v"(hn.w));   // h + skip adds the ROUNDED h
     if (ABL & 32) asm volatile("" ::"v"(cn), "v"(hn));
-    if (!(ABL & 32)) bst4(cn, rc, vlane, m * 1024);
-    if (cur.valid && !(ABL & 32)) {
+    const bool storer = GS == 1 || gate == 0;                   // gate split: all four waves hold c_t and h_t, one stores
+    if (storer && !(ABL & 32)) bst4(cn, rc, vlane, m * 1024);
+    if (storer && cur.valid && !(ABL & 32)) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, hn), ro, cur.voo, oo + 64 * m, 16);   // sc1: the hand-off
       if (SUM) bst4(add_rn4(hn, skip_cur), ro2, cur.voo2, oo + 64 * m);
     }
     pub_val = __builtin_amdgcn_readfirstlane((unsigned)step + 1);   // (wave-uniform: lives in an SGPR until the store)
-    pub_tag = (ABL & 256) ? nullptr : tag_g + m;
+    pub_tag = ((ABL & 256) || !storer) ? nullptr : tag_g + m;
+    // gate split: the slot's only group waits for this very hand-off at its next step — publish now, not in the middle of
+    // the next input part (the deferral hides the drain behind OTHER groups' work, of which there is none here)
+    if constexpr (GS > 1) pub_flush();
     if (!more || dead) break;
     cur = nxt;
     rx0 = nrx0;
@@ -402,12 +478,13 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   }
 }
 
-template <int HH, int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves>
+template <int HH, int NV0, int NS0, int MODE, bool ABLRT = false, int DRIFT = 2, int NW_ = kF32cWaves, int GS = 1>
 int launch_f32c_k(const LstmParams& p, const F32ClusterParams& cp, hipStream_t st) {
   constexpr int NS = HH / 16;
   constexpr int QPS = 1 + NV0 + NS0 + NS;
-  const size_t lds = (size_t)QPS * 4096;
-  auto k = lstm_f32c_kernel<HH, NV0, NS0, MODE, ABLRT, DRIFT, NW_>;
+  const size_t lds = (size_t)QPS * 4096 + (GS > 1 ? (size_t)(NW_ / GS) * 8192 + 64 : 0);   // + the slots' gate records and counters
+  static_assert(QPS * 4096 + (GS > 1 ? (NW_ / GS) * 8192 + 64 : 0) <= 160 * 1024, "LDS");
+  auto k = lstm_f32c_kernel<HH, NV0, NS0, MODE, ABLRT, DRIFT, NW_, GS>;
   if (lds > 48 * 1024)
     FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int ncl = cp.clusters_per_dir * p.ndir;

@@ -15,9 +15,9 @@ constexpr int kF32cWavesH256 = 8;   // H = 256: two waves per SIMD (the row of h
 //            0.8 MB matrix from L2 per group and step, here a step costs one member's matrix work plus a hand-off
 //            (one 4-mic utterance: 25.1 -> 11.7 ms for the three layers; 4 utterances: 40.3 -> 30.1; from 16 utterances on
 //            it was the cluster kernel already: tools/latency_bench.py, profiles/r05/);
-//   H = 256: the online model's narrow-band layers (clusters of 16) while the launch is SMALL (up to 6 groups per CU, where
-//            the 4-waves-per-group kernels ran until round 4); full-chip launches stay on lstm_static3_kernel's rounds
-//            (0.89 of the roof: a wave that owns its groups for the whole recurrence needs no hand-off at all).
+//   H = 256: the online model's narrow-band layers (clusters of 16) below the full-chip size; full-chip launches stay on
+//            lstm_static3_kernel's rounds (0.89 of the roof: a wave that owns its groups for the whole recurrence needs no
+//            hand-off at all).
 // every tensor of the call has its sequences evenly spaced: sequence q at q * si
 static bool f32c_uniform(const LstmParams& p, int mode) {
   auto even = [&](long long so, long long si) { return si >= 0 && so == (long long)p.q_inner * si; };
@@ -57,10 +57,10 @@ bool f32c_handles(const LstmParams& p, int H, int mode) {
   // which the 2-waves-per-group kernels run as 3 wave-times for 2.34 (0.52 of the roof), while here the groups beyond two
   // per wave rotate over the waves step by step (lstm_f32c.h): balanced over the launch
   if (p.reserve) return !fnssl::tune(FNSSL_TUNE_TRAIN_NO_F32_CLUSTER) && groups >= 2LL * kF32cWaves * (ncu / 8);
-  if (H == 256) {
-    const int s4 = fnssl::tune(FNSSL_TUNE_SPLIT4_MAX_H256, 1, 64) ? fnssl::tune(FNSSL_TUNE_SPLIT4_MAX_H256, 1, 64) : 6;
-    return groups <= (long long)s4 * ncu;
-  }
+  // H = 256: everything below the full-chip launch (12 groups per CU: lstm_static3_kernel's one round of 12 waves per CU, 0.89
+  // of the roof) — in between the rounds are paced by their fullest SIMD (9 groups per CU = 3, 2, 2, 2 waves per SIMD), the
+  // cluster's groups are work items that balance (16 utterances: 202 -> 176 ms for the three layers, 0.84 of the roof)
+  if (H == 256) return groups < 12LL * ncu;
   return !fnssl::tune(FNSSL_TUNE_NO_F32_SMALL) || groups >= 12LL * ncu;
 }
 
@@ -79,12 +79,31 @@ int forward_f32c(LstmParams p, int H, int mode, hipStream_t st) {
   cp.prio_mode = fnssl::tune(FNSSL_TUNE_F32C_PRIO, 9, 9) ? 0 : 2;   // see F32ClusterParams
   const size_t tag_bytes = (size_t)p.ndir * cp.clusters_per_dir * cp.groups_per_cluster * members * sizeof(unsigned);
   if (!p.dry) FNSSL_HIP(hipMemsetAsync(p.cluster_ws, 0, 256 + tag_bytes, st));
+  // Gate split (lstm_f32c.h): only with ONE group per cluster (one 2-mic utterance, the full-band layers of a streaming
+  // chunk) — there a step is the group's own matrix work plus its hand-off, and four SIMDs share the former.  With more
+  // groups the waves that each own a group hide one another's hand-off latency, which two (four) slots working through
+  // their groups one by one do not: measured at 6 - 8 groups per cluster 42.0 against 26.8 ms per 4-mic utterance, at 1 - 2
+  // groups (2-mic, 300 frames) the H = 128 layers 5.9 against 5.4 ms; at one group 9.75 against 12.7 ms per utterance and
+  // 3.7 against 5.2 ms per 12-frame chunk (profiles/r05/).
+  const int gs_knob = fnssl::tune(FNSSL_TUNE_F32C_GATE_SPLIT, 1, 4);
+  const bool gsplit = gs_knob ? gs_knob == 4 : cp.groups_per_cluster <= 1;
   if (H == 256) {
     constexpr int W = kF32cWavesH256;
+    if (gsplit) {
+      if (mode == (kHas2 | kSum)) return launch_f32c_k<256, 16, 1, kHas2 | kSum, false, 2, W, 4>(p, cp, st);
+      if (mode == kHas2) return launch_f32c_k<256, 16, 1, kHas2, false, 2, W, 4>(p, cp, st);
+      if (mode == kSum) return launch_f32c_k<256, 16, 0, kSum, false, 2, W, 4>(p, cp, st);
+      return launch_f32c_k<256, 16, 0, 0, false, 2, W, 4>(p, cp, st);
+    }
     if (mode == (kHas2 | kSum)) return launch_f32c_k<256, 16, 1, kHas2 | kSum, false, 2, W>(p, cp, st);
     if (mode == kHas2) return launch_f32c_k<256, 16, 1, kHas2, false, 2, W>(p, cp, st);
     if (mode == kSum) return launch_f32c_k<256, 16, 0, kSum, false, 2, W>(p, cp, st);
     return launch_f32c_k<256, 16, 0, 0, false, 2, W>(p, cp, st);
+  }
+  if (gsplit && !p.reserve) {
+    if (p.c0 == 4) return launch_f32c_k<128, 0, 1, 0, false, 2, kF32cWaves, 4>(p, cp, st);
+    if (mode == kSum) return launch_f32c_k<128, 16, 0, kSum, false, 2, kF32cWaves, 4>(p, cp, st);
+    return launch_f32c_k<128, 16, 0, 0, false, 2, kF32cWaves, 4>(p, cp, st);
   }
 #ifdef FNSSL_BUILD_ABLATE   // timing ablations (wrong results): make ABLATE=1 only
   if (const int abl = env_int("FNSSL_F32C_ABL", 1, 1023)) {

@@ -78,10 +78,11 @@ const char* const kTuneNames[] = {
     "CLUSTER_TEST_STALL",
     "RESERVED_CUS",
     "NO_F32_SMALL",
-    "F32C_MIN_GROUPS"};
+    "F32C_MIN_GROUPS",
+    "F32C_GATE_SPLIT"};
 constexpr int kTuneNamed = (int)(sizeof(kTuneNames) / sizeof(kTuneNames[0]));
 static_assert(kTuneNamed <= FNSSL_TUNE_COUNT, "more knob names than slots");
-static_assert(kTuneNamed == FNSSL_TUNE_F32C_MIN_GROUPS + 1, "knob names out of step with include/fnssl.h");
+static_assert(kTuneNamed == FNSSL_TUNE_F32C_GATE_SPLIT + 1, "knob names out of step with include/fnssl.h");
 }  // namespace
 
 const fnssl_tuning& tuning() {
@@ -168,9 +169,12 @@ extern "C" int fnssl_tuning_get(fnssl_tuning* t) {
 namespace {
 // What another tenant's persistent kernels do to the CUs (RCCL's all-reduce kernels under an overlapped backward): each
 // workgroup claims `lds` bytes of LDS (160 KiB = the whole CU) and idles until *stop != 0 or the time limit.
-__global__ void __launch_bounds__(64) occupy_kernel(const unsigned* stop, long long max_ticks) {
+__global__ void __launch_bounds__(64) occupy_kernel(unsigned* stop, long long max_ticks) {
   extern __shared__ char occ_smem[];
-  if (threadIdx.x == 0) occ_smem[0] = 1;   // the allocation is real
+  if (threadIdx.x == 0) {
+    occ_smem[0] = 1;   // the allocation is real
+    if (stop) __hip_atomic_store(stop + 1 + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // "I am resident"
+  }
   const long long t0 = (long long)wall_clock64();
   while ((long long)wall_clock64() - t0 < max_ticks) {
     if (stop && __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
@@ -179,7 +183,7 @@ __global__ void __launch_bounds__(64) occupy_kernel(const unsigned* stop, long l
 }
 }  // namespace
 
-extern "C" int fnssl_occupy_cus(int nblocks, int lds_bytes, const unsigned* stop, int max_ms, void* stream) {
+extern "C" int fnssl_occupy_cus(int nblocks, int lds_bytes, unsigned* stop, int max_ms, void* stream) {
   FNSSL_REQUIRE(nblocks > 0 && nblocks <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && max_ms > 0 && max_ms <= 60000,
                 "occupy_cus: nblocks %d, lds %d B, limit %d ms", nblocks, lds_bytes, max_ms);
   if (lds_bytes > 48 * 1024)

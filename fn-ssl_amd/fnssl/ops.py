@@ -319,6 +319,7 @@ def _conform(t):
 
 _ws_cache = {}
 _fb_counters = {}
+_fb_nets = None      # weak set of DeviceNet objects (each owns the counter its fnssl_net hands to the library)
 
 
 def fallback_counter(device):
@@ -338,12 +339,20 @@ def fallback_counter(device):
 
 
 def cluster_fallbacks(device=None, reset: bool = False) -> int:
-    """Value of ``fallback_counter(device)`` (SYNCHRONISES the device: measurement code calls it outside timed regions)."""
-    c = fallback_counter(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
-    n = int(c.item())
+    """Fallbacks counted on ``device`` so far: ``fallback_counter(device)`` plus the counters of the live ``DeviceNet``s
+    (SYNCHRONISES the device: measurement code calls it outside timed regions).  ``reset``: zero them afterwards."""
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    cs = [fallback_counter(device)] + [n.fallbacks for n in (_fb_nets or ()) if n.device == device or
+                                       (n.device.index is None and device.index == torch.cuda.current_device())]
+    total = sum(int(c.item()) for c in cs)
     if reset:
-        c.zero_()
-    return n
+        for c in cs:
+            c.zero_()
+        for n in (_fb_nets or ()):
+            n._fb_seen = 0
+    return total
 
 
 
@@ -820,7 +829,12 @@ class DeviceNet:
         # layers whose cluster-resident kernel gave up on a hand-off and were recomputed by the guarded fallback kernels of
         # the same call (fnssl_lstm_forward): counted on the device, read back asynchronously (4 bytes per forward, no
         # synchronisation) and reported one forward later as a RuntimeWarning — results are correct either way
-        self.fallbacks = fallback_counter(self.device) if self.device.type == "cuda" else torch.zeros(1, dtype=torch.int32)
+        self.fallbacks = torch.zeros(1, dtype=torch.int32, device=self.device)
+        global _fb_nets
+        if _fb_nets is None:
+            import weakref
+            _fb_nets = weakref.WeakSet()
+        _fb_nets.add(self)
         self._fb_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else None
         self._fb_event, self._fb_seen = None, 0
         net.fallback_count = self.fallbacks.data_ptr()
@@ -876,8 +890,11 @@ class DeviceNet:
 @on_device
 def occupy_cus(nblocks: int, stop, max_ms: int = 2000, lds_bytes: int = 160 * 1024, stream=None):
     """Diagnostic (fnssl_occupy_cus): ``nblocks`` workgroups, each holding ``lds_bytes`` of LDS (default: a whole CU), idle on
-    ``stream`` (default: the current one) until ``stop[0]`` (an int32 tensor in pinned host or device memory) is non-zero or
-    ``max_ms`` pass — what RCCL's persistent all-reduce kernels do to the CUs under an overlapped backward."""
+    ``stream`` (default: the current one) until ``stop[0]`` is non-zero or ``max_ms`` pass — what RCCL's persistent all-reduce
+    kernels do to the CUs under an overlapped backward.  ``stop``: int32 tensor of 1 + nblocks words in pinned host (or
+    device) memory, zeroed by the caller; workgroup b sets ``stop[1 + b]`` when it has become resident."""
+    if stop.dtype != torch.int32 or stop.numel() < 1 + int(nblocks):
+        raise RuntimeError("fnssl.occupy_cus: stop must hold 1 + nblocks int32 words")
     s = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
     check(_lib.load().fnssl_occupy_cus(int(nblocks), int(lds_bytes), C.c_void_p(stop.data_ptr()), int(max_ms), s), "occupy_cus")
 

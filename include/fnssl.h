@@ -94,6 +94,7 @@ const char* fnssl_last_error(void);
 #define FNSSL_TUNE_RESERVED_CUS 36            /* compute units the caller keeps busy with other work (RCCL's all-reduce kernels under an overlapped backward): the cluster-resident kernels size their co-resident grids for device CUs minus this */
 #define FNSSL_TUNE_NO_F32_SMALL 37            /* few-sequence fp32 launches (one utterance, a streaming chunk) on the split kernels instead of the slice-resident cluster kernel (lstm_f32s.h) */
 #define FNSSL_TUNE_F32C_MIN_GROUPS 38        /* smallest (groups x directions) count the fp32 cluster kernels take for inference (default: see lstm_f32c.hip) */
+#define FNSSL_TUNE_F32C_GATE_SPLIT 39        /* fp32 cluster kernels: 1 = every wave owns a group, 4 = the four waves of a slot share one (one gate each); default: by groups per cluster */
 #define FNSSL_TUNE_COUNT 48               /* room for more without changing the struct */
 
 typedef struct fnssl_tuning {
@@ -112,10 +113,11 @@ int fnssl_tuning_get(fnssl_tuning* t);
 const char* fnssl_tuning_name(int index);
 
 /* Diagnostic (tests of the cluster kernels' co-residency): `nblocks` workgroups of 64 threads, each claiming `lds_bytes`
- * of LDS (160 KiB = a whole CU), idle on `stream` until *stop (DEVICE-visible word, e.g. pinned host memory; may be
- * NULL) is non-zero or `max_ms` have passed — what RCCL's persistent all-reduce kernels do to the CUs while the
- * backward pass they overlap with runs.  Returns at once; never synchronises. */
-int fnssl_occupy_cus(int nblocks, int lds_bytes, const unsigned* stop, int max_ms, void* stream);
+ * of LDS (160 KiB = a whole CU), idle on `stream` until stop[0] is non-zero or `max_ms` have passed — what RCCL's
+ * persistent all-reduce kernels do to the CUs while the backward pass they overlap with runs.  `stop` (may be NULL):
+ * 1 + nblocks DEVICE-visible words (e.g. pinned host memory), zeroed by the caller; workgroup b stores 1 to stop[1 + b]
+ * when it has become resident.  Returns at once; never synchronises. */
+int fnssl_occupy_cus(int nblocks, int lds_bytes, unsigned* stop, int max_ms, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Front end                                                                 */

@@ -1245,7 +1245,7 @@ def test_few_sequence_launches_take_the_slice_resident_cluster_kernel_and_equal_
         r = ops.lstm_layer(mode, x0, None, x2, w, H, out, skip=skip, out_sum=osum, plan_only=plan)
         return r if plan else (out, osum)
 
-    for k in ("FNSSL_NO_F32_SMALL", "FNSSL_NO_F32_CLUSTER"):
+    for k in ("FNSSL_NO_F32_SMALL", "FNSSL_NO_F32_CLUSTER", "FNSSL_F32C_GATE_SPLIT"):
         monkeypatch.delenv(k, raising=False)
     ops.cluster_fallbacks(dev, reset=True)
     assert run(plan=True) == ("f32_cluster", 1), run(plan=True)
@@ -1253,6 +1253,18 @@ def test_few_sequence_launches_take_the_slice_resident_cluster_kernel_and_equal_
     a2, _ = run()
     with torch.cuda.device(dev):
         assert ops.lstm_cluster_status(nb * (nt if mode == "full" else nf), H, ndir, dev) == 0
+    # both work distributions of the cluster kernel: every wave owns a group / the four waves of a slot share one (one gate
+    # each, activated gates exchanged through LDS) — the default picks by groups per cluster
+    for gs in ("1", "4"):
+        monkeypatch.setenv("FNSSL_F32C_GATE_SPLIT", gs)
+        assert run(plan=True) == ("f32_cluster", 1)
+        g_out, g_sum = run()
+        assert torch.equal(g_out, a), "gate split %s differs from the default" % gs
+        if summed:
+            assert torch.equal(g_sum, asum)
+        with torch.cuda.device(dev):
+            assert ops.lstm_cluster_status(nb * (nt if mode == "full" else nf), H, ndir, dev) == 0
+    monkeypatch.delenv("FNSSL_F32C_GATE_SPLIT")
     assert ops.cluster_fallbacks(dev) == 0
     monkeypatch.setenv("FNSSL_NO_F32_SMALL", "1")
     fam, _ = run(plan=True)
@@ -1524,8 +1536,8 @@ def test_timing_select_brackets_one_kernel_name(dev):
 
 
 def test_forward_survives_a_cluster_member_that_never_shows_up(dev, monkeypatch):
-    """Product path (DeviceNet.forward -> fnssl_forward): with one member workgroup of the cluster-resident full-band kernel
-    missing (FNSSL_CLUSTER_TEST_STALL), the forward neither raises nor dies, returns the SAME output, counts the three
+    """Product path (DeviceNet.forward -> fnssl_forward): with one member workgroup of the cluster-resident kernels
+    missing (FNSSL_CLUSTER_TEST_STALL), the forward neither raises nor dies, returns the SAME output, counts the
     recomputed layers in the device counter handed down through fnssl_net.fallback_count, and reports them — one forward
     later, from the 4-byte asynchronous read-back — as a RuntimeWarning."""
     import warnings
@@ -1546,7 +1558,9 @@ def test_forward_survives_a_cluster_member_that_never_shows_up(dev, monkeypatch)
     got = net.forward(x0)
     torch.cuda.synchronize(dev)
     assert torch.equal(got, want), "the forward's result changed when a cluster member went missing"
-    assert int(net.fallbacks.item()) == 3, "three full-band layers should have been recomputed, counted %d" % int(net.fallbacks.item())
+    # all six layers take the cluster-resident kernel at this size since round 5 (96 x 256 narrow-band sequences = 1536
+    # groups = 6 per CU: clusters of 16), and member 5 of cluster 0 is missing in each of them
+    assert int(net.fallbacks.item()) == 6, "six layers should have been recomputed, counted %d" % int(net.fallbacks.item())
     monkeypatch.delenv("FNSSL_CLUSTER_TEST_STALL")
     monkeypatch.delenv("FNSSL_CLUSTER_SPIN_LIMIT")
     with warnings.catch_warnings(record=True) as rec:
@@ -1554,6 +1568,6 @@ def test_forward_survives_a_cluster_member_that_never_shows_up(dev, monkeypatch)
         again = net.forward(x0)
         torch.cuda.synchronize(dev)
     assert any(issubclass(r.category, RuntimeWarning) and "recomputed" in str(r.message) for r in rec), [str(r.message) for r in rec]
-    assert torch.equal(again, want) and int(net.fallbacks.item()) == 3
+    assert torch.equal(again, want) and int(net.fallbacks.item()) == 6
     ops.release_workspaces()
     torch.cuda.empty_cache()

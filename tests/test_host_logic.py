@@ -458,3 +458,21 @@ def test_library_reads_no_environment_and_tuning_is_explicit(monkeypatch):
         assert back.knob[declared["BWD_NO_CLUSTER"]] == 1
     lib.fnssl_tuning_get(C.byref(back))
     assert back.knob[declared["BWD_NO_CLUSTER"]] == 0
+
+
+def test_engine_reserves_compute_units_for_rccl_only_when_there_is_an_exchange():
+    """TrainEngine._backward_tuning: world 1 -> the process default (None); world > 1 (or reserve_always) -> a per-call
+    fnssl_tuning with RESERVED_CUS on top of the current knobs, for the BACKWARD's LSTM calls only (the forward never overlaps
+    the gradient all-reduce)."""
+    from fnssl import _lib, train
+    _lib.load()
+    eng = train.TrainEngine.__new__(train.TrainEngine)
+    eng.pg, eng.reserved_cus, eng.reserve_always = False, 16, False
+    assert eng._backward_tuning() is None
+    eng.reserve_always = True
+    with _lib.tuning(no_bwd2=1):
+        t = eng._backward_tuning()
+    names = _lib.tuning_names()
+    assert t.knob[names["RESERVED_CUS"]] == 16 and t.knob[names["NO_BWD2"]] == 1
+    eng.reserved_cus = 0
+    assert eng._backward_tuning() is None

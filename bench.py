@@ -17,8 +17,11 @@ per-GPU batch (weak scaling; utterances are independent: no data-path collective
 all-reduce) — or, with --scaling strong (config 2), an even share of the configuration's GLOBAL batch, and the line
 then carries `strong_scaling.efficiency` against one rank running the whole batch in the same run.  K steps are timed
 between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line whose `value` is utterance-frames per second
-over all ranks.  The default run (no flags) nests config 2's 'M' pairing and is_online=False variants ("2M", "2off") and
-configs 3, 4, 5 under `other_configs`, each with its own roofline / cpu_baseline / parity.  The line also carries
+over all ranks.  The default run (no flags) nests config 2's 'M' pairing and is_online=False variants ("2M", "2off"), the
+reference's real predict shape — ONE 4-mic utterance, whole ("2b1") and streamed in 12-frame chunks ("2s") — and configs
+3, 4, 5 under `other_configs`, each with its own roofline / cpu_baseline / parity.  Every line carries `cluster_fallbacks`
+(LSTM launches of the timed region whose cluster-resident kernel gave up and were recomputed by the guarded fallback
+kernels: must be 0, else `value` is null) and `peak_mem_gb` (of that configuration alone).  The line also carries
   ab           : same-process A/B legs run AFTER the timed region (A = the shipped default, B = an environment knob that
                  restores the previous kernels; alternating, a few steps each) — a box-independent record of what a
                  kernel change is worth; roofline.peak_measured = this device's own fp32-MFMA ceiling (fnssl_mfma_f32_peak);
@@ -161,19 +164,39 @@ class FnsslForward:
             (" [optional bf16 fast mode: NOT the BASELINE fp32 metric]" if args.bf16 else "")
         log("rank %d/%d on %s: %d utt x %d mics x %d frames, %d pairs" % (rank, world, torch.cuda.get_device_name(dev),
                                                                         self.nb, args.nch, self.nt, self.nb * self.n_pairs))
+        # --stream-chunk T ("2s"): the online model driven chunk by chunk (Model.FN_SSL.forward_stream: the state carry the
+        # reference's causality permits): a step = the NEXT T frames of every utterance, from the feature tensor
+        self.chunk = int(getattr(args, "stream_chunk", 0) or 0)
+        if self.chunk:
+            if not self.online or args.bf16 or self.chunk % 12:
+                raise SystemExit("--stream-chunk: online fp32 model, a multiple of 12 frames")
+            self.feat = ops.preprocess(self.batch.permute(0, 2, 1), args.ch_mode, 1e-6, layout=1)     # [nb*np, 4, 256, nt]
+            self.state, self.pos = None, 0
+            self.frames_per_step = self.nb * self.chunk
+            self.metric = "TF-frames/sec DP-IPD forward, streaming in %d-frame chunks (4-mic 257-bin)" % self.chunk
 
     def step(self):
+        if self.chunk:
+            if self.pos + self.chunk > self.nt:                       # next utterance: fresh state
+                self.state, self.pos = None, 0
+            y, self.state = self.model.arch.forward_stream(self.feat[..., self.pos:self.pos + self.chunk], self.state)
+            self.pos += self.chunk
+            return y
         return self.model.predict_step(self.batch, 0)
 
     def check(self, out):
-        assert tuple(out.shape) == (self.nb * self.n_pairs, self.nt // 12, 512) and bool(torch.isfinite(out).all())
+        nseg = (self.chunk or self.nt) // 12
+        assert tuple(out.shape) == (self.nb * self.n_pairs, nseg, 512) and bool(torch.isfinite(out).all())
 
     def config(self):
         a = self.args
         return {"workload": "BASELINE configs[1]: FN-SSL (%s) DP-IPD forward, waveform->STFT->features->"
                             "3x(full-band BiLSTM + narrow-band LSTM)->head; %d utterances/GPU x %d mics ('%s' = %d pairs) "
-                            "x 257 bins x %d frames, fp32; frame = one STFT frame of one utterance"
-                            % ("online" if self.online else "offline", self.nb, a.nch, a.ch_mode, self.n_pairs, self.nt),
+                            "x 257 bins x %d frames, fp32; frame = one STFT frame of one utterance%s"
+                            % ("online" if self.online else "offline", self.nb, a.nch, a.ch_mode, self.n_pairs, self.nt,
+                               ("; STREAMING: a step = the next %d frames from the feature tensor through FN_SSL.forward_stream "
+                                "(carried LSTM state), %d steps per utterance" % (self.chunk, self.nt // self.chunk)) if self.chunk else ""),
+                "stream_chunk_frames": self.chunk,
                 "utterances_per_gpu": self.nb, "global_batch": self.nb * self.world, "mics": a.nch,
                 "pairs_per_utterance": self.n_pairs, "frames": self.nt,
                 "bins": 257, "parallelism": "dp%d (utterance shards, no collective)" % self.world,
@@ -197,6 +220,13 @@ class FnsslForward:
         if not self.online:
             return kernel_roof(kern, "lstm_h128", "H = 128 layers (offline: every layer; full-band on the cluster-resident lstm_f32c_kernel, "
                                "narrow-band on lstm_static_kernel rounds)", PEAK_FP32_MFMA_TFLOPS)
+        if self.chunk:
+            return kernel_roof(kern, "lstm_h128", "lstm_f32c_kernel<H=128, gate split> (full-band BiLSTM: 256 serial steps per chunk, one "
+                               "16-sequence group per cluster of 8 CUs — latency-bound by the per-step hand-off, not by the matrix pipe)",
+                               PEAK_FP32_MFMA_TFLOPS)
+        if self.nb * self.n_pairs * 256 // 16 < 12 * 256:      # below the full-chip launch the narrow-band layers run lstm_f32c_kernel<256>
+            return kernel_roof(kern, "lstm_h256", "lstm_f32c_kernel<H=256> (narrow-band LSTM: hidden slices over clusters of 16 CUs, weight "
+                               "slice resident in LDS, groups as work items)", PEAK_FP32_MFMA_TFLOPS)
         if self.args.bf16:
             return kernel_roof(kern, "lstm_h256", "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
                                PEAK_BF16_MFMA_TFLOPS)
@@ -230,7 +260,16 @@ class FnsslForward:
                          % (a.cpu_utts, a.nch, cpu_frames, a.ch_mode, a.cpu_utts * self.n_pairs, cores, cdt)}
         # same-run parity gate on the same waveforms: the narrow-band LSTM is causal, the forgetting-norm recursive
         # and the full-band BiLSTM runs along frequency only, so a frame prefix is an exact sub-problem
-        got = self.model.predict_step(self.batch[:a.cpu_utts, :, :cns], 0).cpu()
+        if self.chunk:     # the same frames chunk by chunk: what the streaming steps of the timed region compute
+            feat = self.ops.preprocess(self.batch[:a.cpu_utts, :, :cns].permute(0, 2, 1), a.ch_mode, 1e-6, layout=1)
+            st, parts = None, []
+            for t0 in range(0, cpu_frames - cpu_frames % self.chunk, self.chunk):
+                y, st = self.model.arch.forward_stream(feat[..., t0:t0 + self.chunk], st)
+                parts.append(y)
+            got = torch.cat(parts, dim=1).cpu()
+            ref_out = ref_out[:, :got.shape[1]]
+        else:
+            got = self.model.predict_step(self.batch[:a.cpu_utts, :, :cns], 0).cpu()
         rt, at = (2e-2, 4e-3) if a.bf16 else (1e-4, 1e-5)
         return cpu, parity_of(got, ref_out, rt, at, "%d frames" % cpu_frames)
 
@@ -521,6 +560,8 @@ class Ipdnet2Forward:
                                  time_compression_layer=0, fre_compression_ratio=16, time_compression_ratio=5).eval()
         net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.sd.items()})
         self.fp32 = args.fp32
+        import copy
+        self.net32 = None if self.fp32 else copy.deepcopy(net).to(dev)    # the exact-fp32 kernels: the bf16 mode's yardstick
         self.net = net.to(dev) if self.fp32 else net.to(dev).bfloat16()   # bf16 parameters select FNSSL_PRECISION_BF16
         g = torch.Generator(device=dev)
         g.manual_seed(3000 + rank)
@@ -609,11 +650,33 @@ class Ipdnet2Forward:
                          "ipdnet2_forward: torch.stft, conv1d, layer_norm, matmul; the Mamba block = the published "
                          "algorithm with a python scan over frames, parity unpinned), fp32, %d threads, %.1f s"
                          % (frames, cores, cdt)}
-        got = self.net(self.ops.preprocess_ipdnet2(sig)).cpu()
-        # bf16: no reference exists — the fp32 CPU forward at a tolerance set from what bf16 operand rounding through
-        # 8 layers measures (1.2e-2 max, 2.2e-3 rms on outputs of rms 0.45; the fp32 kernels sit at 9e-7) plus ~8 % margin
-        rt, at = (1e-4, 5e-5) if self.fp32 else (2e-2, 1.3e-2)
-        return cpu, parity_of(got, want, rt, at, "%d frames vs the fp32 PyTorch CPU forward" % frames)
+        feats = self.ops.preprocess_ipdnet2(sig)
+        if self.fp32:
+            return cpu, parity_of(self.net(feats).cpu(), want, 1e-4, 5e-5, "%d frames vs the fp32 PyTorch CPU forward" % frames)
+        # bf16 (BASELINE config 5 as written; no reference of that precision exists).  Two statements on the sample:
+        #  (1) the SAME network on the exact-fp32 kernels against the fp32 CPU forward at the fp32 tolerance — this is what
+        #      holds the kernels' arithmetic to the restated reference;
+        #  (2) the bf16 mode against those fp32 kernels within a bound stated BEFORE measuring: operands rounded to bf16 carry
+        #      a relative error of at most u = 2^-9 each; through S = 4 products per layer x 8 layers of a residual network the
+        #      errors add like a random walk, rms <= u sqrt(S) of the outputs' rms (1.1 %); the largest of the sample's ~4e4
+        #      outputs lies within 6 sigma of that.  (Measured: rms 0.5 %, max 2.4 sigma.)
+        got32 = self.net32(feats).cpu()
+        par = parity_of(got32, want, 1e-4, 5e-5, "%d frames, fp32 kernels vs the fp32 PyTorch CPU forward" % frames)
+        got = self.net(feats).cpu()
+        u, stages = 2.0 ** -9, 4 * self.layers
+        out_rms = float(got32.pow(2).mean().sqrt())
+        rms_bound = u * stages ** 0.5 * out_rms
+        dev_ = (got - got32).abs()
+        rms, mx = float(dev_.pow(2).mean().sqrt()), float(dev_.max())
+        par["bf16_vs_fp32_kernels"] = {"rms": rms, "max": mx, "output_rms": out_rms, "rms_bound": rms_bound, "max_bound": 6.0 * rms_bound,
+                                       "bound": "u sqrt(S) x output rms, u = 2^-9 (bf16 operand rounding), S = 4 products x %d layers; "
+                                                "max within 6 sigma" % self.layers,
+                                       "ok": bool(rms <= rms_bound and mx <= 6.0 * rms_bound)}
+        par["max_abs_err_bf16_vs_cpu"] = float((got - want).abs().max())
+        par["ok"] = bool(par["ok"] and par["bf16_vs_fp32_kernels"]["ok"])
+        log("parity bf16 vs fp32 kernels: rms %.3g (bound %.3g), max %.3g (bound %.3g) ok=%s"
+            % (rms, rms_bound, mx, 6.0 * rms_bound, par["bf16_vs_fp32_kernels"]["ok"]))
+        return cpu, par
 
 
 WORKLOADS = {2: FnsslForward, 3: IpdnetForward, 4: FnsslTrain, 5: Ipdnet2Forward}
@@ -863,6 +926,8 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--ch-mode", default="MM")
     ap.add_argument("--chunk-pairs", type=int, default=0)
+    ap.add_argument("--stream-chunk", type=int, default=0,
+                    help="config 2: streaming inference, a step = the next N frames (multiple of 12) through FN_SSL.forward_stream")
     ap.add_argument("--offline", action="store_true", help="config 2: is_online=False (bidirectional narrow-band LSTM)")
     ap.add_argument("--bf16", action="store_true",
                     help="config 2, NOT the BASELINE metric: the optional fast mode (bf16 MFMA operands in the LSTMs, "
@@ -921,9 +986,9 @@ def main():
 
     others = args.other_configs
     plain = not (args.nb or args.offline or args.bf16 or args.frames != 300 or args.nch != 4 or args.ch_mode != "MM"
-                 or args.chunk_pairs) and args.scaling == "weak" and args.config == 2
+                 or args.chunk_pairs or args.stream_chunk) and args.scaling == "weak" and args.config == 2
     if others is None:
-        others = "2M,2off,3,4,5" if plain else ""
+        others = "2M,2off,2b1,2s,3,4,5" if plain else ""
     if args.ab_steps < 0:
         args.ab_steps = 3 if plain else 0
     if args.scaling == "strong" and args.config != 2:
@@ -935,19 +1000,24 @@ def main():
     for key in other_ids:
         # "2M" / "2off": SURVEY 8d's secondary reports of config 2 — 'M' pairing (np = 3) and is_online=False — as their
         # own nested lines (5 steps each, bounded CPU sample); "3" / "4" / "5": the other BASELINE configurations
-        variant = key if key in ("2M", "2off") else None
+        variant = key if key in ("2M", "2off", "2b1", "2s") else None
         c = 2 if variant else (int(key) if key.isdigit() else -1)
         if (c == args.config and not variant) or c not in WORKLOADS:
             continue
         sub = argparse.Namespace(**vars(args))
         sub.nb, sub.frames, sub.nch, sub.ch_mode, sub.chunk_pairs = 0, 300, 4, "MM", 0
         sub.offline = sub.bf16 = sub.c_step = False
-        sub.ab_steps, sub.scaling = 0, "weak"
+        sub.ab_steps, sub.scaling, sub.stream_chunk = 0, "weak", 0
         nsteps = max(1, min(args.steps, args.other_steps))
         if variant:
-            sub.ch_mode, sub.offline = ("M", False) if variant == "2M" else ("MM", True)
+            # "2b1" / "2s": the reference's real predict shape (Learner.py:219-272: ONE recording) — one 4-mic utterance as a
+            # whole, and streamed in 12-frame chunks
+            sub.ch_mode, sub.offline = {"2M": ("M", False), "2off": ("MM", True)}.get(variant, ("MM", False))
             sub.cpu_seconds = min(args.cpu_seconds, 6.0)
             nsteps = max(1, min(args.steps, 5))
+            if variant in ("2b1", "2s"):
+                sub.nb, nsteps = 1, 25
+                sub.stream_chunk = 12 if variant == "2s" else 0
         try:
             l2, f2 = run_workload(sub, c, dev, rank, world, dist, backend, nsteps, max(1, min(args.warmup, 2)))
         except Exception as e:                                     # a secondary configuration must not lose the headline

@@ -55,9 +55,10 @@ TRAFFIC_JSON = os.path.join("profiles", "r04", "hbm_traffic.json")     # per roo
 TRAFFIC_JSON_R03 = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
 # same-process A/B legs of the default run: (label, environment of the B leg).  A = the shipped default.
 AB_KNOBS = [
-    # round 4: operand-ring narrow-band kernel (lstm_static3.h); issue priorities by phase and leftover-group rotation in the
-    # cluster-resident full-band kernel (lstm_f32c.h)
-    ("round4_kernels_vs_round3_kernels", {"FNSSL_NO_STATIC3": "1", "FNSSL_F32C_PRIO": "9", "FNSSL_F32C_NO_ROTATE": "1"}),
+    # round 4: operand-ring narrow-band kernel (lstm_static3.h) against the one-slice rounds it replaced (round 3's two-slice
+    # kernel was removed in round 5); issue priorities by phase and leftover-group rotation in the cluster-resident full-band
+    # kernel (lstm_f32c.h)
+    ("round4_kernels_vs_one_slice_rounds", {"FNSSL_NO_STATIC3": "1", "FNSSL_F32C_PRIO": "9", "FNSSL_F32C_NO_ROTATE": "1"}),
     # round 3: cluster-resident full-band kernel (lstm_f32c.h) against the per-wave rounds
     ("f32_cluster_vs_rounds", {"FNSSL_NO_F32_CLUSTER": "1"}),
 ]

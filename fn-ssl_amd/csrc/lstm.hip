@@ -154,7 +154,7 @@ static size_t cell_scratch_bytes(int nseq, int hidden, int ndir) {
   const size_t tasks = (size_t)(nseq + 15) / 16 + 16;
   return tasks * ndir * (size_t)(hidden / 16) * 64 * 16 + 256;
 }
-// the pair-interleaved copy of a weight stream (lstm_static2.h) lives behind the cell state: room for the largest
+// the pair-interleaved copy of a weight stream (lstm_static3.h) lives behind the cell state: room for the largest
 // stream of the hidden size (c0 + c2 <= 272 channels) per direction
 static size_t pair_stream_bytes(int hidden, int ndir) {
   return hidden == 256 ? (size_t)ndir * (hidden / 16) * quads_per_slice(256, 16, hidden) * 4096 : 0;
@@ -300,10 +300,8 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   p.quads_per_slice = quads_per_slice(d->c0, d->c2, H);
 #ifdef FNSSL_BUILD_ABLATE
   p.ablate = env_int("FNSSL_ABLATE", 1, 255);   // timing experiments: twin kernels that skip work (wrong results)
-  const bool abl_static2 = env_int("FNSSL_ABL_STATIC2", 1, 1) != 0;
 #else
   p.ablate = 0;                                 // the shipping library contains no ablation twins (make ABLATE=1)
-  const bool abl_static2 = false;
 #endif
   p.dry = dry ? 1 : 0;
   p.fallback_count = d->fallback_count;
@@ -401,14 +399,13 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
       int rc = kNoStatic;
       if (H == 128) rc = launch_static_h128(p, mode, vr.NW, nwg, st);
       if (H == 256) {
-        // two hidden slices per pass (lstm_static2.h) for the full-chip narrow-band rounds of blocks 2 / 3: the stream
-        // is re-ordered into the workspace first (2 MB per direction, one tiny launch) — FNSSL_NO_STATIC2=1: A/B
-        // — or, since round 4, the operand-ring kernel (lstm_static3.h: h_{t-1} streamed like x_t, no register spills, block
-        // 1's 260-channel layer included); FNSSL_NO_STATIC3=1 keeps lstm_static2_kernel / the one-slice kernel: A/B
+        // the full-chip narrow-band rounds: the operand-ring kernel (lstm_static3.h: two hidden slices per pass, x_t and h_{t-1}
+        // streamed, no register spills; block 1's 260-channel layer included) on a pair-interleaved copy of the stream (re-
+        // ordered into the workspace first: 2 MB per direction, one tiny launch).  NO_STATIC3 keeps the one-slice kernel: A/B.
+        // (Round 3's two-slice kernel with h_{t-1} in registers, lstm_static2.h, was removed in round 5: superseded.)
         const bool s3 = !p.ablate && !fnssl::tune(FNSSL_TUNE_NO_STATIC3) && (mode == kSum || mode == 0 || mode == (kHas2 | kSum)) &&
                         ((d->c2 == 0 && !(mode & kHas2)) || (d->c2 == 4 && (mode & kHas2)));
-        const bool s2 = d->c2 == 0 && !(mode & ~kSum) && (!p.ablate || abl_static2) && !fnssl::tune(FNSSL_TUNE_NO_STATIC2);
-        if (vr.NW == 12 && d->c0 == 256 && !p.carry && (s3 || s2)) {
+        if (vr.NW == 12 && d->c0 == 256 && !p.carry && s3) {
           LstmParams p2 = p;
           const long long n4 = (long long)(H / 16) * p.quads_per_slice * 4 * 64;      // float4 per direction
           char* dst = reinterpret_cast<char*>(d->workspace) + cell_scratch_bytes(d->nseq, H, d->ndir);
@@ -420,14 +417,9 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
             p2.wpack[di] = reinterpret_cast<const float*>(o);
           }
           FNSSL_CHECK_LAUNCH("pair_stream_kernel");
-          rc = s3 ? launch_static3_h256(p2, mode, nwg, st) : kNoStatic;
+          rc = launch_static3_h256(p2, mode, nwg, st);
           if (rc != kNoStatic) {
             report(FNSSL_LSTM_FAMILY_STATIC3);
-            return rc;
-          }
-          rc = s2 ? launch_static2_h256(p2, mode, nwg, st) : kNoStatic;
-          if (rc != kNoStatic) {
-            report(FNSSL_LSTM_FAMILY_STATIC2);
             return rc;
           }
         }

@@ -316,7 +316,6 @@ inline bool cluster_grid_fits(const void* kernel, int threads, size_t lds, int g
 inline int cluster_test_stall() { return fnssl::tune(FNSSL_TUNE_CLUSTER_TEST_STALL, 1, 1 << 20) - 1; }
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
-int launch_static2_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static2.h, pair-interleaved stream
 int launch_static3_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static3.h, pair-interleaved stream
 int launch_static_ipdnet(const LstmParams& p, int mode, int H, int NW, int nwg, hipStream_t st);
 

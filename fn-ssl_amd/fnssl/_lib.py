@@ -34,7 +34,7 @@ LIB_PATH = os.environ.get("FNSSL_LIB_PATH", LIB_PATH)
 ABI_VERSION = 18
 CH_MODE = {"M": 0, "MM": 1}
 # kernel families fnssl_lstm_plan reports (include/fnssl.h: FNSSL_LSTM_FAMILY_*)
-LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2", 4: "split", 5: "split_static", 6: "f32_cluster",
+LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2 (retired)", 4: "split", 5: "split_static", 6: "f32_cluster",
                7: "static3", 8: "bf16", 9: "bf16_solo", 10: "bf16_pair", 11: "bf16_cluster", 12: "train", 13: "bwd", 14: "bwd_cluster"}
 
 # every symbol include/fnssl.h declares

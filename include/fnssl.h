@@ -56,8 +56,8 @@ const char* fnssl_last_error(void);
 /* Knob indices.  0 is every knob's default; all of them select between kernels that produce the SAME bits
  * (A/B references, launch geometries) except the fault-injection hook, which the fallback tests use. */
 #define FNSSL_TUNE_LSTM_NO_STATIC 0           /* per-wave LSTM rounds: the generic run-time-loop kernels instead of the shape-specialised ones */
-#define FNSSL_TUNE_NO_STATIC3 1               /* H = 256 narrow-band layers: the two-slice kernel (lstm_static2.h) instead of the operand-ring kernel */
-#define FNSSL_TUNE_NO_STATIC2 2               /* ... and the one-slice kernel (lstm_static.h) instead of lstm_static2.h */
+#define FNSSL_TUNE_NO_STATIC3 1               /* H = 256 narrow-band layers at full-chip size: the one-slice kernel (lstm_static.h) instead of the operand-ring kernel (lstm_static3.h) */
+#define FNSSL_TUNE_NO_STATIC2 2               /* (unused since round 5: lstm_static2.h was removed; the slot keeps the indices stable) */
 #define FNSSL_TUNE_NO_STATIC_IPDNET 3         /* IPDnet layer shapes on the generic kernels */
 #define FNSSL_TUNE_LSTM_SPLIT 4               /* 1 / 2 / 4: force the waves-per-group split of small launches */
 #define FNSSL_TUNE_SPLIT4_MAX_H256 5          /* largest groups-per-CU count that still takes 4 waves per group at H = 256 (default 6) */
@@ -307,7 +307,7 @@ int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);
  * rounds with the rounds.  *rounds (optional) = number of launches of the family (planner rounds; 1 otherwise). */
 #define FNSSL_LSTM_FAMILY_GENERIC 1         /* lstm_rec_kernel rounds (any shape)                               */
 #define FNSSL_LSTM_FAMILY_STATIC 2          /* shape-specialised rounds (lstm_static.h)                         */
-#define FNSSL_LSTM_FAMILY_STATIC2 3         /* two-slices-per-pass rounds, hidden 256 (lstm_static2.h)          */
+#define FNSSL_LSTM_FAMILY_STATIC2 3         /* (retired in round 5: lstm_static2.h removed; never reported)      */
 #define FNSSL_LSTM_FAMILY_SPLIT 4           /* several waves per 16-sequence group, generic (small batches)     */
 #define FNSSL_LSTM_FAMILY_SPLIT_STATIC 5    /* the same, shape-specialised and ring-free                        */
 #define FNSSL_LSTM_FAMILY_F32_CLUSTER 6     /* cluster-resident fp32 kernel (lstm_f32c.h) + guarded fallback    */

@@ -1286,7 +1286,7 @@ def test_few_sequence_launches_take_the_slice_resident_cluster_kernel_and_equal_
     assert_close(got, O.lstm(seq, sd, "L.", bidir), RTOL, ATOL, "few-sequence cluster kernel vs oracle")
 
 
-@pytest.mark.parametrize("kind", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", ["f32", "bf16", "f32_h256", "f32_gate_split", "f32_h256_gate_split"])
 def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch, kind):
     """A member workgroup that never shows up (FNSSL_CLUSTER_TEST_STALL: what a CU-masked, shared or busy device does to
     a kernel that needs all its members resident) must cost time, not the process and not the result: the waiting waves
@@ -1308,6 +1308,32 @@ def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(
             osum = torch.full_like(out, float("nan"))
             r = ops.lstm_layer("full", x, None, None, w, H, out, skip=skip, out_sum=osum, fallback_count=counter, plan_only=plan)
             return r if plan else torch.cat([out, osum], -1)
+    elif kind.startswith("f32_"):
+        # round 5's forms of the fp32 cluster kernel: H = 256 (clusters of 16, the concatenated data channels), and the gate
+        # split of a one-group-per-cluster launch (four waves per group: a sibling that gave up must not leave the other
+        # three spinning on the slot's LDS counter)
+        if kind == "f32_gate_split":
+            mode_, H, c0, c2, nb, nt, nf, ndir = "full", 128, 256, 0, 1, 249, 64, 2      # 16 groups per direction = 1 per cluster
+        elif kind == "f32_h256_gate_split":
+            mode_, H, c0, c2, nb, nt, nf, ndir = "narrow", 256, 256, 4, 1, 40, 256, 1     # 16 groups = 1 per cluster of 16
+        else:
+            mode_, H, c0, c2, nb, nt, nf, ndir = "narrow", 256, 256, 4, 6, 40, 256, 1     # 96 groups = 6 per cluster
+        sd = lstm_state(c0 + c2, H, ndir == 2, 5720 + nb)
+        w = [ops.pack_lstm(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, c2, dev)
+             for s_ in (("", "_reverse") if ndir == 2 else ("",))]
+        gcpu = torch.Generator(device="cpu").manual_seed(5721)
+        x = (torch.randn((nb, nt, nf, c0), generator=gcpu) * 0.5).to(dev)
+        x2 = (torch.randn((nb, nt, nf, c2), generator=gcpu) * 0.5).to(dev) if c2 else None
+        skip = (torch.randn((nb, nt, nf, ndir * H), generator=gcpu) * 0.5).to(dev)
+        off_env, fam, nseq = "FNSSL_NO_F32_SMALL", "f32_cluster", nb * (nt if mode_ == "full" else nf)
+
+        def run(counter=None, plan=False):
+            shape = (nb, nt, nf, ndir * H)
+            mk = (lambda: torch.full(shape, float("nan"), device=dev)) if mode_ == "full" else \
+                (lambda: torch.full((nb, nf, nt, ndir * H), float("nan"), device=dev).permute(0, 2, 1, 3))
+            out, osum = mk(), mk()
+            r = ops.lstm_layer(mode_, x, None, x2, w, H, out, skip=skip, out_sum=osum, fallback_count=counter, plan_only=plan)
+            return r if plan else torch.cat([out, osum], -1)
     else:
         H, c0, c2, nb, nt, nf, ndir = 256, 256, 16, 9, 4, 257, 1
         sd = lstm_state(c0 + c2, H, False, 5710)
@@ -1321,7 +1347,8 @@ def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(
             r = ops.lstm_layer("narrow", x0, None, x2, w, H, out, bf16=True, wide=True, fallback_count=counter, plan_only=plan)
             return r if plan else out
 
-    for k in (off_env, "FNSSL_CLUSTER_TEST_STALL", "FNSSL_CLUSTER_SPIN_LIMIT", "FNSSL_NO_F32C_B1", "FNSSL_CLUSTER_SPREAD"):
+    for k in (off_env, "FNSSL_CLUSTER_TEST_STALL", "FNSSL_CLUSTER_SPIN_LIMIT", "FNSSL_NO_F32C_B1", "FNSSL_CLUSTER_SPREAD",
+              "FNSSL_F32C_GATE_SPLIT", "FNSSL_NO_F32_CLUSTER", "FNSSL_NO_F32_SMALL"):
         monkeypatch.delenv(k, raising=False)
     counter = torch.zeros(1, dtype=torch.int32, device=dev)
     assert run(plan=True)[0] == fam
@@ -1350,9 +1377,9 @@ def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(
 
 
 @pytest.mark.parametrize("c2,summed", [(0, True), (0, False), (4, True)])
-def test_lstm_operand_ring_kernel_equals_two_slice_and_one_slice_kernels(dev, monkeypatch, c2, summed):
-    """lstm_static3.h (round 4: h_{t-1} streamed through the operand ring like x_t, no register spills) bit-for-bit against the kernels it replaces at the full-chip narrow-band size — lstm_static2_kernel
-    (blocks 2 / 3) and the one-slice lstm_static_kernel (block 1's 260 channels) — for the three layer variants of the
+def test_lstm_operand_ring_kernel_equals_one_slice_kernel(dev, monkeypatch, c2, summed):
+    """lstm_static3.h (round 4: h_{t-1} streamed through the operand ring like x_t, no register spills) bit-for-bit against the
+    one-slice lstm_static_kernel at the full-chip narrow-band size — for the three layer variants of the
     network, with a reversed-direction-free, ragged-free shape and steps 0..6 (step 0 reads h_{-1} = 0 through a
     zero-record descriptor); a few sequences against the oracle."""
     from fnssl import ops
@@ -1377,7 +1404,7 @@ def test_lstm_operand_ring_kernel_equals_two_slice_and_one_slice_kernels(dev, mo
     a, asum = run()
     a6, a6sum = run()                                    # (and again: repeatable)
     monkeypatch.setenv("FNSSL_NO_STATIC3", "1")
-    assert run(plan=True)[0] == ("static2" if c2 == 0 else "static")
+    assert run(plan=True)[0] == "static"
     b, bsum = run()
     assert torch.isfinite(a).all()
     assert torch.equal(a, b) and torch.equal(a, a6), "operand-ring kernel differs from the kernels it replaces"

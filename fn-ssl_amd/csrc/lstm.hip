@@ -242,6 +242,14 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   FNSSL_REQUIRE(d->c2 == 0 || d->src2.p, "lstm_forward: src2 missing");
   FNSSL_REQUIRE(d->out && d->wpack[0] && (d->ndir == 1 || d->wpack[1]), "lstm_forward: null out/weights");
   FNSSL_REQUIRE(!d->out_sum || d->skip.p, "lstm_forward: out_sum needs a skip view");
+  // no input may be an output: the recurrence re-reads h_{t-1} from `out`, and the guarded fallback kernels behind a cluster
+  // kernel that gave up recompute the layer from the inputs — which the first attempt must not have overwritten
+  {
+    const void* outs[2] = {d->out, d->out_sum};
+    const void* ins[4] = {d->src0.p, d->src1.p, d->src2.p, d->skip.p};
+    for (const void* o : outs)
+      for (const void* i : ins) FNSSL_REQUIRE(!o || o != i, "lstm_forward: an input tensor aliases an output tensor");
+  }
   auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   FNSSL_REQUIRE(aligned(d->src0.p) && aligned(d->src1.p) && aligned(d->src2.p) && aligned(d->out) &&
                     aligned(d->wpack[0]) && aligned(d->wpack[1]) && aligned(d->workspace) && aligned(d->skip.p) &&

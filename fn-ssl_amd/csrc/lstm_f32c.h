@@ -397,6 +397,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
 
     // ---- cell update of my 16 units, stores, publish
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(0);
+    // A wave that gave up on a hand-off (or saw the launch draining) has multiplied garbage: it stores nothing and publishes
+    // nothing — peers that are not waiting at this moment must not consume it and run on; the guarded fallback launch of the
+    // same call rewrites out / out_sum / reserve (which is why no input of a call may alias them: lstm_forward_impl checks).
+    if (dead) break;
     v4f cn, hn;
     if (ABL & 2) {     // timing ablation: cheap gates
       cn = acc[1] + cprev_cur + acc[0];

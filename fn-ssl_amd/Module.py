@@ -73,8 +73,9 @@ class RemoveChFromBatch(nn.Module):
 
 class DPIPD(nn.Module):
     """DP-IPD template bank exp(-j 2 pi f tau) for a grid of candidate directions (host, numpy;
-    built once per array geometry).  ``forward()`` returns (template, None, doa_candidate) like the
-    reference with ``source_doa=None``; generating ground-truth targets is outside the path."""
+    built once per array geometry).  ``forward(source_doa)`` returns (template, dpipd, doa_candidate) like the
+    reference (Module.py:464-498; numpy in, numpy out); the training path's targets come from one HIP kernel
+    (``fnssl.doa.dpipd_targets``, used by ``predict_step.MyModel.data_preprocess``)."""
 
     def __init__(self, ndoa_candidate, mic_location, nf=257, fre_max=8000, ch_mode='M', speed=343.0):
         super(DPIPD, self).__init__()
@@ -85,9 +86,10 @@ class DPIPD(nn.Module):
             mic_location, ndoa_candidate[0], ndoa_candidate[1], nf, fre_max, ch_mode, speed)
 
     def forward(self, source_doa=None):
+        dpipd = None
         if source_doa is not None:
-            raise NotImplementedError("ground-truth DP-IPD targets (training) are outside the forward path")
-        return self.dpipd_template, None, self.doa_candidate
+            dpipd = fdoa.dpipd_of_sources(source_doa, self.mic_location, self.nf, self.fre_max, self.ch_mode, self.speed)
+        return self.dpipd_template, dpipd, self.doa_candidate
 
 
 class SourceDetectLocalize(nn.Module):

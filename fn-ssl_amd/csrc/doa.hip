@@ -118,3 +118,85 @@ int fnssl_ipd2doa(const float* pred, long long sb, long long sp, long long st, l
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DP-IPD TARGETS of the training step (reference: DPIPD.forward(source_doa), FN-SSL/Lightning/Module.py:464-498, and the
+// ground-truth half of MyModel.data_preprocess, FN-SSL/Lightning/main.py:227-262): for every (utterance, segment, pair,
+// bin) the direct-path phase difference of each source, exp(+j 2 pi f tau) with tau = r(doa) . (mic_i - mic_j) / c
+// (pair (i, j), i < j: the reference's data_adjust keeps [m1 = i, m2 = j] of its [nmic x nmic] table), masked by the
+// source's voice activity (mean over the segment's VAD frames > 0) and summed over the sources:
+//     ipd[b, s, k, p] = sum_src vad * cos(phase)      k <  nf_used
+//     ipd[b, s, nf_used + k, p] = sum_src vad * sin(phase)
+// The reference forms the phase in float64 (numpy) and rounds the cos / sin to float32: so does this kernel (a few
+// thousand double-precision sincos per utterance — nothing to optimise).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256)
+dpipd_targets_kernel(const float* __restrict__ doa, const float* __restrict__ vad, int nb, int nseg, int nvad, int ns,
+                     const float* __restrict__ mic, int nmic, int ch_mode, int np, int bin0, int nf_used, int nbins,
+                     float fre_max, float speed, int use_vad, float* __restrict__ ipd, float* __restrict__ vad_mean) {
+  const int bs = blockIdx.x;                  // (utterance, segment)
+  __shared__ double tau_s[64 * 8];            // [source][pair], <= 8 sources x 64 pairs
+  __shared__ float gate_s[8];
+  const int tid = threadIdx.x;
+  if (tid < ns) {
+    float m = 0.f;
+    for (int v = 0; v < nvad; ++v) m += vad[((size_t)bs * nvad + v) * ns + tid];     // vad [nb, nseg, nvad, ns]
+    m = nvad > 0 ? m / (float)nvad : 1.f;                                             // vad_batch.mean(axis=2)
+    if (vad_mean) vad_mean[(size_t)bs * ns + tid] = m;
+    gate_s[tid] = use_vad ? (m > 0.f ? 1.f : 0.f) : 1.f;                              // th = 0 (main.py:251-253)
+  }
+  for (int i = tid; i < ns * np; i += 256) {
+    const int src = i / np, p = i - src * np;
+    int mi = 0, mj = p + 1;                                                           // 'M': pairs (0, j)
+    if (ch_mode == FNSSL_CH_MODE_MM) {                                                // 'MM': pairs (i, j), i < j, i-major
+      int rem = p;
+      mi = 0;
+      while (rem >= nmic - 1 - mi) {
+        rem -= nmic - 1 - mi;
+        ++mi;
+      }
+      mj = mi + 1 + rem;
+    }
+    const double ele = doa[((size_t)bs * 2 + 0) * ns + src], azi = doa[((size_t)bs * 2 + 1) * ns + src];   // doa [nb, nseg, 2, ns]
+    const double rx = sin(ele) * cos(azi), ry = sin(ele) * sin(azi), rz = cos(ele);
+    const double dx = (double)mic[mi * 3 + 0] - (double)mic[mj * 3 + 0], dy = (double)mic[mi * 3 + 1] - (double)mic[mj * 3 + 1],
+                 dz = (double)mic[mi * 3 + 2] - (double)mic[mj * 3 + 2];
+    tau_s[src * np + p] = (rx * dx + ry * dy + rz * dz) / (double)speed;              // ITD[m1 = i, m2 = j] (Module.py:488)
+  }
+  __syncthreads();
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int i = tid; i < nf_used * np; i += 256) {
+    const int k = i / np, p = i - k * np;
+    const double f = (double)fre_max * (double)(bin0 + k) / (double)(nbins - 1);      // np.linspace(0, fre_max, nf)[bin0 + k]
+    float re = 0.f, im = 0.f;
+    for (int src = 0; src < ns; ++src) {
+      const double ph = two_pi * f * tau_s[src * np + p];                             // (-2 pi f ITD) * (-1), Module.py:489-490
+      re += gate_s[src] * (float)cos(ph);                                             // float32 sum over sources (torch.sum, main.py:258)
+      im += gate_s[src] * (float)sin(ph);
+    }
+    float* o = ipd + (size_t)bs * (2 * nf_used) * np;
+    o[(size_t)k * np + p] = re;
+    o[(size_t)(nf_used + k) * np + p] = im;
+  }
+}
+
+}  // namespace
+
+extern "C" int fnssl_dpipd_targets(const float* doa, const float* vad, int nb, int nseg, int nvad, int ns, const float* mic_loc,
+                                   int nmic, int ch_mode, int bin0, int nf_used, int nbins, float fre_max, float speed,
+                                   int use_vad, float* ipd, float* vad_mean, void* stream) {
+  FNSSL_REQUIRE(doa && mic_loc && ipd && (vad || nvad == 0), "dpipd_targets: null pointer");
+  FNSSL_REQUIRE(nb > 0 && nseg > 0 && ns >= 1 && ns <= 8 && nmic >= 2 && nvad >= 0, "dpipd_targets: nb %d nseg %d sources %d (1..8) mics %d", nb,
+                nseg, ns, nmic);
+  FNSSL_REQUIRE(ch_mode == FNSSL_CH_MODE_M || ch_mode == FNSSL_CH_MODE_MM, "dpipd_targets: channel mode %d", ch_mode);
+  const int np = fnssl_num_pairs(nmic, ch_mode);
+  FNSSL_REQUIRE(np >= 1 && np <= 64, "dpipd_targets: %d microphone pairs (at most 64)", np);
+  FNSSL_REQUIRE(nbins >= 2 && bin0 >= 0 && nf_used >= 1 && bin0 + nf_used <= nbins && fre_max > 0.f && speed > 0.f,
+                "dpipd_targets: bins [%d, %d) of %d", bin0, bin0 + nf_used, nbins);
+  hipLaunchKernelGGL(dpipd_targets_kernel, dim3(nb * nseg), dim3(256), 0, fnssl::as_stream(stream), doa, vad, nb, nseg, nvad, ns,
+                     mic_loc, nmic, ch_mode, np, bin0, nf_used, nbins, fre_max, speed, use_vad, ipd, vad_mean);
+  FNSSL_CHECK_LAUNCH("dpipd_targets_kernel");
+  return FNSSL_OK;
+}

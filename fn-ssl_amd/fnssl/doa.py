@@ -43,6 +43,49 @@ def dpipd_templates(mic_location, nele: int = 37, nazi: int = 73, nf: int = 257,
     return out, [ele, azi]
 
 
+def dpipd_of_sources(source_doa, mic_location, nf: int = 257, fre_max: float = 8000.0, ch_mode: str = "MM",
+                     speed: float = 340.0) -> np.ndarray:
+    """Host form of ``DPIPD.forward(source_doa)`` (Module.py:464-498): source_doa [nb, ntime, 2, nsource] (numpy, radians)
+    -> complex64 [nb, ntime, nf, np, nsource] = exp(+j 2 pi f tau), tau = r(doa) . (mic_i - mic_j) / speed for pair
+    (i, j).  Kept for API compatibility of the drop-in class; the training path uses ``dpipd_targets`` (one HIP kernel)."""
+    doa = np.asarray(source_doa, dtype=np.float64).transpose(0, 1, 3, 2)           # [nb, ntime, nsource, 2]
+    mic = np.asarray(mic_location, dtype=np.float64)
+    fre = np.linspace(0.0, fre_max, nf)
+    r = np.stack([np.sin(doa[..., 0]) * np.cos(doa[..., 1]), np.sin(doa[..., 0]) * np.sin(doa[..., 1]), np.cos(doa[..., 0])],
+                 axis=3)                                                             # [nb, ntime, nsource, 3]
+    pairs = pair_list(mic.shape[-2], ch_mode)
+    out = np.empty(doa.shape[:3] + (nf, len(pairs)), dtype=np.complex64)
+    for p, (i, j) in enumerate(pairs):
+        itd = np.dot(r, mic[i] - mic[j]) / speed                                     # ITD[m1 = i, m2 = j] (:488)
+        out[..., p] = np.exp(1j * (2 * np.pi * fre[None, None, None, :] * itd[..., None]))
+    return out.transpose(0, 1, 3, 4, 2)                                              # [nb, ntime, nf, np, nsource]
+
+
+@on_device
+def dpipd_targets(doa: torch.Tensor, vad, mic_location, ch_mode: str = "MM", bin0: int = 1, nf_used: int = 256,
+                  nbins: int = 257, fre_max: float = 8000.0, speed: float = 340.0, use_vad: bool = True):
+    """The training targets on device (``fnssl_dpipd_targets``; reference main.py:227-262): doa [nb, nseg, 2, ns],
+    vad [nb, nseg, nvad, ns] (or None) -> (ipd [nb, nseg, 2 * nf_used, np], vad_mean [nb, nseg, ns])."""
+    _need_dev(doa, vad)
+    doa = doa.contiguous()
+    nb, nseg, two, ns = doa.shape
+    if two != 2:
+        raise RuntimeError("fnssl.doa.dpipd_targets: doa must be [nb, nseg, 2, nsource]")
+    if vad is not None:
+        vad = vad.contiguous()
+        if vad.ndim != 4 or vad.shape[0] != nb or vad.shape[1] != nseg or vad.shape[3] != ns:
+            raise RuntimeError("fnssl.doa.dpipd_targets: vad %s does not match doa %s" % (tuple(vad.shape), tuple(doa.shape)))
+    mic = torch.as_tensor(np.asarray(mic_location, dtype=np.float32).reshape(-1, 3)).to(doa.device).contiguous()
+    nmic = mic.shape[0]
+    npair = len(pair_list(nmic, ch_mode))
+    ipd = torch.empty((nb, nseg, 2 * nf_used, npair), dtype=torch.float32, device=doa.device)
+    vmean = torch.empty((nb, nseg, ns), dtype=torch.float32, device=doa.device)
+    _lib.check(_lib.load().fnssl_dpipd_targets(_ptr(doa), _ptr(vad), nb, nseg, 0 if vad is None else vad.shape[2], ns, _ptr(mic), nmic,
+                                               _lib.CH_MODE[ch_mode], bin0, nf_used, nbins, float(fre_max), float(speed),
+                                               1 if use_vad else 0, _ptr(ipd), _ptr(vmean), _stream()), "dpipd_targets")
+    return ipd, vmean
+
+
 def template_bank(template: np.ndarray):
     """The bank PredDOA searches (Module.py:702-716): [cos | sin] of bins 1..256, middle elevation
     row, upper azimuth half; candidates ele = pi/2, azi = linspace(0, pi, 37)."""

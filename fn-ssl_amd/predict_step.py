@@ -99,7 +99,7 @@ class MyModel(_Base):
                  fs: int = 16000, win_len: int = 512, nfft: int = 512, win_shift_ratio: float = 0.5,
                  method_mode: str = 'IDL', source_num_mode: str = 'KNum', max_num_sources: int = 1,
                  return_metric: bool = True, exp_name: str = 'exp', compile: bool = False,
-                 device: str = "cuda", fused_engine: bool = True):
+                 device: str = "cuda", fused_engine: bool = True, mic_location=None):
         super().__init__()
         if (win_len, nfft, win_shift_ratio) != (512, 512, 0.5):
             raise ValueError("the MI355X path is built for win_len = nfft = 512, hop 256 (main.py:38-44)")
@@ -112,6 +112,13 @@ class MyModel(_Base):
             self.automatic_optimization = not self.fused_engine
         self.method_mode, self.source_num_mode, self.max_num_sources = method_mode, source_num_mode, max_num_sources
         self.ch_mode = ch_mode
+        self.tar_useVAD = tar_useVAD
+        self.fre_max = fs / 2
+        # the array geometry the DP-IPD targets are generated for: the reference hard-codes its two-microphone array
+        # (main.py:121-123); other arrays pass theirs
+        import numpy as _np
+        self.mic_location = _np.array(((-0.04, 0.0, 0.0), (0.04, 0.0, 0.0))) if mic_location is None else _np.asarray(mic_location)
+        self.speed = 340
         self.nfft = nfft
         self.dev = device
         self.fre_range_used = range(1, int(self.nfft / 2) + 1, 1)
@@ -131,7 +138,10 @@ class MyModel(_Base):
         """batch = (mic_sig_batch [nb, ns, nch], gt_batch with 'ipd' [nb, nt//12, 512, np]).
         One complete optimisation step on this rank's shard; returns {"loss": detached scalar}."""
         mic_sig_batch, gt_batch = batch[0], batch[1]
-        x = ops.preprocess(mic_sig_batch.to(self.dev), self.ch_mode, 1e-6, layout=1)
+        if 'ipd' not in gt_batch:          # the reference's batches carry DOAs and VADs: main.py:152 builds the targets here
+            x, gt_batch = self.data_preprocess(mic_sig_batch, gt_batch)
+        else:
+            x = ops.preprocess(mic_sig_batch.to(self.dev), self.ch_mode, 1e-6, layout=1)
         if not self.fused_engine:
             # main.py:153-157 as written: forward with a graph (the module must be in train() mode, which Lightning's fit
             # loop / Learner.train_epoch set), differentiable loss; Lightning or the caller does backward + optimizer step
@@ -177,16 +187,26 @@ class MyModel(_Base):
             self._train_engine.lr *= 0.8988                                      # ExponentialLR gamma (main.py:272)
 
     def data_preprocess(self, mic_sig_batch=None, gt_batch=None, vad_batch=None, eps=1e-6, nor_flag=True):
-        """Input half of main.py:200-225: [nb, ns, nch] -> [[nb*np, 4, 256, nt]] (reference layout)."""
-        if gt_batch is not None:
-            raise NotImplementedError("ground-truth DP-IPD targets (numpy DPIPD, main.py:227-265) are outside "
-                                      "the forward path")
+        """main.py:200-265: [nb, ns, nch] -> [[nb*np, 4, 256, nt]] (reference layout), and — with ``gt_batch`` {'doa' [nb, nseg,
+        2, ns], 'vad_sources' [nb, nseg, nvad, ns]} — the DP-IPD TARGETS gt_batch['ipd'] [nb, nseg, 512, np] (one HIP kernel,
+        ``fnssl_dpipd_targets``, in place of the reference's per-batch numpy on the host), gt_batch['vad_sources'] = its mean
+        over the segment's frames and gt_batch['doa'] on the device: returns [input, gt_batch] like the reference."""
         if not nor_flag:
             raise NotImplementedError("nor_flag=False is not part of the path")
         data = []
         if mic_sig_batch is not None:
             mic_sig_batch = mic_sig_batch.to(self.dev)
             data += [ops.preprocess(mic_sig_batch, self.ch_mode, eps, layout=1)]
+        if gt_batch is not None:
+            from fnssl import doa as fdoa
+            doa_b = gt_batch['doa'].to(self.dev).float()
+            vad_b = gt_batch['vad_sources'].to(self.dev).float()
+            ipd, vmean = fdoa.dpipd_targets(doa_b, vad_b, self.mic_location, self.ch_mode, 1, int(self.nfft / 2),
+                                            int(self.nfft / 2) + 1, self.fre_max, self.speed, self.tar_useVAD)
+            gt_batch['doa'] = doa_b
+            gt_batch['ipd'] = ipd
+            gt_batch['vad_sources'] = vmean
+            data += [gt_batch]
         return data
 
     @torch.no_grad()

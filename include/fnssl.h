@@ -541,6 +541,24 @@ int fnssl_linear(const float* x, int m, int k, const float* wt, const float* b, 
  *   idx   [nb, nt, nsrc]     winning candidate per source (int32)
  *   vad   [nb, nt, nsrc]     1 ('kNum') or the projection ratio ('unkNum', unk_num = 1)
  */
+/*
+ * DP-IPD TARGETS of the training step: replaces DPIPD.forward(source_doa) (FN-SSL/Lightning/Module.py:464-498) and the
+ * ground-truth half of MyModel.data_preprocess (FN-SSL/Lightning/main.py:227-262) — the reference builds them on the host
+ * in numpy for every batch.
+ *   doa      [nb, nseg, 2, ns]   (elevation, azimuth) of every source per segment, radians
+ *   vad      [nb, nseg, nvad, ns] voice activity per frame of the segment (may be NULL with nvad = 0: all active)
+ *   mic_loc  DEVICE [nmic, 3]    microphone positions in metres
+ *   pairs    FNSSL_CH_MODE_M: (0, j); FNSSL_CH_MODE_MM: (i, j), i < j, i-major (Module.py:500-514)
+ *   bins     bin0 .. bin0 + nf_used - 1 of np.linspace(0, fre_max, nbins) (main.py:130: bins 1..256 of 257)
+ *   ipd      [nb, nseg, 2 * nf_used, np] (written) = sum over sources of gate * [cos | sin](2 pi f tau),
+ *            tau = r(doa) . (mic_i - mic_j) / speed, gate = (mean_v vad > 0) when use_vad else 1 (main.py:249-258);
+ *            the phase is formed in double precision like numpy's, the result rounded to fp32
+ *   vad_mean [nb, nseg, ns] (written; may be NULL) = vad.mean(axis 2) (main.py:243), what gt_batch['vad_sources'] becomes
+ */
+int fnssl_dpipd_targets(const float* doa, const float* vad, int nb, int nseg, int nvad, int ns, const float* mic_loc,
+                        int nmic, int ch_mode, int bin0, int nf_used, int nbins, float fre_max, float speed, int use_vad,
+                        float* ipd, float* vad_mean, void* stream);
+
 int fnssl_ipd2doa(const float* pred, long long sb, long long sp, long long st, long long sk,
                   const float* bank, int nb, int np, int nt, int nf2,
                   int ncand, int nsrc, int unk_num, float* ss, int* idx, float* vad, void* stream);

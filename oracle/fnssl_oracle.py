@@ -347,6 +347,45 @@ def dpipd_templates(mic_location: np.ndarray, nele: int = 37, nazi: int = 73, nf
     return out, [ele, azi]
 
 
+def dpipd_of_sources(source_doa: np.ndarray, mic_location, nf: int = 257, fre_max: float = 8000.0, ch_mode: str = "MM",
+                     speed: float = 340.0) -> np.ndarray:
+    """DPIPD.forward(source_doa), FN-SSL/Lightning/Module.py:464-498: source_doa [nb, ntime, 2, nsource] ->
+    complex64 [nb, ntime, nf, np, nsource].  Note the sign: ITD[m1, m2] = r . (mic[m1] - mic[m2]) / c (:488) and the
+    phase is (-2 pi f ITD) * (-1) (:489-490) — the conjugate convention of the template bank of __init__."""
+    doa = np.asarray(source_doa).transpose(0, 1, 3, 2)                        # (nb, ntime, nsource, 2)  :472
+    mic = np.asarray(mic_location, dtype=np.float64)
+    nmic = mic.shape[-2]
+    nb, ntime, nsource = doa.shape[:3]
+    fre = np.linspace(0.0, fre_max, nf)
+    r = np.stack([np.sin(doa[..., 0]) * np.cos(doa[..., 1]), np.sin(doa[..., 0]) * np.sin(doa[..., 1]), np.cos(doa[..., 0])],
+                 axis=3)                                                      # :484-486
+    ipd = np.empty((nb, ntime, nsource, nf, nmic, nmic))
+    for m1 in range(nmic):
+        for m2 in range(nmic):
+            itd = np.dot(r, mic[m1, :] - mic[m2, :]) / speed                  # :488
+            ipd[:, :, :, :, m1, m2] = -2 * np.pi * fre[None, None, None, :] * itd[..., None] * (-1)   # :489-490
+    full = np.exp(1j * ipd)
+    pairs = pair_list(nmic, ch_mode)                                          # data_adjust :500-514
+    out = np.empty((nb, ntime, nsource, nf, len(pairs)), dtype=np.complex64)
+    for p, (i, j) in enumerate(pairs):
+        out[..., p] = full[..., i, j]
+    return out.transpose(0, 1, 3, 4, 2)                                       # (nb, ntime, nf, np, nsource)  :495
+
+
+def dpipd_targets(doa: np.ndarray, vad: np.ndarray, mic_location, ch_mode: str = "MM", use_vad: bool = True,
+                  nfft: int = 512, fs: int = 16000, speed: float = 340.0):
+    """Ground-truth half of MyModel.data_preprocess, FN-SSL/Lightning/main.py:227-262: doa [nb, nseg, 2, ns], vad [nb, nseg,
+    nvad, ns] -> (gt_batch['ipd'] [nb, nseg, 2 * 256, np] float32, gt_batch['vad_sources'] [nb, nseg, ns])."""
+    dp = dpipd_of_sources(doa, mic_location, nfft // 2 + 1, fs / 2, ch_mode, speed)
+    used = slice(1, nfft // 2 + 1)                                            # fre_range_used, main.py:130
+    ipd = np.concatenate((dp.real[:, :, used], dp.imag[:, :, used]), axis=2).astype(np.float32)     # :237-238
+    vmean = np.asarray(vad, dtype=np.float32).mean(axis=2)                    # :243
+    if use_vad:                                                               # :249-257, th = 0
+        gate = (vmean > 0).astype(np.float32)
+        ipd = ipd * gate[:, :, None, None, :]
+    return ipd.sum(axis=-1, dtype=np.float32), vmean                          # :258
+
+
 def template_bank(template: np.ndarray, doa_candidate):
     """The candidate bank PredDOA.predgt2DOA actually searches, Module.py:702-716: real|imag of
     bins 1..256 concatenated along frequency, elevation fixed to the middle row, azimuth the upper

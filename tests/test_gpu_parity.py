@@ -451,6 +451,53 @@ def test_doa_backend_golden(dev):
     assert_close(ss.cpu().numpy(), g["m4_ss"], 1e-5, 1e-6, "4-mic spatial spectrum")
 
 
+def test_dpipd_targets_kernel_golden_and_reference_training_step_literal(dev):
+    """The training TARGETS on device (fnssl_dpipd_targets) against the real reference's (G16: DPIPD.forward(source_doa) +
+    main.py:227-262) and the oracle; then the reference's training_step as written — batch = (mic_sig, {'doa', 'vad_sources'}),
+    `in_batch, gt_batch = self.data_preprocess(mic_sig_batch, gt_batch)`, forward with a graph, cal_loss, backward, Adam —
+    through predict_step.MyModel(fused_engine=False)."""
+    import predict_step as ps
+    from fnssl import doa as fdoa
+    from fnssl import weights as W
+    from oracle import fnssl_oracle as O
+    g = load_golden("g16_dpipd_targets")
+    for name in ("c0", "c1", "c2", "c3"):
+        mode = "MM" if int(g[name + "_cfg"][0]) else "M"
+        use_vad = bool(int(g[name + "_cfg"][1]))
+        mics, doa, vad = g[name + "_mics"], g[name + "_doa"], g[name + "_vad"]
+        ipd, vmean = fdoa.dpipd_targets(to_dev(doa, dev), to_dev(vad, dev), mics, mode, 1, 256, 257, 8000.0, 340.0, use_vad)
+        assert_close(ipd.cpu().numpy(), g[name + "_ipd"], 0, 2e-6, name + " targets vs the reference")
+        assert_close(vmean.cpu().numpy(), g[name + "_vmean"], 0, 1e-7, name + " vad mean")
+        want, _ = O.dpipd_targets(doa, vad, mics, mode, use_vad)
+        assert_close(ipd.cpu().numpy(), want, 0, 2e-6, name + " targets vs the oracle")
+    # no VAD tensor: every source active
+    ipd_nv, _ = fdoa.dpipd_targets(to_dev(g["c1_doa"], dev), None, g["c1_mics"], "MM", use_vad=True)
+    want_nv, _ = O.dpipd_targets(g["c1_doa"], np.ones_like(g["c1_vad"]), g["c1_mics"], "MM", True)
+    assert_close(ipd_nv.cpu().numpy(), want_nv, 0, 2e-6, "targets without a VAD tensor")
+    # ---- the reference's training_step, literally (two-microphone array of main.py:121-123)
+    m = ps.MyModel(device=str(dev), fused_engine=False)
+    m.arch.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in W.make_fnssl_state(9).items()})
+    m.to(dev).train()
+    nb, nseg = 2, 2
+    sig = to_dev(rs_randn(51, (nb, 512 + (12 * nseg - 1) * 256, 2), 0.1), dev)           # [nb, ns, nch]
+    rs = np.random.RandomState(52)
+    doa = np.stack((np.full((nb, nseg, 1), np.pi / 2), rs.uniform(0.0, np.pi, (nb, nseg, 1))), axis=2).astype(np.float32)
+    vad = np.ones((nb, nseg, 12, 1), dtype=np.float32)
+    opt = m.configure_optimizers()["optimizer"]
+    losses = []
+    for _ in range(4):
+        gt = {"doa": torch.from_numpy(doa), "vad_sources": torch.from_numpy(vad)}       # host tensors, as a dataloader yields
+        out = m.training_step((sig, gt), 0)
+        assert gt["ipd"].shape == (nb, nseg, 512, 1) and gt["ipd"].is_cuda and gt["vad_sources"].shape == (nb, nseg, 1)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"].detach()))
+    want_ipd, _ = O.dpipd_targets(doa, vad, np.array(((-0.04, 0.0, 0.0), (0.04, 0.0, 0.0))), "MM", True)
+    assert_close(gt["ipd"].cpu().numpy(), want_ipd, 0, 2e-6, "targets built inside training_step")
+    assert losses[-1] < losses[0], losses
+
+
 def test_waveform_to_doa_end_to_end(dev):
     """waveform -> DP-IPD -> DOA entirely on device equals oracle forward + oracle back end."""
     import Module as at_module

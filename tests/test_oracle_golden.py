@@ -289,3 +289,28 @@ def test_torch_ref_ipdnet_and_ipdnet2_match_reference_golden():
     seed, nb, ns, nch, sl = (int(v) for v in g15["c0_cfg"])
     f = R.array_preprocess(torch.from_numpy(rs_randn(seed, (nb, ns, nch), 0.1)), sl, 320, True).numpy()
     assert np.abs(f - g15["c0_feat"]).max() <= 2e-6 * np.abs(g15["c0_feat"]).max()
+
+
+def test_g16_dpipd_targets_oracle_and_host_dropin_match_reference():
+    """G16 (tests/golden/make_golden_targets.py: the REAL reference's DPIPD.forward(source_doa) + the gt half of
+    data_preprocess, main.py:227-262): the oracle's restatement and the drop-in DPIPD's host form reproduce the targets —
+    2- and 4-microphone arrays, 'MM' and 'M' pairing, 1 - 3 sources, a silent source, tar_useVAD on and off."""
+    import Module as at_module
+    from fnssl import doa as fdoa
+    g = load_golden("g16_dpipd_targets")
+    for name in ("c0", "c1", "c2", "c3"):
+        mode = "MM" if int(g[name + "_cfg"][0]) else "M"
+        use_vad = bool(int(g[name + "_cfg"][1]))
+        mics, doa, vad = g[name + "_mics"], g[name + "_doa"], g[name + "_vad"]
+        ipd, vmean = O.dpipd_targets(doa, vad, mics, mode, use_vad)
+        assert_close(ipd, g[name + "_ipd"], 0, 2e-6, name + " targets (oracle)")
+        assert_close(vmean, g[name + "_vmean"], 0, 1e-7, name + " vad mean")
+        raw = O.dpipd_of_sources(doa, mics, 257, 8000.0, mode, 340.0)
+        assert_close(raw[:, :, ::32], g[name + "_dpipd_sub"], 0, 2e-6, name + " DPIPD.forward (oracle)")
+        host = fdoa.dpipd_of_sources(doa, mics, 257, 8000.0, mode, 340.0)
+        assert_close(host[:, :, ::32], g[name + "_dpipd_sub"], 0, 2e-6, name + " DPIPD.forward (drop-in host form)")
+        t, dp, cand = at_module.DPIPD([5, 9], mics, nf=257, fre_max=8000, ch_mode=mode, speed=340)(source_doa=doa)
+        assert dp.shape == raw.shape and dp.dtype == np.complex64 and len(cand) == 2
+        assert_close(dp[:, :, ::32], g[name + "_dpipd_sub"], 0, 2e-6, name + " drop-in DPIPD")
+    # a silent source contributes nothing when tar_useVAD is on (c0: the only source of utterance 0, segment 0)
+    assert np.all(g["c0_ipd"][0, 0] == 0.0) and np.abs(g["c0_ipd"][0, 1]).max() > 0.5

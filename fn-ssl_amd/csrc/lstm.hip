@@ -244,7 +244,7 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   FNSSL_REQUIRE(!d->out_sum || d->skip.p, "lstm_forward: out_sum needs a skip view");
   // no input may be an output: the recurrence re-reads h_{t-1} from `out`, and the guarded fallback kernels behind a cluster
   // kernel that gave up recompute the layer from the inputs — which the first attempt must not have overwritten
-  {
+  if (!dry) {   // (fnssl_lstm_plan launches nothing: a query may describe the shapes with one buffer)
     const void* outs[2] = {d->out, d->out_sum};
     const void* ins[4] = {d->src0.p, d->src1.p, d->src2.p, d->skip.p};
     for (const void* o : outs)

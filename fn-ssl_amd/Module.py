@@ -139,10 +139,12 @@ class PredDOA(nn.Module):
         self.register_buffer("bank", torch.from_numpy(bank), persistent=False)
 
     def predgt2DOA(self, pred_batch=None, gt_batch=None, time_pool_size=None):
-        if time_pool_size is not None:
-            raise NotImplementedError("time pooling of non-network IPDs is outside the path")
         if pred_batch is not None:
             pred_ipd = pred_batch.detach()
+            if time_pool_size is not None:       # mean over blocks of time_pool_size segments, floor (Module.py:723-730)
+                from fnssl import ops as _ops
+                nbp, nt, nf2 = pred_ipd.shape
+                pred_ipd = _ops.avgpool_time(pred_ipd.float().reshape(nbp, 1, nt, nf2), int(time_pool_size)).reshape(nbp, -1, nf2)
             npair = self.bank.shape[-1]
             nb = pred_ipd.shape[0] // npair
             idx, vads, ss = fdoa.localize(pred_ipd, self.bank.to(pred_ipd.device), nb,

@@ -130,14 +130,18 @@ def forgetting_coefs(nt: int, sample_length: int, device):
 
 @on_device
 def pair_features(spec, magsum, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int = 298,
-                  layout: int = 0):
-    """main.py:207-225.  Returns (x, mu); x is [nb', nt, 256, 4] (layout 0) or [nb', 4, 256, nt] (layout 1)."""
+                  layout: int = 0, normalise: bool = True):
+    """main.py:207-225.  Returns (x, mu); x is [nb', nt, 256, 4] (layout 0) or [nb', 4, 256, nt] (layout 1).
+    ``normalise=False`` = the reference's ``nor_flag=False`` branch (main.py:219-221: real / imag parts as they are): the same
+    kernels with a zero recursion (mu = 0) and eps = 1, i.e. an exact division by one."""
     _need_dev(spec, magsum)
     nb, nch, nt = magsum.shape
     np_ = num_pairs(nch, ch_mode)
     if np_ <= 0:
         raise RuntimeError("fnssl.pair_features: need at least 2 channels, got %d" % nch)
     ca, cb = forgetting_coefs(nt, sample_length, spec.device)
+    if not normalise:
+        ca, cb, eps = torch.zeros_like(ca), torch.zeros_like(cb), 1.0
     mu = torch.empty((nb * np_, nt), dtype=torch.float32, device=spec.device)
     shape = (nb * np_, nt, NF, 4) if layout == 0 else (nb * np_, 4, NF, nt)
     x = torch.empty(shape, dtype=torch.float32, device=spec.device)
@@ -147,10 +151,10 @@ def pair_features(spec, magsum, ch_mode: str = "MM", eps: float = 1e-6, sample_l
     return x, mu
 
 
-def preprocess(sig, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int = 298, layout: int = 0):
+def preprocess(sig, ch_mode: str = "MM", eps: float = 1e-6, sample_length: int = 298, layout: int = 0, normalise: bool = True):
     """Waveforms [nb, ns, nch] -> network features (data_preprocess, main.py:200-225)."""
     spec, magsum = stft(sig)
-    x, _ = pair_features(spec, magsum, ch_mode, eps, sample_length, layout)
+    x, _ = pair_features(spec, magsum, ch_mode, eps, sample_length, layout, normalise)
     return x
 
 

@@ -191,12 +191,10 @@ class MyModel(_Base):
         2, ns], 'vad_sources' [nb, nseg, nvad, ns]} — the DP-IPD TARGETS gt_batch['ipd'] [nb, nseg, 512, np] (one HIP kernel,
         ``fnssl_dpipd_targets``, in place of the reference's per-batch numpy on the host), gt_batch['vad_sources'] = its mean
         over the segment's frames and gt_batch['doa'] on the device: returns [input, gt_batch] like the reference."""
-        if not nor_flag:
-            raise NotImplementedError("nor_flag=False is not part of the path")
         data = []
         if mic_sig_batch is not None:
             mic_sig_batch = mic_sig_batch.to(self.dev)
-            data += [ops.preprocess(mic_sig_batch, self.ch_mode, eps, layout=1)]
+            data += [ops.preprocess(mic_sig_batch, self.ch_mode, eps, layout=1, normalise=bool(nor_flag))]
         if gt_batch is not None:
             from fnssl import doa as fdoa
             doa_b = gt_batch['doa'].to(self.dev).float()

@@ -436,6 +436,16 @@ def test_doa_backend_golden(dev):
         np.testing.assert_array_equal(out["doa"].cpu().numpy(), g["c%d_doa" % ci])
         assert_close(out["vad_sources"].cpu().numpy(), g["c%d_vad" % ci], 1e-4, 1e-6, "vad")
         assert_close(out["spatial_spectrum"].cpu().numpy(), g["c%d_ss" % ci], 1e-5, 1e-6, "spatial spectrum")
+    # time_pool_size (Module.py:723-730): localisation on the mean of every 2 consecutive segments == localisation of the
+    # pooled prediction
+    pd = at_module.PredDOA(max_num_sources=1, ch_mode="MM", device=str(dev)).to(dev)
+    pred = to_dev(np.tanh(rs_randn(1230, (3, 5, 512))), dev)
+    pooled = torch.stack((pred[:, 0:2].mean(dim=1), pred[:, 2:4].mean(dim=1)), dim=1)
+    a_, _ = pd.predgt2DOA(pred_batch=pred, time_pool_size=2)
+    b_, _ = pd.predgt2DOA(pred_batch=pooled)
+    assert a_["doa"].shape == (3, 2, 2, 1)
+    np.testing.assert_array_equal(a_["doa"].cpu().numpy(), b_["doa"].cpu().numpy())
+    assert_close(a_["spatial_spectrum"].cpu().numpy(), b_["spatial_spectrum"].cpu().numpy(), 1e-5, 1e-6, "pooled spectrum")
     mics4 = g["tmpl_mics"]
     for mode in ("MM", "M"):
         t, _, cand = at_module.DPIPD([5, 9], mics4, nf=257, fre_max=8000, ch_mode=mode, speed=340)()
@@ -449,6 +459,25 @@ def test_doa_backend_golden(dev):
     np.testing.assert_array_equal(doa.cpu().numpy(), g["m4_doa"])
     assert_close(vad.cpu().numpy(), g["m4_vad"], 1e-4, 1e-6, "4-mic vad")
     assert_close(ss.cpu().numpy(), g["m4_ss"], 1e-5, 1e-6, "4-mic spatial spectrum")
+
+
+def test_data_preprocess_nor_flag_false_is_the_raw_real_imag_pairs(dev):
+    """main.py:219-221: with nor_flag=False the features are the pairs' real / imaginary STFT parts as they are."""
+    import predict_step as ps
+    from fnssl import ops
+    m = ps.MyModel(device=str(dev))
+    sig = to_dev(rs_randn(61, (2, 512 + 23 * 256, 3), 0.1), dev)                       # [nb, ns, nch]
+    x, = m.data_preprocess(sig, nor_flag=False)
+    spec, _ = ops.stft(sig)                                                          # [nb, nch, nt, 257] (re, im) interleaved
+    spec = spec.reshape(2, 3, 24, 257, 2)
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    assert tuple(x.shape) == (6, 4, 256, 24)
+    for b in range(2):
+        for p, (i, j) in enumerate(pairs):
+            want = torch.stack((spec[b, i, :, 1:, 0], spec[b, j, :, 1:, 0], spec[b, i, :, 1:, 1], spec[b, j, :, 1:, 1]), 0)   # [4, nt, 256]
+            assert torch.equal(x[b * 3 + p], want.permute(0, 2, 1)), (b, p)
+    xn, = m.data_preprocess(sig)                                                      # and the default still normalises
+    assert not torch.equal(xn, x)
 
 
 def test_dpipd_targets_kernel_golden_and_reference_training_step_literal(dev):
@@ -1463,6 +1492,21 @@ def test_lstm_operand_ring_kernel_equals_one_slice_kernel(dev, monkeypatch, c2, 
     want = O.lstm(seq, sd, "L.", False)
     got = np.stack([a[b_, :, f_].cpu().numpy() for b_, f_ in rows])
     assert_close(got, want, RTOL, ATOL, "operand-ring kernel vs oracle")
+
+
+def test_lstm_forward_rejects_an_input_that_aliases_an_output(dev):
+    """The recurrence re-reads h_{t-1} from `out`, and the guarded fallback kernels behind a cluster kernel that gave up
+    recompute the layer from the inputs: an in-place call would corrupt either (round-4 advisor note) — it is an error."""
+    from fnssl import ops
+    sd = lstm_state(256, 256, False, 5250)
+    w = [ops.pack_lstm(sd["L.weight_ih_l0"], sd["L.weight_hh_l0"], sd["L.bias_ih_l0"], sd["L.bias_hh_l0"], 256, 0, dev)]
+    x = torch.zeros((1, 4, 16, 256), device=dev)
+    with pytest.raises(RuntimeError, match="aliases"):
+        ops.lstm_layer("narrow", x, None, None, w, 256, x)
+    out = torch.empty_like(x)
+    with pytest.raises(RuntimeError, match="aliases"):
+        ops.lstm_layer("narrow", x, None, None, w, 256, out, skip=x, out_sum=x)
+    ops.lstm_layer("narrow", x, None, None, w, 256, out)              # (and the legitimate call goes through)
 
 
 def test_lstm_bf16_wide_rejects_unbuilt_shapes(dev):

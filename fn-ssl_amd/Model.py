@@ -132,14 +132,27 @@ class FNblock(nn.Module):
             if fb_skip is None:
                 raise RuntimeError("FNblock: fb_skip is required unless is_first")
             fb_prev = fb_skip.reshape(nb, nt, nf, -1)
+        from fnssl import train as _train                       # combine(): the fused element-wise sum kernel
         f = torch.empty((nb, nt, nf, fh2), dtype=torch.float32, device=x.device)
-        ops.lstm_layer("full", x, None if self.is_first else fb_prev, None, full_w, self.full_hidden_size, f)
+        # The residual sums of blocks 2 / 3 (Model.py:36-37, 44-45) are formed by one element-wise kernel each, so that every
+        # LSTM call sees ONE summed input and takes the shape-specialised / cluster-resident kernels (a second summed operand
+        # is only built into the generic rounds and the several-waves-per-group kernels); same fp32 add, same bits.
+        if self.is_first:
+            ops.lstm_layer("full", x, None, None, full_w, self.full_hidden_size, f)
+        else:
+            x = ops._conform(x.float())
+            fb_prev = ops._conform(fb_prev.float())
+            u = torch.empty((nb, nt, nf, nc), dtype=torch.float32, device=x.device)
+            _train.combine(u, plain=(x, fb_prev))                                              # x + fb_skip  :36-37
+            ops.lstm_layer("full", u, None, None, full_w, self.full_hidden_size, f)
         n = torch.empty((nb, nf, nt, nh), dtype=torch.float32, device=x.device)
         n_logical = n.permute(0, 2, 1, 3)                      # [nb, nt, nf, Hn] view
         if self.is_first:
             ops.lstm_layer("narrow", f, None, x, narr_w, self.narr_hidden_size, n_logical)     # cat  :42-43
         else:
-            ops.lstm_layer("narrow", f, x, None, narr_w, self.narr_hidden_size, n_logical)     # add  :44-45
+            v = torch.empty((nb, nf, nt, fh2), dtype=torch.float32, device=x.device).permute(0, 2, 1, 3)
+            _train.combine(v, plain=(f, x))                                                    # + nb_skip  :44-45
+            ops.lstm_layer("narrow", v, None, None, narr_w, self.narr_hidden_size, n_logical)
         return n_logical, f.view(nb * nt, nf, fh2), n.view(nb * nf, nt, nh)
 
 

@@ -51,7 +51,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only, by is_online
-TRAFFIC_JSON = os.path.join("profiles", "r04", "hbm_traffic.json")     # per roofline kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_JSON = os.path.join("profiles", "r05", "hbm_traffic.json")     # per roofline kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 TRAFFIC_JSON_R03 = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
 # same-process A/B legs of the default run: (label, environment of the B leg).  A = the shipped default.
 AB_KNOBS = [
@@ -64,15 +64,35 @@ AB_KNOBS = [
 ]
 
 
+SQ_JSON = os.path.join("profiles", "r05", "pmc_sq_sn_mamba_scan.json")
+
+
+def sq_counters_of(kernel):
+    """SQ counters of one kernel from the committed rocprofv3 --pmc summary (tools/pmc_summary.py), or None."""
+    for path in (SQ_JSON, os.path.join("profiles", "r04", "h_pmc_sq_sn_mamba_scan.json")):
+        full = os.path.join(ROOT, path)
+        if os.path.exists(full):
+            try:
+                with open(full) as f:
+                    d = json.load(f)
+            except ValueError:
+                continue
+            for k, v in d.items():
+                if kernel in k:
+                    return v
+    return None
+
+
 def traffic_of(key):
     """(bytes per launch, source) of a roofline kernel from the committed PMC summaries, or (None, None): counter
     passes cannot run inside the timed region (gpurun refuses --pmc next to traces, and they perturb the clock)."""
-    path = os.path.join(ROOT, TRAFFIC_JSON)
-    if os.path.exists(path):
-        with open(path) as f:
-            d = json.load(f).get(key)
-        if d and d.get("bytes_per_launch"):
-            return d["bytes_per_launch"], TRAFFIC_JSON + "[%s] (%s; not this run)" % (key, d.get("how", "rocprofv3 --pmc"))
+    for rel in (TRAFFIC_JSON, os.path.join("profiles", "r04", "hbm_traffic.json")):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f).get(key)
+            if d and d.get("bytes_per_launch"):
+                return d["bytes_per_launch"], rel + "[%s] (%s; not this run)" % (key, d.get("how", "rocprofv3 --pmc"))
     if key == "c2_lstm_h256" and os.path.exists(os.path.join(ROOT, TRAFFIC_JSON_R03)):
         with open(os.path.join(ROOT, TRAFFIC_JSON_R03)) as f:
             return json.load(f).get("bytes_per_launch"), TRAFFIC_JSON_R03 + " (round-3 build; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)"
@@ -222,12 +242,14 @@ class FnsslForward:
             return kernel_roof(kern, "lstm_h128", "H = 128 layers (offline: every layer; full-band on the cluster-resident lstm_f32c_kernel, "
                                "narrow-band on lstm_static_kernel rounds)", PEAK_FP32_MFMA_TFLOPS)
         if self.chunk:
+            traffic, src = traffic_of("c2s_lstm_h128")
             return kernel_roof(kern, "lstm_h128", "lstm_f32c_kernel<H=128, gate split> (full-band BiLSTM: 256 serial steps per chunk, one "
                                "16-sequence group per cluster of 8 CUs — latency-bound by the per-step hand-off, not by the matrix pipe)",
-                               PEAK_FP32_MFMA_TFLOPS)
+                               PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
         if self.nb * self.n_pairs * 256 // 16 < 12 * 256:      # below the full-chip launch the narrow-band layers run lstm_f32c_kernel<256>
+            traffic, src = traffic_of("c2b1_lstm_h256") if self.nb == 1 and self.n_pairs == 6 else (None, None)
             return kernel_roof(kern, "lstm_h256", "lstm_f32c_kernel<H=256> (narrow-band LSTM: hidden slices over clusters of 16 CUs, weight "
-                               "slice resident in LDS, groups as work items)", PEAK_FP32_MFMA_TFLOPS)
+                               "slice resident in LDS, groups as work items)", PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
         if self.args.bf16:
             return kernel_roof(kern, "lstm_h256", "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
                                PEAK_BF16_MFMA_TFLOPS)
@@ -626,10 +648,26 @@ class Ipdnet2Forward:
             peak = 1024 * clock / 592.0                                    # wave-steps per second, all SIMDs issuing
             ach = wave_steps * (k["count"] / (2.0 * self.layers)) / (k["ms"] * 1e-3) if k["ms"] > 0 else 0.0
             traffic, src = traffic_of("c5_sn_mamba_scan")
-            return {"name": dom, "bound": "valu", "kernel": "sn_mamba_scan (selective scan: no matrix product; roof = VALU / "
-                    "transcendental issue, 592 issue cycles per wave-step, DESIGN section 10)", "achieved": round(ach / 1e9, 3),
-                    "peak": round(peak / 1e9, 3), "unit": "G wave-steps/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            roof = {"name": dom, "bound": "valu", "kernel": "sn_mamba_scan (selective scan: no matrix product; roof = VALU / "
+                    "transcendental issue)", "achieved": round(ach / 1e9, 3), "unit": "G wave-steps/s", "traffic": traffic,
                     "traffic_source": src, "launches": k["count"], "avg_ms": round(k["ms"] / max(1, k["count"]), 4)}
+            # The roof from COUNTERS (committed rocprofv3 --pmc pass of this kernel, like `traffic`): the fraction of its cycles a
+            # SIMD spends issuing vector-ALU instructions = (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, per wave) x the waves resident
+            # per SIMD (S sequences x 3 waves on 1024 SIMDs) — recomputable from the JSON; `peak` = achieved / frac.  The
+            # instruction-count model of rounds 3 - 4 (592 issue cycles per wave-step at an assumed 2.4 GHz) is kept as
+            # `frac_model` for comparison only.
+            sq = sq_counters_of("sn_mamba_scan_kernel")
+            waves_per_simd = min(8.0, nb * 16 * 3 / 1024.0)
+            if sq and sq.get("SQ_WAVE_CYCLES"):
+                frac = min(1.0, sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * waves_per_simd)
+                roof.update({"frac": round(frac, 4), "peak": round(ach / frac / 1e9, 3) if frac > 0 else None,
+                             "frac_source": SQ_JSON + ": SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = %.3f per wave x %.2f waves resident per SIMD "
+                                            "(not this run)" % (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], waves_per_simd),
+                             "frac_model": round(ach / peak, 4)})
+            else:
+                roof.update({"frac": round(ach / peak, 4), "peak": round(peak / 1e9, 3),
+                             "frac_source": "instruction-count model: 592 issue cycles per wave-step at 2.4 GHz (no committed SQ counters found)"})
+            return roof
         r = kernel_roof(kern, dom, "%s (dominant kernel of the step%s)" % (dom, ", bf16 MFMA operands" if on_bf16 else
                                                                            ", fp32 arithmetic"),
                         PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS)

@@ -298,6 +298,9 @@ int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_p
  * already enqueued the per-wave rounds / pair-split kernels behind it, guarded by that word: they return at once when
  * it is 0 and otherwise recompute the whole layer (same bits as the cluster kernel).  Before launching, the grid is
  * checked against the occupancy the device reports; a cluster kernel that cannot be co-resident is not launched.
+ * Two cluster launches on different streams of one process take turns on the device by themselves (measured: two
+ * concurrent one-utterance forwards = 2 x one, no fallback; tools/two_stream_probe.py); should the dispatcher ever split
+ * the CUs between them, the bounded waits and the guarded fallback above are what ends it.
  * Returns FNSSL_OK or a negative status (invalid descriptor, workspace, HIP launch error) with fnssl_last_error().
  */
 int fnssl_lstm_forward(const fnssl_lstm_desc* d, void* stream);

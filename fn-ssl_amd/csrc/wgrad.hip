@@ -26,7 +26,11 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kTM = 256, kTN = 128, kBK = 16;
+#ifndef FNSSL_WGRAD_BK
+#define FNSSL_WGRAD_BK 16
+#endif
+constexpr int kTM = 256, kTN = 128, kBK = FNSSL_WGRAD_BK;   // rows per stage: 16 (two workgroups per CU) or 32 (one; experiment)
+constexpr int kRA = kBK / 8, kRB = kBK / 16;                // float4 per thread and stage: A rows ar + 8 i, B rows br + 16 j
 constexpr int kLdA = kTM + 16, kLdB = kTN + 16;          // LDS row strides (floats): stride % 64 == 16
 constexpr int kThreads = 512;
 
@@ -69,8 +73,9 @@ __device__ __forceinline__ v4f ldg4(const float* p) { return *reinterpret_cast<c
 // 1's two layers — runs one workgroup per CU).
 template <bool SMALL>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
-  __shared__ __attribute__((aligned(16))) float As[2][kBK][kLdA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kBK][kLdB];
+  extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+  float (*As)[kBK][kLdA] = reinterpret_cast<float (*)[kBK][kLdA]>(wg_smem);
+  float (*Bs)[kBK][kLdB] = reinterpret_cast<float (*)[kBK][kLdB]>(wg_smem + 2 * kBK * kLdA);
   // ---- which tile: consecutive items stay on one XCD (workgroups are dealt to the 8 XCDs round-robin)
   const int nitems = p.slabs * p.mtiles * p.ntiles;
   const int per_xcd = (nitems + 7) / 8;
@@ -116,10 +121,11 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
   // re-requested right after it has been written to LDS, i.e. two stage-times (~4000 cycles of MFMA issue per SIMD)
   // before it is needed again — one stage ahead left the HBM latency of a loaded chip exposed at the stage end.
   struct Regs {
-    v4f a0, a1, b, x0, x1;
+    v4f a[kRA], b[kRB], x[kRA];
   };
   Regs R0, R1;
-  R0.x0 = R0.x1 = R1.x0 = R1.x1 = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < kRA; ++i) R0.x[i] = R1.x[i] = v4f{0.f, 0.f, 0.f, 0.f};
   // step index of this thread's B row inside its sequence, advanced by one stage per load (32-bit arithmetic)
   int tb = (int)((r_begin + br) % p.nsteps);
   const int tb_adv = kBK % p.nsteps;
@@ -128,25 +134,36 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
     const long long r0 = r_begin + (long long)st * kBK;
     const long long ra = r0 + ar, rb_ = r0 + br;
     const v4f z = {0.f, 0.f, 0.f, 0.f};
-    R.a0 = ra < r_end ? ldg4(a_src + ra * p.lda) : z;
-    R.a1 = ra + 8 < r_end ? ldg4(a_src + (ra + 8) * p.lda) : z;
-    const bool ok = bcol_ok && rb_ < r_end && !(shift != 0 && tb == t_bad);
-    R.b = ok ? ldg4(b_src + (rb_ + shift) * bld) : z;
+#pragma unroll
+    for (int i = 0; i < kRA; ++i) R.a[i] = ra + 8 * i < r_end ? ldg4(a_src + (ra + 8 * i) * p.lda) : z;
+#pragma unroll
+    for (int j = 0; j < kRB; ++j) {
+      const int tbj = j == 0 ? tb : (tb + 16 * j) % p.nsteps;   // step index of row rb_ + 16 j inside its sequence
+      const bool ok = bcol_ok && rb_ + 16 * j < r_end && !(shift != 0 && tbj == t_bad);
+      R.b[j] = ok ? ldg4(b_src + (rb_ + 16 * j + shift) * bld) : z;
+    }
     if (do_small) {     // the whole wave reads one row: a broadcast load (rows past the end meet zero A values)
-      R.x0 = ldg4(p.xs + (ra < p.rows ? ra : p.rows - 1) * p.ldxs);
-      R.x1 = ldg4(p.xs + (ra + 8 < p.rows ? ra + 8 : p.rows - 1) * p.ldxs);
+#pragma unroll
+      for (int i = 0; i < kRA; ++i) R.x[i] = ldg4(p.xs + (ra + 8 * i < p.rows ? ra + 8 * i : p.rows - 1) * p.ldxs);
     }
     tb += tb_adv;
     if (tb >= p.nsteps) tb -= p.nsteps;
   };
   auto store_stage = [&](int buf, const Regs& R) {
-    *reinterpret_cast<v4f*>(&As[buf][ar][ac4]) = R.a0;
-    *reinterpret_cast<v4f*>(&As[buf][ar + 8][ac4]) = R.a1;
-    *reinterpret_cast<v4f*>(&Bs[buf][br][bc4]) = R.b;
-    if (do_db) dbacc += R.a0 + R.a1;
+#pragma unroll
+    for (int i = 0; i < kRA; ++i) *reinterpret_cast<v4f*>(&As[buf][ar + 8 * i][ac4]) = R.a[i];
+#pragma unroll
+    for (int j = 0; j < kRB; ++j) *reinterpret_cast<v4f*>(&Bs[buf][br + 16 * j][bc4]) = R.b[j];
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < kRA; i += 2) dbacc += R.a[i] + R.a[i + 1];
+    }
     if (do_small) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sacc[c] += R.a0[c] * R.x0 + R.a1[c] * R.x1;
+      for (int i = 0; i < kRA; i += 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sacc[c] += R.a[i][c] * R.x[i] + R.a[i + 1][c] * R.x[i + 1];
+      }
     }
   };
 
@@ -284,9 +301,16 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p) {
   }
 }
 
+constexpr size_t kWgradLds = (size_t)2 * kBK * (kLdA + kLdB) * sizeof(float);
+#if FNSSL_WGRAD_BK == 16
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) wgrad_kernel(const WgradParams p) {
   wgrad_body<false>(p);
 }
+#else
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) wgrad_kernel(const WgradParams p) {
+  wgrad_body<false>(p);
+}
+#endif
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 3))) wgrad_small_kernel(const WgradParams p) {
   wgrad_body<true>(p);
 }
@@ -411,10 +435,14 @@ int fnssl_lstm_weight_grads(const fnssl_wgrad_desc* d, void* stream) {
   const int per_xcd = (nitems + 7) / 8;
   {
     fnssl::TimedLaunch tl(H >= 256 ? "wgrad_h256" : "wgrad_h128", st, 2.0 * (double)p.rows * p.M * p.ncat);
+    if (kWgradLds > 48 * 1024) {
+      FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
+      FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgradLds));
+    }
     if (p.xs)
-      hipLaunchKernelGGL(wgrad_small_kernel, dim3(per_xcd * 8), dim3(kThreads), 0, st, p);
+      hipLaunchKernelGGL(wgrad_small_kernel, dim3(per_xcd * 8), dim3(kThreads), kWgradLds, st, p);
     else
-      hipLaunchKernelGGL(wgrad_kernel, dim3(per_xcd * 8), dim3(kThreads), 0, st, p);
+      hipLaunchKernelGGL(wgrad_kernel, dim3(per_xcd * 8), dim3(kThreads), kWgradLds, st, p);
     FNSSL_CHECK_LAUNCH("wgrad_kernel");
   }
   ReduceParams r{};

@@ -12,9 +12,11 @@ size_t bwdc_bytes(int nseq, int ndir) {
   return 256 + (tasks + 256) * (size_t)ndir * 16 * sizeof(unsigned);
 }
 
-// does the cluster kernel take this layer?  H = 128, the output slices make whole clusters inside an XCD, and at least half
-// the waves of a cluster get a group (config 4, block 1: 2 members, 9.4 groups per cluster — 10.7 against 13.4 ms on the
-// split kernels; fewer: the split kernels fill the chip better).  FNSSL_BWD_NO_CLUSTER=1 turns it off.
+// does the cluster kernel take this layer?  H = 128 and the output slices make whole clusters inside an XCD (config 4, block
+// 1: 2 members, 9.4 groups per cluster — 10.7 against 13.4 ms on the split kernels).  Round 4 kept shards of fewer than 8
+// groups per cluster on the split kernels; measured in round 5 (4 / 2 utterances per GPU: 4 / 2 groups per cluster) those
+// take 31.1 / 30.5 ms for the three layers against 10.5 / 9.7 ms here — every group pulls the whole W^T from L2 per step —
+// so the default threshold is 1 (knob BWD_CLUSTER_MIN_GROUPS).  BWD_NO_CLUSTER turns the kernel off.
 bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
   if (H != 128 || fnssl::tune(FNSSL_TUNE_BWD_NO_CLUSTER)) return false;
   // the kernel's addressing (lstm_bwdc.h locate()) takes a group's first sequence as its lowest address and lets a group
@@ -33,7 +35,7 @@ bool bwdc_handles(const BwdParams& p, int H, BwdClusterParams& cp) {
   cp.clusters_per_dir = clusters / p.ndir;
   cp.groups_per_cluster = (p.ntasks + cp.clusters_per_dir - 1) / cp.clusters_per_dir;
   const int min_groups = fnssl::tune(FNSSL_TUNE_BWD_CLUSTER_MIN_GROUPS, 1, 1 << 20);
-  return cp.groups_per_cluster >= (min_groups ? min_groups : 8);
+  return cp.groups_per_cluster >= (min_groups ? min_groups : 1);
 }
 
 // ws = the region bwdc_bytes() sizes.  FNSSL_OK, kNoCluster, or an error.

@@ -35,9 +35,10 @@ bool f32c_handles(const LstmParams& p, int H, int mode) {
     //  NO_F32C_B1 keeps it on the rounds: A/B)
     if (!(p.c0 == 256 && (mode == kSum || mode == 0)) && !(p.c0 == 4 && mode == 0 && !fnssl::tune(FNSSL_TUNE_NO_F32C_B1))) return false;
   } else {
-    if (p.reserve || p.ndir != 1 || p.c0 != 256 || fnssl::tune(FNSSL_TUNE_NO_F32_SMALL)) return false;
+    if (p.ndir != 1 || p.c0 != 256 || fnssl::tune(FNSSL_TUNE_NO_F32_SMALL)) return false;
     const bool plain = p.c2 == 0 && (mode == 0 || mode == kSum), cat = p.c2 == 4 && (mode == kHas2 || mode == (kHas2 | kSum));
     if (!plain && !cat) return false;
+    if (p.reserve && ((mode & kSum) || p.carry)) return false;   // training forward: no fused residual, no streaming
   }
   // the kernel's addressing takes a group's first sequence as its lowest address and lets a group cross ONE outer index
   // (q_inner >= 16) — or the sequences are evenly spaced in every tensor (so == q_inner * si: a 12-frame streaming chunk's
@@ -53,10 +54,16 @@ bool f32c_handles(const LstmParams& p, int H, int mode) {
   if (const int mg = fnssl::tune(FNSSL_TUNE_F32C_MIN_GROUPS, 1, 1 << 30)) {
     if (groups < mg) return false;
   }
-  // training forward (reserve): from two groups per wave of every cluster — config 4's shard has 1200 groups on 1024 SIMDs,
-  // which the 2-waves-per-group kernels run as 3 wave-times for 2.34 (0.52 of the roof), while here the groups beyond two
-  // per wave rotate over the waves step by step (lstm_f32c.h): balanced over the launch
-  if (p.reserve) return !fnssl::tune(FNSSL_TUNE_TRAIN_NO_F32_CLUSTER) && groups >= 2LL * kF32cWaves * (ncu / 8);
+  // training forward (reserve).  H = 128: config 4's shard has 1200 groups on 1024 SIMDs, which the 2-waves-per-group kernels
+  // run as 3 wave-times for 2.34 (0.52 of the roof), while here the groups beyond two per wave rotate over the waves step by
+  // step (lstm_f32c.h): balanced over the launch — and, round 5, every SMALLER shard too: 16 utterances per GPU took 38.3 ms
+  // on the split kernels, as long as 32 (37.1).  H = 256 (round 5): the narrow-band layers of shards BELOW config 4's (fewer
+  // than two groups per CU), which the 4-waves-per-group kernels ran at 80 - 86 ms per step whatever the batch (16
+  // utterances: 85.9 ms against 59.9 for 32; 24 utterances: 111 ms); from two groups per CU on, lstm_fwd2_kernel (0.82) stays.
+  if (p.reserve) {
+    if (fnssl::tune(FNSSL_TUNE_TRAIN_NO_F32_CLUSTER)) return false;
+    return H == 128 ? true : groups < 2LL * ncu;
+  }
   // H = 256: everything below the full-chip launch (12 groups per CU: lstm_static3_kernel's one round of 12 waves per CU, 0.89
   // of the roof) — in between the rounds are paced by their fullest SIMD (9 groups per CU = 3, 2, 2, 2 waves per SIMD), the
   // cluster's groups are work items that balance (16 utterances: 202 -> 176 ms for the three layers, 0.84 of the roof)
@@ -89,6 +96,8 @@ int forward_f32c(LstmParams p, int H, int mode, hipStream_t st) {
   const bool gsplit = gs_knob ? gs_knob == 4 : cp.groups_per_cluster <= 1;
   if (H == 256) {
     constexpr int W = kF32cWavesH256;
+    if (p.reserve)
+      return p.c2 == 4 ? launch_f32c_k<256, 16, 1, kHas2 | kSave, false, 2, W>(p, cp, st) : launch_f32c_k<256, 16, 0, kSave, false, 2, W>(p, cp, st);
     if (gsplit) {
       if (mode == (kHas2 | kSum)) return launch_f32c_k<256, 16, 1, kHas2 | kSum, false, 2, W, 4>(p, cp, st);
       if (mode == kHas2) return launch_f32c_k<256, 16, 1, kHas2, false, 2, W, 4>(p, cp, st);

@@ -52,7 +52,9 @@ static int plan_rounds(int tasks, int ndir, int max_split, int split4_groups_per
   if (split > 1) {
     // (one group per workgroup — 512 four-wave workgroups, two per CU, which drift apart — was measured at config 4:
     //  narrow-band BPTT 77.7 ms against 75.3 with two groups per workgroup)
-    const int nw = (split == 4 && total >= 2LL * ncu) ? 8 : 4;
+    // (more groups than CUs: two groups per workgroup as well — 24 utterances per GPU = 384 narrow-band groups ran their
+    //  BPTT as 384 one-group workgroups on 256 CUs in 72.4 ms, against 64.4 ms for config 4's 512 groups as 256 pairs)
+    const int nw = (split == 4 && total > (long long)ncu) ? 8 : 4;
     return fn(Geometry{nw, split, 0, tasks});
   }
   const int W = (int)((total + ncu - 1) / ncu);

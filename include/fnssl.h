@@ -76,7 +76,7 @@ const char* fnssl_last_error(void);
 #define FNSSL_TUNE_BF16P_DRAIN 18             /* pair-split bf16 kernels: drained ring barriers on every shape */
 #define FNSSL_TUNE_BF16W_SOLO 19              /* wide bf16 layers: one wave per group instead of the pair split */
 #define FNSSL_TUNE_BWD_NO_CLUSTER 20          /* H = 128 BPTT on the split kernels instead of the cluster-resident kernel (lstm_bwdc.h) */
-#define FNSSL_TUNE_BWD_CLUSTER_MIN_GROUPS 21  /* smallest groups-per-cluster count the cluster BPTT takes (default 8) */
+#define FNSSL_TUNE_BWD_CLUSTER_MIN_GROUPS 21  /* smallest groups-per-cluster count the cluster BPTT takes (default 1; round 4: 8) */
 #define FNSSL_TUNE_BWD_CLUSTER_NO_ROTATE 22   /* cluster BPTT: leftover groups stay with one wave */
 #define FNSSL_TUNE_BWDC_NO_PREFETCH 23        /* cluster BPTT: phase-A operands requested in their own group-step */
 #define FNSSL_TUNE_BWDC_NO_TOKEN 24           /* cluster BPTT: no per-SIMD matrix-phase token */

@@ -307,7 +307,57 @@ def test_cluster_training_forward_equals_split_kernels(dev, monkeypatch, c0, nb,
     assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)), "reserve"
 
 
-@pytest.mark.parametrize("c0g,nb,nt,nf", [(256, 32, 300, 7), (256, 33, 301, 5), (0, 32, 300, 7)])
+@pytest.mark.parametrize("mode,H,c0,c2,nb,nt,nf", [
+    ("narrow", 256, 256, 0, 16, 9, 256),      # 16 two-mic utterances per GPU: 256 groups = 16 per cluster of 16 (blocks 2-3)
+    ("narrow", 256, 256, 4, 16, 7, 256),      # block 1: the concatenated data channels
+    ("narrow", 256, 256, 4, 5, 11, 250),      # ragged: 1250 sequences, groups cross pairs
+    ("full", 128, 256, 0, 16, 300, 5),        # a 16-utterance shard's full-band layer (600 groups: below the round-4 threshold)
+    ("full", 128, 4, 0, 3, 40, 6),            # a tiny shard: 8 groups per direction
+])
+def test_cluster_training_forward_of_smaller_shards_equals_split_kernels(dev, monkeypatch, mode, H, c0, c2, nb, nt, nf):
+    """Round 5: the reserve-saving forward of shards SMALLER than config 4's runs on the cluster-resident kernel too — the
+    H = 256 narrow-band layers (clusters of 16, kSave form) below two groups per CU, the H = 128 full-band layers at any size.
+    The several-waves-per-group kernels they replace took as long for 16 utterances as for 32 (85.9 / 38.3 ms against 59.9 /
+    37.1).  h AND the reserve bit for bit equal to those kernels (TRAIN_NO_F32_CLUSTER), twice."""
+    from fnssl import ops
+    from fnssl import weights as W
+    bidir = mode == "full"
+    ndir = 2 if bidir else 1
+    sd = W.make_state([("L." + n, s) for n, s in W.lstm_param_shapes(c0 + c2, H, bidir)], seed=995 + c0 + c2)
+    packed = [ops.pack_lstm(sd["L.weight_ih_l0" + s], sd["L.weight_hh_l0" + s], sd["L.bias_ih_l0" + s], sd["L.bias_hh_l0" + s], c0, c2, dev)
+              for s in (("", "_reverse") if bidir else ("",))]
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    x0 = torch.randn((nb, nt, nf, c0), generator=g, device=dev) * 0.7
+    x2 = torch.randn((nb, nt, nf, c2), generator=g, device=dev) * 0.7 if c2 else None
+    nseq, nsteps = (nb * nt, nf) if mode == "full" else (nb * nf, nt)
+
+    def run(plan=False):
+        if mode == "full":
+            out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev)
+        else:
+            out = torch.full((nb, nf, nt, ndir * H), float("nan"), device=dev).permute(0, 2, 1, 3)
+        reserve = torch.full((ops.lstm_reserve_floats(nseq, H, ndir, nsteps),), float("nan"), device=dev)
+        r = ops.lstm_layer(mode, x0, None, x2, packed, H, out, reserve=reserve, plan_only=plan)
+        return r if plan else (out, reserve)
+
+    for k in ("FNSSL_TRAIN_NO_F32_CLUSTER", "FNSSL_NO_F32_SMALL", "FNSSL_NO_F32_CLUSTER"):
+        monkeypatch.delenv(k, raising=False)
+    ops.cluster_fallbacks(dev, reset=True)
+    assert run(plan=True)[0] == "f32_cluster", run(plan=True)
+    a, ra = run()
+    a2, ra2 = run()
+    assert ops.cluster_fallbacks(dev) == 0
+    monkeypatch.setenv("FNSSL_TRAIN_NO_F32_CLUSTER", "1")
+    assert run(plan=True)[0] == "train"
+    b, rb = run()
+    assert not torch.isnan(a).any()
+    assert torch.equal(a, b) and torch.equal(a, a2), "h"
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0)  # noqa: E731  (rows of a ragged last group stay unwritten in both)
+    assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)), "reserve"
+
+
+@pytest.mark.parametrize("c0g,nb,nt,nf", [(256, 32, 300, 7), (256, 33, 301, 5), (0, 32, 300, 7), (256, 3, 40, 6), (0, 2, 300, 5)])
 def test_cluster_bptt_equals_split_kernels(dev, monkeypatch, c0g, nb, nt, nf):
     """Round 4: back-propagation through time of the H = 128 full-band layers at config 4's shard on the cluster-resident
     kernel (lstm_bwdc.h: the 6 output slices of [W_ih | W_hh]^T over clusters of 6 CUs, 30 groups per cluster on 12 waves,

@@ -541,3 +541,9 @@ int fnssl_lstm_plan(const fnssl_lstm_desc* d, int* family, int* rounds) {
 }
 
 }  // extern "C"
+
+// ---- the generic recurrence kernels for hidden size 128 (explicit instantiation, see lstm_kernel.h; the other hidden sizes:
+// lstm_hsmall.hip, lstm_h256.hip)
+namespace fnssl_lstm {
+template int launch_h<128>(int, const LstmParams&, int, int, hipStream_t);
+}  // namespace fnssl_lstm

@@ -268,3 +268,10 @@ static int lstm_backward_impl(const fnssl_lstm_bwd_desc* d, void* stream, int dr
     return H == 128 ? launch_bwd<128>(gm.nw, gm.split, p, nwg, st) : launch_bwd<256>(gm.nw, gm.split, p, nwg, st);
   });
 }
+
+// ---- the training kernels (forward with reserve, BPTT) for hidden size 128 (explicit instantiation, see lstm_train.h; hidden
+// size 256: lstm_train_h256.hip)
+namespace fnssl_lstm {
+template int launch_bwd<128>(int, int, const BwdParams&, int, hipStream_t);
+template int launch_save<128>(int, int, const LstmParams&, int, int, hipStream_t);
+}  // namespace fnssl_lstm

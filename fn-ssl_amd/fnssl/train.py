@@ -314,6 +314,7 @@ class TrainEngine:
         self.pg = process_group          # None: the default group (if initialised); False: never distributed
         self.force_seed = None           # tests / bench parity: use exactly this base seed for the next steps
         self._pending, self._wait_events, self._reduce_now = [], None, False
+        self.last_comm_launches = 0      # all-reduces issued by the last step (one per layer with more than one rank)
         self.step_count = 0
         self.online = bool(model.is_online)
         dev = next(model.parameters()).device
@@ -345,6 +346,8 @@ class TrainEngine:
         # all-reduce): with more than one rank the backward's cluster kernels size their co-resident grids for the rest
         self.reserved_cus = 16
         self.reserve_always = False      # tests: reserve with one rank too
+        self.reduce_single_rank = False  # tests: issue the per-layer all-reduces on a ONE-rank group too (a sum over one
+                                         # rank is the identity: it exercises the RCCL plumbing a single GPU can show)
 
     # ------------------------------------------------------------------ distributed plumbing
     def _world_rank(self):
@@ -385,9 +388,11 @@ class TrainEngine:
         """Start the sum all-reduce of one layer's gradient slice (RCCL runs it on its own stream, ordered after
         everything enqueued so far on the compute stream)."""
         world, _ = self._world_rank()
-        if world <= 1 or not self._reduce_now:
+        if not self._reduce_now or (world <= 1 and not (self.reduce_single_rank and self.pg is not False and
+                                                        torch.distributed.is_available() and torch.distributed.is_initialized())):
             return
         lo, hi = self._bucket(prefix)
+        self.last_comm_launches += 1
         self._pending.append(torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                           group=self.pg or None, async_op=True))
 
@@ -485,6 +490,7 @@ class TrainEngine:
         fw, bw = self._pack_all()
         self.grad.zero_()
         self.loss_dev.zero_()
+        self.last_comm_launches = 0
         n_total = nbp * nt2 * nf2
         cp = self.chunk_pairs or nbp
         cp = max(npair, (cp // npair) * npair)            # whole utterances per chunk

@@ -184,6 +184,77 @@ def test_ddp_over_the_autograd_route_matches_single_process(tmp_path):
     assert abs(0.5 * (losses[0] + losses[1]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
 
 
+def _rccl_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "fn-ssl_amd"), ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import predict_step as ps
+    from fnssl import ops, train
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" IS RCCL on ROCm
+    sig, gt = _data()
+    x = ops.preprocess(torch.from_numpy(sig).to(dev), "MM", layout=1)
+    g = torch.from_numpy(gt).to(dev)
+    # the fused engine: per-layer gradient all-reduce on the side stream, through RCCL
+    eng = train.TrainEngine(_make(dev), seed=3)
+    eng.reduce_single_rank = True                                   # the per-bucket asynchronous all-reduces, as with N ranks
+    loss = eng.step(x, g)
+    assert eng.last_comm_launches == 7, eng.last_comm_launches      # six LSTM layers + the head
+    np.save(os.path.join(out_dir, "rccl_engine_theta.npy"), eng.theta.cpu().numpy())
+    np.save(os.path.join(out_dir, "rccl_engine_loss.npy"), np.array([loss, float(eng.cluster_fallbacks())]))
+    # the reference's route: DDP's reducer over the autograd functions, through RCCL
+    net = _make(dev).train()
+    net.dropout_seed = 3
+    ddp = DDP(net, device_ids=[0])
+    opt = torch.optim.Adam(ddp.parameters(), lr=1e-3)
+    opt.zero_grad()
+    loss = ps._MSELoss.apply(ddp(x), g)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "rccl_ddp_theta.npy"),
+            torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy())
+    np.save(os.path.join(out_dir, "rccl_ddp_loss.npy"), np.array([float(loss)]))
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_both_training_routes(tmp_path):
+    """What ONE GPU can show of the RCCL path (the N > 1 curve is the driver's): a process group on the "nccl" backend
+    (= RCCL) with this library loaded; TrainEngine.step's gradient all-reduce and DistributedDataParallel's reducer over the
+    autograd route both go through it, beside the cluster-resident kernels, and leave exactly the parameters of the same
+    step without a process group (a one-rank sum / average is the identity)."""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a ROCm device")
+    import torch.multiprocessing as mp
+    import predict_step as ps
+    from fnssl import ops, train
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    dev = torch.device("cuda:0")
+    sig, gt = _data()
+    x = ops.preprocess(torch.from_numpy(sig).to(dev), "MM", layout=1)
+    g = torch.from_numpy(gt).to(dev)
+    eng = train.TrainEngine(_make(dev), seed=3)
+    loss = eng.step(x, g)
+    got = np.load(os.path.join(str(tmp_path), "rccl_engine_loss.npy"))
+    assert got[0] == loss and got[1] == 0.0                         # same loss, no guarded fallback beside RCCL
+    np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "rccl_engine_theta.npy")), eng.theta.cpu().numpy())
+    net = _make(dev).train()
+    net.dropout_seed = 3
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    loss = ps._MSELoss.apply(net(x), g)
+    loss.backward()
+    opt.step()
+    assert np.load(os.path.join(str(tmp_path), "rccl_ddp_loss.npy"))[0] == float(loss)
+    np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "rccl_ddp_theta.npy")),
+                                  torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu().numpy())
+
+
 def test_bench_self_launches_n_ranks(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE must itself start 2 ranks (torch.distributed.run, one process per
     GPU).  This box has ONE GPU, so (a) without the test hook the call must exit non-zero, not fall back to one rank;

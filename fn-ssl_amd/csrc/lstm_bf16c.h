@@ -341,14 +341,16 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       const auto s11 = __builtin_amdgcn_permlane32_swap(d1[1], d3[1], false, false);
       const v4u lo = {s00[0], s01[0], s00[1], s01[1]};   // hb 0: tile 0 units 0-3, 4-7; hb 1: tile 2
       const v4u hi = {s10[0], s11[0], s10[1], s11[1]};   // hb 0: tile 1;                hb 1: tile 3
-      if (valid[PT]) {
+      // (a wave that gave up on a hand-off, or saw the launch draining, has multiplied operands it did not wait for: it stores
+      //  and publishes nothing more — the guarded fallback launch of the same call rewrites out / out_sum)
+      if (valid[PT] && !dead) {
         __builtin_amdgcn_raw_buffer_store_b128(lo, RO(PT), voo[PT], oo, 0);
         __builtin_amdgcn_raw_buffer_store_b128(hi, RO(PT), voo[PT], oo + 16, 0);
       }
     }
     // tiles 4 m, 4 m + 1 -> block 2 m (bytes 0-7, 8-15 of the lane's 16); tiles 4 m + 2, 4 m + 3 -> block 2 m + 1
     const int wpar = step & 1;
-    if constexpr (!(ABL & 64)) {
+    if constexpr (!(ABL & 64)) if (!dead) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[0], hq[1])), rhx, vlane, hx_off(wpar, PT, 2 * m), 16);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, join8(hq[2], hq[3])), rhx, vlane, hx_off(wpar, PT, 2 * m + 1), 16);
       // publish: the tag store follows five K-steps into the next part (pub_flush), behind an s_waitcnt vmcnt(0) — by then
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   };
 
   for (int step = 0; step < p.nsteps && !dead; ++step) static_for<NP>([&](auto pt) { part_step(pt, step); });
-  pub_flush(NP - 1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
+  if (!dead) pub_flush(NP - 1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

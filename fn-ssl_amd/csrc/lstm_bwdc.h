@@ -252,6 +252,9 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
                            [&]() { tv = __hip_atomic_load(tag_g + 8 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x60000u);
     }
     lap(0);   // drain of the previous item's output stores + hand-over wait
+    // A wave that gave up on a hand-off (or saw the launch draining) stops HERE: it stores and publishes nothing computed from
+    // operands it did not wait for (the guarded fallback launch of the same call rewrites every output)
+    if (dead) break;
 
     // ---- phase A: gate gradients of my hidden slices (the expressions of lstm_bwd_kernel, in its order) -------------
 #pragma unroll
@@ -327,6 +330,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_bwdc_kernel(const BwdParams p, 
                            [&]() { tv = __hip_atomic_load(tag_g + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 0x50000u);
     }
     lap(4);   // waiting for the other members' tags
+    if (dead) break;   // (as above: no output stores, no "phase B done" tag from rows that were not complete)
     __builtin_amdgcn_s_setprio(2);   // matrix phase above the gate arithmetic of the SIMD's other waves (none / reversed: +4 %; by wave rank: no effect)
     v4f xr[XD];
     // plain loads: a dA row is read by this CU once, after all of it has been announced — no line of it can sit in this CU's

@@ -1,0 +1,5 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final6; mkdir -p $O; cd $R
+timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -4 > $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench.err
+cat $O/pytest.log; tail -1 $O/smoke.log; cut -c1-260 $O/bench_default.json; tail -2 $O/bench.err

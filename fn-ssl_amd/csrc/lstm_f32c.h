@@ -72,9 +72,15 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   // (k - DRIFT)-th: the eight members then read a group's input rows within a few group-times of each other and the seven
   // later ones find them in the XCD's L2 (4 MB for four clusters) instead of fetching them again from memory
   constexpr int XD = NW_ > 12 ? 4 : 8;   // input ring: block v is requested XD - 1 quads (~3.6 k cycles) before its use — the other members have pushed it out of L2
+  // STRH (H = 256, a wave owns its groups): h_{t-1} is STREAMED through the operand ring behind the input blocks — [x_t | h_{t-1}]
+  // is one stream of NV0 + NS sixteen-channel blocks, as in lstm_static3_kernel — instead of held in 64 registers for the
+  // recurrent part.  That is what lets the H = 256 members run 16 waves (four per SIMD, 128 registers) like the H = 128 ones
+  // instead of 8 (two per SIMD, 237 registers): profiles/r05/n_*.
+  constexpr bool STRH = H == 256 && GS == 1 && NW_ > 8;
   static_assert((CAT ? NS0 == 1 : !(NV0 && NS0)) && (NV0 == 0 || NV0 % XD == 0) && (H == 128 || H == 256),
                 "blocks of src0, or its remainder alone, or blocks of src0 + the remainder quad of src2");
-  static_assert(H == 128 || NW_ <= 8, "H = 256: at most two waves per SIMD (register budget)");
+  static_assert(H == 128 || NW_ <= 8 || STRH, "H = 256 with the row of h_{t-1} held: at most two waves per SIMD (register budget)");
+  static_assert(!STRH || (NV0 >= XD && (NV0 + NS) % XD == 0), "streamed row: the ring depth divides the block count");
   static_assert(GS == 1 || (!SAVE && !ABLRT), "gate split: inference kernels only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ABL = ABLRT ? p.ablate : 0;
@@ -211,10 +217,10 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
   float xs0 = 0.f;
   v4f cprev = zero4, skipv = zero4;
   unsigned tagv = 0, tagd = 0;
-  auto request = [&](const Grp& gr, rsrc_t qx0, rsrc_t qsk, bool with_c) {   // early requests of group-step gr
+  auto request = [&](const Grp& gr, rsrc_t qx0, rsrc_t qsk, bool with_c, bool with_x = true) {   // early requests of group-step gr
     const unsigned tt = tt_of(gr.step);
     if (!(ABL & 8)) {
-      if constexpr (NV0 > 0) static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
+      if constexpr (NV0 > 0) if (with_x) static_for<XD>([&](auto v) { xr[v.value] = bld4(qx0, gr.vo0, tt * st0 + 64 * v.value); });
       if constexpr (NS0 > 0 && !CAT) xs0 = bld1(qx0, gr.vo0, tt * st0);
     }
     if (SUM && !(ABL & 64)) skipv = bld4(qsk, gr.vok, tt * stk + 64 * m);
@@ -251,7 +257,7 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     const v4f skip_cur = skipv;
 
     // h_{step - 1} of the whole row: every member's slice, once all NS tags show it
-    v4f hold[NS];
+    v4f hold[STRH ? 1 : NS];
     auto fetch_h = [&]() {
       if (DRIFT > 0 && !(ABL & 4) && !dead && task - DRIFT * NWS >= g0) {
         unsigned* const tag_d = tag_cl + (size_t)(task - DRIFT * NWS - g0) * NS;
@@ -263,13 +269,17 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
           dead = !bounded_wait([&]() { return __builtin_amdgcn_ballot_w64(tagv < (unsigned)step) == 0; },
                                [&]() { tagv = __hip_atomic_load(tag_g + (lane & (NS - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, 16, 0x30000u);
         if (late_c && !(ABL & 64)) cprev_cur = bld4_l2(rc, vlane, m * 1024);
+        if constexpr (!STRH) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) hold[s] = bld4_l2(ro, cur.voo, op + 64 * s);
-      } else {
+          for (int s = 0; s < NS; ++s) hold[s] = bld4_l2(ro, cur.voo, op + 64 * s);
+        }
+      } else if constexpr (!STRH) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) hold[s] = (ABL & 16) ? cprev : zero4;   // (ablation: any live register value)
       }
     };
+    const bool hrow = step > 0 || cy;                           // (STRH) the row exists: else h_{-1} = 0
+    auto hblock = [&](int j) { return hrow ? bld4_l2(ro, cur.voo, op + 64 * j) : zero4; };
 
     // ---- matrix phase: record j of quad Q + 1 is read from LDS right after the MFMAs that used record j of quad Q
     if (cp.prio_mode == 2) __builtin_amdgcn_s_setprio(2);
@@ -332,13 +342,20 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
     if constexpr (NV0 > 0) {
       static_for<NV0>([&](auto v) {
         constexpr int V = decltype(v)::value;
-        if constexpr (V == NV0 / 2) {          // half the input part is left to cover the recurrent operands' round trip
+        if constexpr (STRH) {
+          if constexpr (V == NV0 / 2) pub_flush();
+          if constexpr (V == NV0 - XD) fetch_h();   // the waits: the first block of the row is requested behind this quad
+        } else if constexpr (V == NV0 / 2) {   // half the input part is left to cover the recurrent operands' round trip
           pub_flush();
           fetch_h();
         }
         const v4f xb = xr[V % XD];
         quad(ic<1 + V>{}, xb.x, xb.y, xb.z, xb.w);
-        if constexpr (V + XD < NV0) if (!(ABL & 8)) xr[V % XD] = bld4(rx0, cur.vo0, o0 + 64 * (V + XD));
+        if constexpr (V + XD < NV0) {
+          if (!(ABL & 8)) xr[V % XD] = bld4(rx0, cur.vo0, o0 + 64 * (V + XD));
+        } else if constexpr (STRH) {
+          xr[V % XD] = hblock(V + XD - NV0);
+        }
       });
       if constexpr (NS0 > 0) quad1(ic<1 + NV0>{}, xs0);          // the 4 concatenated data channels (src2) behind the blocks
     } else {
@@ -387,12 +404,23 @@ __global__ void __launch_bounds__(NW_ * 64) lstm_f32c_kernel(const LstmParams p,
         }
         locate(nxt.task, qo0, qi0, nxt, nrx0, nro, nrsk, nro2, nrx2);
       }
-      request(nxt, nrx0, nrsk, !single && nxt.task < g0 + FULL);
+      request(nxt, nrx0, nrsk, !single && nxt.task < g0 + FULL, !STRH);
       if constexpr (CAT) xs0 = bld1(nrx2, nxt.vo2, tt_of(nxt.step) * st2);
     }
     static_for<NS>([&](auto sp) {
       constexpr int SP = decltype(sp)::value;
-      quad(ic<1 + NV0 + NS0 + SP>{}, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
+      if constexpr (STRH) {
+        constexpr int B = NV0 + SP, B2 = B + XD;                // block B of [x_t | h_{t-1}]; its ring slot is refilled with block B2
+        const v4f hb = xr[B % XD];
+        quad(ic<1 + NV0 + NS0 + SP>{}, hb.x, hb.y, hb.z, hb.w);
+        if constexpr (B2 < NV0 + NS) {
+          xr[B % XD] = hblock(B2 - NV0);
+        } else {                                                // wrapped: the next group-step's first input blocks
+          if (more) xr[B % XD] = bld4(nrx0, nxt.vo0, tt_of(nxt.step) * st0 + 64 * (B2 - NV0 - NS));
+        }
+      } else {
+        quad(ic<1 + NV0 + NS0 + SP>{}, hold[SP].x, hold[SP].y, hold[SP].z, hold[SP].w);
+      }
     });
 
     // ---- cell update of my 16 units, stores, publish

@@ -3,3 +3,4 @@ timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -4
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench.err
 cat $O/pytest.log; tail -1 $O/smoke.log; cut -c1-260 $O/bench_default.json; tail -2 $O/bench.err
+mkdir -p $O; timeout 300 python tools/latency_bench.py --json $O/latency.json > $O/latency.txt 2>&1; grep -E "^utt|^batch|^chunk" $O/latency.txt | cut -c1-200

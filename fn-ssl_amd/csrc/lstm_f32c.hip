@@ -63,7 +63,9 @@ bool f32c_handles(const LstmParams& p, int H, int mode) {
   // utterances: 85.9 ms against 59.9 for 32; 24 utterances: 111 ms); from two groups per CU on, lstm_fwd2_kernel (0.82) stays.
   if (p.reserve) {
     if (fnssl::tune(FNSSL_TUNE_TRAIN_NO_F32_CLUSTER)) return false;
-    return H == 128 ? true : groups < 2LL * ncu;
+    // (H = 256, end of round 5: with the streamed row and 16 waves per member the cluster kernel also takes config 4's shard and
+    //  anything larger — 57.8 against lstm_fwd2_kernel's 59.6 ms for the three layers; lstm_fwd2_kernel stays its guarded fallback)
+    return true;
   }
   // H = 256: everything below the full-chip launch (12 groups per CU: lstm_static3_kernel's one round of 12 waves per CU, 0.89
   // of the roof) — in between the rounds are paced by their fullest SIMD (9 groups per CU = 3, 2, 2, 2 waves per SIMD), the

@@ -565,15 +565,20 @@ def test_two_groups_per_wave_training_forward_equals_four_waves_per_group(dev, m
         ops.lstm_layer("narrow", x0, None, x2, packed, H, out, reserve=reserve)
         return out, reserve
 
-    monkeypatch.delenv("FNSSL_NO_FWD2", raising=False)
+    # (end of round 5: the cluster-resident kernel with the streamed row takes this launch by default — lstm_f32c.h — and
+    #  lstm_fwd2_kernel is its guarded fallback: all three families must agree)
+    for k in ("FNSSL_NO_FWD2", "FNSSL_TRAIN_NO_F32_CLUSTER"):
+        monkeypatch.delenv(k, raising=False)
+    c, rc = run()
+    monkeypatch.setenv("FNSSL_TRAIN_NO_F32_CLUSTER", "1")
     a, ra = run()
     a2, ra2 = run()
     monkeypatch.setenv("FNSSL_NO_FWD2", "1")
     b, rb = run()
     assert not torch.isnan(a).any()
-    assert torch.equal(a, b) and torch.equal(a, a2), "h"
-    nn = lambda t: torch.nan_to_num(t, nan=-7.0)  # noqa: E731  (rows of a ragged last group stay unwritten in both)
-    assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)), "reserve"
+    assert torch.equal(a, b) and torch.equal(a, a2) and torch.equal(a, c), "h"
+    nn = lambda t: torch.nan_to_num(t, nan=-7.0)  # noqa: E731  (rows of a ragged last group stay unwritten in all)
+    assert torch.equal(nn(ra), nn(rb)) and torch.equal(nn(ra), nn(ra2)) and torch.equal(nn(ra), nn(rc)), "reserve"
 
 
 def test_cluster_bptt_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch):

@@ -53,7 +53,8 @@ struct F32ClusterParams {
                         // order, a static rank per wave and a staggered start were measured as well: equal or worse.
 };
 
-// HH: hidden size (128: clusters of 8; 256: clusters of 16, NW_ <= 8 — the row of h_{t-1} alone is 64 registers);
+// HH: hidden size (128: clusters of 8; 256: clusters of 16 — NW_ = 16 with h_{t-1} streamed through the operand ring (STRH below),
+// NW_ <= 8 with the row held, 64 registers: the gate-split form and launches of up to 8 groups per cluster);
 // NV0: 16-channel blocks of the summed input; NS0: one 4-channel remainder quad — of src0 (block 1's full-band layer, NV0
 // = 0) or, with MODE & kHas2, of the concatenated src2 behind the NV0 blocks of src0 (block 1's narrow-band layer);
 // MODE: kSum / kHas2 / kSave bits

@@ -22,6 +22,7 @@ torch.cuda.set_device(dev)
 N = int(os.environ.get("REPS", 200))
 CASES = [  # name, mode, H, nb, nt, nf, c2, summed
     ("H=256 narrow, 4-mic utterance (6 groups per cluster of 16), [256 | 4] + residual", "narrow", 256, 6, 60, 256, 4, True),
+    ("H=256 narrow, 96 pairs (96 groups per cluster: h streamed through the operand ring, 16 waves per member)", "narrow", 256, 96, 24, 256, 4, True),
     ("H=256 narrow, 2-mic utterance (1 group per cluster: gate split)", "narrow", 256, 1, 60, 256, 0, True),
     ("H=128 full, 2-mic utterance (1 group per cluster and direction: gate split)", "full", 128, 1, 249, 64, 0, True),
     ("H=128 full, 12-frame chunk of 6 pairs (72 evenly spaced sequences: gate split)", "full", 128, 6, 12, 64, 0, False),

@@ -1287,6 +1287,8 @@ def test_lstm_f32_cluster_kernel_equals_rounds_and_oracle(dev, monkeypatch, nb, 
     ("narrow", 256, 6, 20, 256, 4, True),      # block 1: [256 | 4] = the concatenated data channels as a remainder quad of src2
     ("narrow", 256, 1, 37, 256, 4, False),     # one 2-mic utterance: ONE group per cluster, last block's shape (no residual)
     ("narrow", 256, 3, 13, 250, 0, False),     # ragged: 750 sequences = 46 groups + 14 sequences, groups cross pairs
+    ("narrow", 256, 11, 9, 250, 4, True),      # 172 groups = 11 per cluster (ragged): h_{t-1} streamed through the operand ring, 16 waves
+    ("narrow", 256, 40, 5, 256, 0, False),     # 40 per cluster = 2 per wave + 8 leftover groups that change hands every step (streamed-row form)
     ("full", 128, 1, 249, 256, 0, True),       # one 2-mic utterance, full-band: 16 groups per direction = one per cluster
     ("full", 128, 6, 40, 256, 0, False),       # 240 sequences: 15 groups per direction, fewer than clusters
 ])
@@ -1362,7 +1364,7 @@ def test_few_sequence_launches_take_the_slice_resident_cluster_kernel_and_equal_
     assert_close(got, O.lstm(seq, sd, "L.", bidir), RTOL, ATOL, "few-sequence cluster kernel vs oracle")
 
 
-@pytest.mark.parametrize("kind", ["f32", "bf16", "f32_h256", "f32_gate_split", "f32_h256_gate_split"])
+@pytest.mark.parametrize("kind", ["f32", "bf16", "f32_h256", "f32_gate_split", "f32_h256_gate_split", "f32_h256_streamed_row"])
 def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(dev, monkeypatch, kind):
     """A member workgroup that never shows up (FNSSL_CLUSTER_TEST_STALL: what a CU-masked, shared or busy device does to
     a kernel that needs all its members resident) must cost time, not the process and not the result: the waiting waves
@@ -1392,8 +1394,11 @@ def test_cluster_kernel_gives_up_cleanly_and_the_same_call_recomputes_the_layer(
             mode_, H, c0, c2, nb, nt, nf, ndir = "full", 128, 256, 0, 1, 249, 64, 2      # 16 groups per direction = 1 per cluster
         elif kind == "f32_h256_gate_split":
             mode_, H, c0, c2, nb, nt, nf, ndir = "narrow", 256, 256, 4, 1, 40, 256, 1     # 16 groups = 1 per cluster of 16
+        elif kind == "f32_h256_streamed_row":
+            mode_, H, c0, c2, nb, nt, nf, ndir = "narrow", 256, 256, 4, 10, 24, 256, 1    # 160 groups = 10 per cluster: 16 waves per
+                                                                                            # member, h_{t-1} through the operand ring
         else:
-            mode_, H, c0, c2, nb, nt, nf, ndir = "narrow", 256, 256, 4, 6, 40, 256, 1     # 96 groups = 6 per cluster
+            mode_, H, c0, c2, nb, nt, nf, ndir = "narrow", 256, 256, 4, 6, 40, 256, 1     # 96 groups = 6 per cluster (row held)
         sd = lstm_state(c0 + c2, H, ndir == 2, 5720 + nb)
         w = [ops.pack_lstm(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_], c0, c2, dev)
              for s_ in (("", "_reverse") if ndir == 2 else ("",))]

@@ -174,6 +174,12 @@ __global__ void __launch_bounds__(NW * 64) lstm_static3_kernel(const LstmParams 
 
     for (int pr = 0; pr < NP; ++pr) {
       const int s0 = 2 * pr;
+#ifdef FNSSL_BUILD_ABLATE   // timing ablation (wrong results): FNSSL_STATIC3_ABL bit 1 = no operand loads in every second pass (what
+      // four slices per pass would request), bit 2 = no operand loads at all
+      const bool skip_ring = (p.ablate & 2) || ((p.ablate & 1) && (pr & 1));
+#else
+      constexpr bool skip_ring = false;
+#endif
       v4f cprev0 = zero4, cprev1 = zero4, skip0 = zero4, skip1 = zero4;
       const bool last = pr + 1 == NP;
       // the input blocks requested across the end of the pass: the same row, or (last pair) the next step's
@@ -197,14 +203,16 @@ __global__ void __launch_bounds__(NW * 64) lstm_static3_kernel(const LstmParams 
         SQUAD3(QI, ob.x, ob.y, ob.z, ob.w);
         // request block B + XD: of this pass, or (wrapping) of the next one
         constexpr int BN = (B + XD) % NB;
-        if constexpr (B + XD < NB) {
-          if constexpr (BN < NV0)
-            br[B % XD] = bld4(rx0, vo0, o0 + 64 * BN);
-          else
-            br[B % XD] = bld4(rh, voo, op + 64 * (BN - NV0));
-        } else {
-          static_assert(BN < NV0, "the wrapped requests are input blocks");
-          br[B % XD] = bld4(rx0, vo0, nx + 64 * BN);
+        if (!skip_ring) {
+          if constexpr (B + XD < NB) {
+            if constexpr (BN < NV0)
+              br[B % XD] = bld4(rx0, vo0, o0 + 64 * BN);
+            else
+              br[B % XD] = bld4(rh, voo, op + 64 * (BN - NV0));
+          } else {
+            static_assert(BN < NV0, "the wrapped requests are input blocks");
+            br[B % XD] = bld4(rx0, vo0, nx + 64 * BN);
+          }
         }
         if constexpr (B == NB - 4) {       // cell state / residual operand of the first slice: four quads ahead of their use
           if (step > 0) cprev0 = bld4(rc, vlane, s0 * 1024);

@@ -3,7 +3,11 @@
 
 namespace fnssl_lstm {
 
-int launch_static3_h256(const LstmParams& p, int mode, int nwg, hipStream_t st) {
+int launch_static3_h256(const LstmParams& p_in, int mode, int nwg, hipStream_t st) {
+  LstmParams p = p_in;
+#ifdef FNSSL_BUILD_ABLATE
+  p.ablate = env_int("FNSSL_STATIC3_ABL", 1, 3);
+#endif
   // Ring geometry of lstm_static2_kernel: 6-quad chunks, 4 staging registers per wave, 48 barriers per step.  (9-quad
   // chunks — 6 staging registers, 32 barriers per step — were built and measured: 111.1 against 110.3 ms with the fused
   // residual, 108.2 against 107.5 without, 112.1 against 110.7 for block 1's layer: fewer barriers, longer skew; not kept.)

@@ -247,7 +247,8 @@ class FnsslForward:
                                "16-sequence group per cluster of 8 CUs — latency-bound by the per-step hand-off, not by the matrix pipe)",
                                PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
         if self.nb * self.n_pairs * 256 // 16 < 12 * 256:      # below the full-chip launch the narrow-band layers run lstm_f32c_kernel<256>
-            traffic, src = traffic_of("c2b1_lstm_h256") if self.nb == 1 and self.n_pairs == 6 else (None, None)
+            traffic, src = (traffic_of("c2b1_lstm_h256") if self.nb == 1 and self.n_pairs == 6 else
+                            traffic_of("c2M_lstm_h256") if self.nb * self.n_pairs == 96 else (None, None))
             return kernel_roof(kern, "lstm_h256", "lstm_f32c_kernel<H=256> (narrow-band LSTM: hidden slices over clusters of 16 CUs, weight "
                                "slice resident in LDS, groups as work items)", PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
         if self.args.bf16:

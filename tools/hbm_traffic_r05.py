@@ -27,6 +27,9 @@ KEYS = {
     "c2b1": ("c2b1_lstm_h256", "lstm_f32c_kernel<256", 1536 * 300 * 7 * KIB,
              "one 4-mic utterance: 1536 sequences x 300 steps x 7 KiB per sequence-step (the basis of c2_lstm_h256); every one of "
              "the 16 members of a cluster reads the whole x_t and h_{t-1} rows: L2 hits when the members keep together"),
+    "c2M": ("c2M_lstm_h256", "lstm_f32c_kernel<256", 24576 * 300 * 7 * KIB,
+            "the 'M' pairing of config 2's batch (96 pairs): 24576 sequences x 300 steps x 7 KiB per sequence-step (the basis of "
+            "c2_lstm_h256); streamed-row form, 16 waves per member, 96 groups per cluster of 16 CUs"),
     "c2s": ("c2s_lstm_h128", "lstm_f32c_kernel<128", 72 * 256 * 2 * 3.5 * KIB,
             "a 12-frame chunk of 6 pairs: 72 sequences x 256 steps x 2 directions x 3.5 KiB per sequence-step (x_t 1 KiB read, h "
             "0.5 KiB written and read back, cell state both ways, residual operand / sum where fused)"),

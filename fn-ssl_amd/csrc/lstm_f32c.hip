@@ -70,7 +70,13 @@ bool f32c_handles(const LstmParams& p, int H, int mode) {
   // H = 256: everything below the full-chip launch (12 groups per CU: lstm_static3_kernel's one round of 12 waves per CU, 0.89
   // of the roof) — in between the rounds are paced by their fullest SIMD (9 groups per CU = 3, 2, 2, 2 waves per SIMD), the
   // cluster's groups are work items that balance (16 utterances: 202 -> 176 ms for the three layers, 0.84 of the roof)
-  if (H == 256) return groups < 12LL * ncu;
+  if (H == 256) {
+    // ... and ABOVE it whenever the groups do not fill whole rounds of 12 waves per CU (48 utterances = 18 groups per CU: two
+    // rounds of 9 = 3, 2, 2, 2 waves per SIMD, i.e. two full round-times for 1.5 rounds of work): the streamed-row form keeps
+    // its 0.86 - 0.89 at any group count, the rounds lose what their last round idles
+    const long long full = 12LL * ncu, rounds = (groups + full - 1) / full;
+    return groups < full || groups * 100 < rounds * full * 97;
+  }
   return !fnssl::tune(FNSSL_TUNE_NO_F32_SMALL) || groups >= 12LL * ncu;
 }
 

@@ -16,20 +16,25 @@ A "step" is one pass of the hot path over one synthetic batch already resident i
 per-GPU batch (weak scaling; utterances are independent: no data-path collective, config 4 has the one gradient
 all-reduce) — or, with --scaling strong (config 2), an even share of the configuration's GLOBAL batch, and the line
 then carries `strong_scaling.efficiency` against one rank running the whole batch in the same run.  K steps are timed
-between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line whose `value` is utterance-frames per second
-over all ranks.  The default run (no flags) nests config 2's 'M' pairing and is_online=False variants ("2M", "2off"), the
+between barrier + synchronize, max over ranks; rank 0 prints ONE JSON line (compact: < 4 KB, `compact_line`) whose `value`
+is utterance-frames per second over all ranks; the FULL record goes to --detail (default gpurun_out/bench_detail.json).
+The default run (no flags) also measures config 2's 'M' pairing and is_online=False variants ("2M", "2off"), the
 reference's real predict shape — ONE 4-mic utterance, whole ("2b1") and streamed in 12-frame chunks ("2s") — and configs
-3, 4, 5 under `other_configs`, each with its own roofline / cpu_baseline / parity.  Every line carries `cluster_fallbacks`
-(LSTM launches of the timed region whose cluster-resident kernel gave up and were recomputed by the guarded fallback
-kernels: must be 0, else `value` is null) and `peak_mem_gb` (of that configuration alone).  The line also carries
-  ab           : same-process A/B legs run AFTER the timed region (A = the shipped default, B = an environment knob that
-                 restores the previous kernels; alternating, a few steps each) — a box-independent record of what a
-                 kernel change is worth; roofline.peak_measured = this device's own fp32-MFMA ceiling (fnssl_mfma_f32_peak);
-  roofline     : the dominant kernel against its roof, timed with HIP events on the launch stream inside the timed
-                 region — only that kernel is bracketed there (fnssl_timing_select); `kernels` and `frontend` (the STFT
-                 + feature kernels against the HBM roof, config 2) come from an instrumented pass before it;
+3, 4, 5: the stdout line carries {value, ms_per_step, roofline_frac, cpu_baseline, parity_ok} of each under
+`other_configs`, the detail file their full lines (own roofline / cpu_baseline / parity).  Every line carries
+`cluster_fallbacks` (LSTM launches of the timed region whose cluster-resident kernel gave up and were recomputed by the
+guarded fallback kernels: must be 0, else `value` is null) and `peak_mem_gb` (of that configuration alone).
+stdout line:
+  roofline     : the dominant kernel against its roof {bound, kernel, achieved, peak, frac, traffic, launches, avg_ms,
+                 flop_per_launch}, timed with HIP events on the launch stream inside the timed region — only that kernel
+                 is bracketed there (fnssl_timing_select); peak_measured / peak_measured_sustained = this device's own
+                 fp32-MFMA ceiling, a 35-ms burst and >= 2 s of back-to-back launches (fnssl_mfma_f32_peak), with the
+                 slowest / fastest XCD clock of the sustained run — what makes a slow box attributable from the line;
   cpu_baseline : the CPU restatement of the reference (oracle/) timed on this host on a bounded sample
-                 (N = 1, rank 0 only), and `parity`: the same sample through the HIP path vs that CPU output.
+                 (N = 1, rank 0 only), and `parity`: the same sample through the HIP path vs that CPU output;
+  ab_gain_pct  : per same-process A/B leg, what the shipped default gains over the knob that restores the old kernels.
+detail file only: `kernels` and `frontend` tables (instrumented pass before the timed region), `ab` legs in full, the
+prose fields (`traffic_source`, `how`, `sample` unclipped).
 A failed parity check nulls `value` and exits 1.
 """
 import argparse
@@ -722,6 +727,104 @@ class Ipdnet2Forward:
 WORKLOADS = {2: FnsslForward, 3: IpdnetForward, 4: FnsslTrain, 5: Ipdnet2Forward}
 
 
+# ------------------------------------------------------------------------------------------------------------ #
+# the ONE stdout line: compact (< 4 KB); everything else goes to the detail file
+# ------------------------------------------------------------------------------------------------------------ #
+LINE_LIMIT = 4096
+_CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_ms", "flop_per_launch",
+              "peak_measured", "frac_of_peak_measured", "peak_measured_sustained", "slowest_xcd_mhz", "fastest_xcd_mhz")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+_TOP_KEYS = ("cluster_fallbacks", "rccl_world_size", "backend", "peak_mem_gb", "whole_path_tflops",
+             "ms_per_step_median_hip_events", "ms_per_step_per_rank")
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+def _pick(d, keys, clip=None):
+    if not isinstance(d, dict):
+        return d
+    return {k: (_clip(d[k], clip[k]) if clip and k in clip else d[k]) for k in keys if k in d}
+
+
+def compact_line(full, detail_path=None, limit=LINE_LIMIT):
+    """The stdout line of a run: the contract keys of the headline, its roofline / cpu_baseline / parity in numbers, and
+    `other_configs` reduced to five numbers per key.  Per-kernel tables, A/B legs and the prose (`*_source`, `how`) stay
+    in the full record (`detail_path`).  Guaranteed `len(json.dumps(result)) < limit`: optional keys are dropped in a
+    fixed order if a line would still be too long (the contract keys never are)."""
+    line = {k: full.get(k) for k in _CONTRACT}
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = _clip(cfg.get("workload", ""), 260)
+    for k in list(cfg):
+        if k != "workload" and isinstance(cfg[k], str):
+            cfg[k] = _clip(cfg[k], 60)
+    line["config"] = cfg
+    line["roofline"] = _pick(full.get("roofline"), _ROOF_KEYS, {"kernel": 100})
+    line["cpu_baseline"] = _pick(full.get("cpu_baseline"), _CPU_KEYS, {"sample": 150})
+    par = full.get("parity")
+    line["parity"] = _pick(par, ("max_abs_err", "rtol", "atol", "ok"))
+    for k in _TOP_KEYS:
+        if k in full:
+            line[k] = full[k]
+    fe = full.get("frontend")
+    if isinstance(fe, dict):
+        line["frontend"] = _pick(fe, ("bound", "achieved", "peak", "unit", "frac", "ms_per_step"))
+    if isinstance(full.get("strong_scaling"), dict):
+        line["strong_scaling"] = _pick(full["strong_scaling"], ("global_batch", "utterances_per_rank",
+                                                                "one_rank_same_run_ms_per_step", "efficiency"))
+    if isinstance(full.get("ab"), dict):        # the A/B legs as one number each: what the shipped default gains over the knob
+        line["ab_gain_pct"] = {_clip(k, 40): v.get("gain_of_default_pct") for k, v in full["ab"].items()}
+    others = full.get("other_configs")
+    if isinstance(others, dict):
+        small = {}
+        for key, o in others.items():
+            if not isinstance(o, dict) or o.get("error"):
+                small[key] = {"error": _clip(str((o or {}).get("error", "?")), 80)}
+                continue
+            r, c, p = o.get("roofline") or {}, o.get("cpu_baseline") or {}, o.get("parity") or {}
+            small[key] = {"value": o.get("value"), "ms_per_step": o.get("ms_per_step"), "dtype": o.get("dtype"),
+                          "roofline_frac": r.get("frac"), "cpu_baseline": c.get("value"), "parity_ok": p.get("ok"),
+                          "cluster_fallbacks": o.get("cluster_fallbacks"), "peak_mem_gb": o.get("peak_mem_gb")}
+        line["other_configs"] = small
+    if detail_path:
+        line["detail"] = detail_path
+    # fit: drop optional keys, least important first
+    for victim in ("ms_per_step_per_rank", "frontend", "ab_gain_pct", "detail", "ms_per_step_median_hip_events", "backend",
+                   "peak_mem_gb", "whole_path_tflops"):
+        if len(json.dumps(line)) < limit:
+            break
+        if victim == "ms_per_step_per_rank" and len(line.get(victim) or []) <= 8:
+            continue
+        line.pop(victim, None)
+    if len(json.dumps(line)) >= limit and isinstance(line.get("other_configs"), dict):
+        line["other_configs"] = {k: (v if "error" in v else {"value": v.get("value"), "ms_per_step": v.get("ms_per_step")})
+                                 for k, v in line["other_configs"].items()}
+    if len(json.dumps(line)) >= limit:
+        line["config"] = {"workload": _clip(cfg["workload"], 120)}
+        if isinstance(line.get("cpu_baseline"), dict):
+            line["cpu_baseline"]["sample"] = _clip(line["cpu_baseline"].get("sample"), 60)
+    assert len(json.dumps(line)) < limit, "compact line still %d bytes" % len(json.dumps(line))
+    return line
+
+
+def write_detail(full, path):
+    """The full record of the run (what the stdout line used to carry) as indented JSON; returns the path or None."""
+    try:
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, sort_keys=False)
+            f.write("\n")
+        return path
+    except OSError as e:
+        log("could not write %s: %r" % (path, e))
+        return None
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -854,6 +957,14 @@ def run_workload(args, cfg, dev, rank, world, dist, backend, steps, warmup):
             roof["frac_of_peak_measured"] = round(roof["achieved"] / pm, 4) if pm > 0 else None
             roof["peak_measured_how"] = ("fnssl_mfma_f32_peak on this device in this process: v_mfma_f32_16x16x4_f32 only, 2 waves "
                                          "per SIMD on every CU, HIP events, best of 3")
+            # ... and held for >= 2 s (the regime a 10-s timed region runs in), with the XCD clocks of the last launch
+            if getattr(args, "sustained_seconds", 0) > 0:
+                sp = ops.mfma_f32_peak_sustained(seconds=args.sustained_seconds)
+                roof["peak_measured_sustained"] = round(sp["tflops_last_quarter"], 1)
+                roof["slowest_xcd_mhz"], roof["fastest_xcd_mhz"] = sp["slowest_xcd_mhz"], sp["fastest_xcd_mhz"]
+                roof["peak_sustained_detail"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in sp.items()}
+                log("fp32 MFMA ceiling: burst %.1f, sustained %.1f TFLOP/s over %.1f s (last quarter %.1f); XCD clocks %s MHz"
+                    % (pm, sp["tflops"], sp["seconds"], sp["tflops_last_quarter"], sp["xcd_mhz"]))
         except Exception as e:            # calibration only
             log("mfma_f32_peak failed: %r" % (e,))
     # (b) same-process A/B of the kernels this and the previous round changed (A = the shipped default, B = the knob):
@@ -987,6 +1098,12 @@ def main():
     ap.add_argument("--ab-steps", type=int, default=-1,
                     help="steps per leg of the same-process A/B legs run after the timed region (config 2; default 3 in the "
                          "plain default run, else 0)")
+    ap.add_argument("--sustained-seconds", type=float, default=-1.0,
+                    help="length of the sustained fp32-MFMA calibration after the timed region (roofline.peak_measured_sustained; "
+                         "default 2 s for the primary configuration of a one-rank run, 0 = off)")
+    ap.add_argument("--detail", default=os.path.join("gpurun_out", "bench_detail.json"),
+                    help="where the FULL record of the run goes (per-kernel tables, A/B legs, nested configurations in full); "
+                         "stdout carries the compact line (< 4 KB) only.  Relative paths are taken from the repo root")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -1031,6 +1148,8 @@ def main():
         others = "2M,2off,2b1,2s,3,4,5" if plain else ""
     if args.ab_steps < 0:
         args.ab_steps = 3 if plain else 0
+    if args.sustained_seconds < 0:
+        args.sustained_seconds = 2.0
     if args.scaling == "strong" and args.config != 2:
         raise SystemExit("--scaling strong is defined for config 2 (the fixed global batch of the headline)")
     other_ids = [c.strip() for c in others.split(",") if c.strip()]
@@ -1047,7 +1166,7 @@ def main():
         sub = argparse.Namespace(**vars(args))
         sub.nb, sub.frames, sub.nch, sub.ch_mode, sub.chunk_pairs = 0, 300, 4, "MM", 0
         sub.offline = sub.bf16 = sub.c_step = False
-        sub.ab_steps, sub.scaling, sub.stream_chunk = 0, "weak", 0
+        sub.ab_steps, sub.scaling, sub.stream_chunk, sub.sustained_seconds = 0, "weak", 0, 0.0
         nsteps = max(1, min(args.steps, args.other_steps))
         if variant:
             # "2b1" / "2s": the reference's real predict shape (Learner.py:219-272: ONE recording) — one 4-mic utterance as a
@@ -1073,7 +1192,14 @@ def main():
     if rank == 0:
         if nested:
             line["other_configs"] = nested
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        # the full record (per-kernel tables, A/B legs, prose) goes to the detail file; stdout gets the compact line only:
+        # the driver keeps ~10 KB of stdout, and a line it cannot parse is an unmeasured round
+        detail = write_detail(line, args.detail if os.path.isabs(args.detail) else os.path.join(ROOT, args.detail))
+        small = compact_line(line, os.path.relpath(detail, ROOT) if detail else None)
+        log("headline: %s frames/s, %.3f ms/step, roofline frac %s, cpu_baseline %s; detail -> %s"
+            % (small["value"], small["ms_per_step"], (small.get("roofline") or {}).get("frac"),
+               (small.get("cpu_baseline") or {}).get("value"), detail))
+        os.write(json_fd, (json.dumps(small) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
     if failed:

@@ -175,6 +175,13 @@ static size_t cluster_bytes(int nseq, int hidden, int ndir, int precision) {
   return 256 + (groups + 512) * ndir * (hidden / 16) * sizeof(unsigned);   // one tag word per (group, member); +512: the last cluster's groups are rounded up
 }
 
+// ... and behind that, for the one shape whose STREAMING calls (carry_state) the cluster-resident fp32 kernel takes (H = 256,
+// one direction): a snapshot of the carried cell state.  lstm_f32c_kernel updates c in place every step, so a launch that gives
+// up has already overwritten c_{-1}; the guarded fallback of the same call restarts from the snapshot (restore_cell_kernel).
+static size_t carry_backup_bytes(int nseq, int hidden, int ndir, int precision) {
+  return (precision == FNSSL_PRECISION_FP32 && hidden == 256 && ndir == 1) ? cell_scratch_bytes(nseq, hidden, ndir) : 0;
+}
+
 int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_per_wg, int cap) {
   FNSSL_REQUIRE((hidden == 128 || hidden == 256) && nseq > 0 && (ndir == 1 || ndir == 2) && ncu > 0 && waves_per_wg && cap > 0,
                 "lstm_plan_rounds: bad arguments");
@@ -187,7 +194,8 @@ int fnssl_lstm_plan_rounds(int hidden, int nseq, int ndir, int ncu, int* waves_p
 
 size_t fnssl_lstm_workspace_bytes_ex(int nseq, int hidden, int ndir, int precision) {
   if (nseq <= 0 || hidden <= 0 || ndir <= 0) return 0;
-  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir) + cluster_bytes(nseq, hidden, ndir, precision);
+  return cell_scratch_bytes(nseq, hidden, ndir) + pair_stream_bytes(hidden, ndir) + cluster_bytes(nseq, hidden, ndir, precision) +
+         carry_backup_bytes(nseq, hidden, ndir, precision);
 }
 
 size_t fnssl_lstm_workspace_bytes(int nseq, int hidden, int ndir) {   // sufficient for every precision
@@ -209,6 +217,14 @@ __global__ void __launch_bounds__(256) pair_stream_kernel(const float4* __restri
   const long long pp = pq / qps;
   const long long src = (((2 * pp + j) * qps + q) * 4 + r) * 64 + l;
   out[i] = in[src];
+}
+
+// guarded fallback of a streaming (carry) call, first step: put back the cell state the aborted cluster kernel has advanced.
+// Returns at once unless the cluster kernel left a non-zero status word.
+__global__ void __launch_bounds__(256) restore_cell_kernel(const unsigned* __restrict__ guard, const float4* __restrict__ backup,
+                                                           float4* __restrict__ cell, long long n4) {
+  if (__hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) cell[i] = backup[i];
 }
 }  // namespace
 
@@ -383,6 +399,13 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
   // — followed, in the same call, by the rounds below as its GUARDED fallback (they return at once unless the cluster
   // kernel recorded a hand-off it gave up on: include/fnssl.h, fnssl_lstm_forward)
   if (d->variant == 0 && !(mode & kHas1) && f32c_handles(p, H, mode)) {
+    // streaming call: the cluster kernel advances the carried cell state in place — snapshot c_{-1} first, so that the guarded
+    // fallback below can restart from it if the launch gives up (carry_backup_bytes)
+    const size_t cell_bytes = cell_scratch_bytes(d->nseq, H, d->ndir);
+    char* backup = p.cluster_ws + cluster_bytes(d->nseq, H, d->ndir, d->precision);
+    const bool snap = p.carry && !dry && carry_backup_bytes(d->nseq, H, d->ndir, d->precision) >= cell_bytes;
+    FNSSL_REQUIRE(!p.carry || dry || snap, "lstm_forward: no room for the carried cell state's snapshot (hidden %d)", H);
+    if (snap) FNSSL_HIP(hipMemcpyAsync(backup, p.cscratch, cell_bytes, hipMemcpyDeviceToDevice, st));
     const int rc = forward_f32c(p, H, mode, st);
     if (rc == FNSSL_OK) {
       report(FNSSL_LSTM_FAMILY_F32_CLUSTER);
@@ -390,6 +413,12 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
       if (dry) return FNSSL_OK;
       guarded = true;
       p.guard = reinterpret_cast<const unsigned*>(p.cluster_ws);
+      if (snap) {
+        const long long n4 = (long long)(cell_bytes / 16);
+        hipLaunchKernelGGL(restore_cell_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 2048)), dim3(256), 0, st, p.guard,
+                           reinterpret_cast<const float4*>(backup), reinterpret_cast<float4*>(p.cscratch), n4);
+        FNSSL_CHECK_LAUNCH("restore_cell_kernel");
+      }
     } else if (rc != kNoCluster) {
       return rc;
     }

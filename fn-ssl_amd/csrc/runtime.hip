@@ -208,8 +208,15 @@ typedef float peak_v4f __attribute__((ext_vector_type(4)));
 // (dependent latency 40 cycles < 4 x 32 cycles of issue), `wps` waves per SIMD on every CU.  bench.py times it with
 // HIP events and reports it as roofline.peak_measured, so that a 2 % difference between two boxes (clock, power
 // budget) cannot hide or fake a 2 % kernel gain.
-__global__ void __launch_bounds__(256) mfma_f32_peak_kernel(float* out, int iters) {
+// `clk` (may be null): per workgroup {shader cycles, 100 MHz wall ticks, XCC id} of wave 0 over the whole loop — the clock the
+// XCD actually ran at while the matrix pipe was saturated (the sustained mode of bench.py reads it after >= 2 s of launches).
+__global__ void __launch_bounds__(256) mfma_f32_peak_kernel(float* out, int iters, unsigned long long* clk) {
   const int lane = threadIdx.x & 63;
+  unsigned long long c0 = 0, r0 = 0;
+  if (clk) {
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
   peak_v4f acc[4];
   for (int i = 0; i < 4; ++i) acc[i] = peak_v4f{0.f, 0.f, 0.f, 0.f};
   float a = 1.0f + 0.001f * lane, b = 0.5f - 0.002f * lane;
@@ -225,19 +232,33 @@ __global__ void __launch_bounds__(256) mfma_f32_peak_kernel(float* out, int iter
   }
   const peak_v4f r = acc[0] + acc[1] + acc[2] + acc[3];
   out[(size_t)blockIdx.x * 256 + threadIdx.x] = r.x + r.y + r.z + r.w;
+  if (clk && threadIdx.x == 0) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    clk[3 * (size_t)blockIdx.x + 0] = c1 - c0;
+    clk[3 * (size_t)blockIdx.x + 1] = r1 - r0;
+    clk[3 * (size_t)blockIdx.x + 2] = xcc & 15u;
+  }
 }
 }  // namespace
 
 extern "C" {
 
-int fnssl_mfma_f32_peak(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop, void* stream) {
+int fnssl_mfma_f32_peak_clocks(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop,
+                               unsigned long long* clocks, size_t clocks_len, void* stream) {
   FNSSL_REQUIRE(out && flop && iters > 0 && waves_per_simd >= 1 && waves_per_simd <= 8, "mfma_f32_peak: bad arguments");
   const int nblk = fnssl::device_cus() * waves_per_simd;
   FNSSL_REQUIRE(out_floats >= (size_t)nblk * 256, "mfma_f32_peak: out needs %zu floats", (size_t)nblk * 256);
-  hipLaunchKernelGGL(mfma_f32_peak_kernel, dim3(nblk), dim3(256), 0, fnssl::as_stream(stream), out, iters);
+  FNSSL_REQUIRE(!clocks || clocks_len >= (size_t)nblk * 3, "mfma_f32_peak: clocks needs %zu entries", (size_t)nblk * 3);
+  hipLaunchKernelGGL(mfma_f32_peak_kernel, dim3(nblk), dim3(256), 0, fnssl::as_stream(stream), out, iters, clocks);
   FNSSL_CHECK_LAUNCH("mfma_f32_peak_kernel");
   *flop = (double)nblk * 4 * (double)iters * 64 * (2.0 * 16 * 16 * 4);
   return FNSSL_OK;
+}
+
+int fnssl_mfma_f32_peak(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop, void* stream) {
+  return fnssl_mfma_f32_peak_clocks(out, out_floats, iters, waves_per_simd, flop, nullptr, 0, stream);
 }
 
 int fnssl_abi_version(void) { return FNSSL_ABI_VERSION; }

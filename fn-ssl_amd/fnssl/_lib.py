@@ -31,7 +31,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libfnssl_hip.so")
 # `make ABLATE=1` build with the timing-ablation twins) — never a different implementation, never a fallback
 LIB_PATH = os.environ.get("FNSSL_LIB_PATH", LIB_PATH)
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 CH_MODE = {"M": 0, "MM": 1}
 # kernel families fnssl_lstm_plan reports (include/fnssl.h: FNSSL_LSTM_FAMILY_*)
 LSTM_FAMILY = {1: "generic", 2: "static", 3: "static2 (retired)", 4: "split", 5: "split_static", 6: "f32_cluster",
@@ -51,7 +51,7 @@ SYMBOLS = [
     "fnssl_lstm_reserve_bytes", "fnssl_lstm_bwd_packed_floats", "fnssl_lstm_pack_bwd", "fnssl_lstm_bwd_workspace_bytes",
     "fnssl_lstm_backward", "fnssl_lstm_backward_plan", "fnssl_lstm_backward_status", "fnssl_lstm_weight_grads_workspace_bytes", "fnssl_lstm_weight_grads", "fnssl_lstm_packed_floats_bf16", "fnssl_lstm_pack_bf16", "fnssl_train_combine", "fnssl_dropout_scale", "fnssl_head_backward_workspace_bytes",
     "fnssl_head_backward", "fnssl_mse_loss", "fnssl_adam_step",
-    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select", "fnssl_mfma_f32_peak",
+    "fnssl_forward_workspace_bytes", "fnssl_forward", "fnssl_timing_enable", "fnssl_timing_collect", "fnssl_timing_select", "fnssl_mfma_f32_peak", "fnssl_mfma_f32_peak_clocks",
     "fnssl_lstm_packed_floats_bf16w", "fnssl_lstm_pack_bf16w",
     "fnssl_train_create", "fnssl_train_destroy", "fnssl_train_param_floats", "fnssl_train_param_offset",
     "fnssl_train_map_bytes", "fnssl_train_upload_maps", "fnssl_train_workspace_bytes", "fnssl_train_backward",
@@ -235,6 +235,7 @@ def load():
     lib.fnssl_lstm_plan_rounds.argtypes = [i, i, i, i, vp, i]
     lib.fnssl_lstm_plan.argtypes = [C.POINTER(LstmDesc), vp, vp]
     lib.fnssl_mfma_f32_peak.argtypes = [vp, sz, i, i, vp, vp]
+    lib.fnssl_mfma_f32_peak_clocks.argtypes = [vp, sz, i, i, vp, vp, sz, vp]
     lib.fnssl_lstm_cluster_status.argtypes = [vp, sz, i, i, i, vp, vp]
     lib.fnssl_lstm_weight_grads_workspace_bytes.argtypes = [ll, i, i, i, i]
     lib.fnssl_lstm_weight_grads_workspace_bytes.restype = sz

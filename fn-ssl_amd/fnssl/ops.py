@@ -519,6 +519,52 @@ def mfma_f32_peak(iters: int = 20000, waves_per_simd: int = 2, reps: int = 3, de
     return best
 
 
+def mfma_f32_peak_sustained(seconds: float = 2.0, iters: int = 20000, waves_per_simd: int = 2, device=None) -> dict:
+    """The same ceiling held for ``seconds`` of back-to-back launches (fnssl_mfma_f32_peak_clocks): what the matrix pipe
+    delivers once the power / thermal management has settled, which is the regime the 85 – 115 ms LSTM kernels of a 10-s
+    timed region run in — a 35-ms burst does not show it.  Returns TFLOP/s of the whole window and of its last quarter,
+    and the clock (MHz, shader cycles per 100 MHz tick of wave 0 of every workgroup) per XCD during the LAST launch."""
+    lib = _lib.load()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ncu = torch.cuda.get_device_properties(device).multi_processor_count
+    nblk = ncu * waves_per_simd
+    out = torch.empty(nblk * 256, dtype=torch.float32, device=device)
+    clk = torch.zeros(nblk * 3, dtype=torch.int64, device=device)
+    flop = C.c_double(0.0)
+
+    def launch(with_clocks):
+        check(lib.fnssl_mfma_f32_peak_clocks(out.data_ptr(), out.numel(), iters, waves_per_simd, C.byref(flop),
+                                             clk.data_ptr() if with_clocks else None, clk.numel() if with_clocks else 0,
+                                             _stream()), "mfma_f32_peak_clocks")
+
+    launch(False)                                       # code-object load + one-launch duration
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch(False)
+    e1.record()
+    e1.synchronize()
+    one_ms = max(e0.elapsed_time(e1), 1e-3)
+    n = max(4, int(seconds * 1e3 / one_ms + 0.999))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record()
+    for k in range(n):
+        launch(k == n - 1)
+        ev[k + 1].record()
+    ev[n].synchronize()
+    total_ms = ev[0].elapsed_time(ev[n])
+    q = max(1, n // 4)
+    last_ms = ev[n - q].elapsed_time(ev[n])
+    c = clk.cpu().numpy().reshape(nblk, 3)
+    mhz = c[:, 0] / np.maximum(c[:, 1], 1) * 100.0
+    per_xcd = {}
+    for x in sorted(set(int(v) for v in c[:, 2])):
+        m = mhz[c[:, 2] == x]
+        per_xcd[x] = round(float(m.mean()), 1)
+    return {"tflops": flop.value * n / (total_ms * 1e-3) / 1e12, "tflops_last_quarter": flop.value * q / (last_ms * 1e-3) / 1e12,
+            "seconds": total_ms * 1e-3, "launches": n, "xcd_mhz": per_xcd,
+            "slowest_xcd_mhz": min(per_xcd.values()), "fastest_xcd_mhz": max(per_xcd.values())}
+
+
 def lstm_cluster_status(nseq: int, hidden: int, ndir: int, device=None) -> int:
     """Status word the cluster-resident LSTM kernels left in the current stream's LSTM workspace (0 = every hand-off
     arrived; otherwise the layer was recomputed by the guarded fallback kernels of the same call — see

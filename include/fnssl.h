@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FNSSL_ABI_VERSION 18
+#define FNSSL_ABI_VERSION 19
 
 #define FNSSL_OK 0
 #define FNSSL_E_INVALID (-1)     /* bad argument / unsupported shape          */
@@ -838,6 +838,14 @@ int fnssl_sn_forward(const fnssl_sn_net* net, const float* x, long long x_sb, lo
  * launch.  The caller times it with events on `stream`; bench.py reports flop / time as roofline.peak_measured next to
  * the datasheet peak.  out: >= CUs * waves_per_simd * 256 floats of scratch. */
 int fnssl_mfma_f32_peak(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop, void* stream);
+/* The same launch, additionally recording per workgroup b: clocks[3b] = shader cycles (s_memtime), clocks[3b + 1] = ticks of
+ * the constant 100 MHz counter (s_memrealtime), clocks[3b + 2] = the XCD it ran on (HW_REG_XCC_ID) — cycles / ticks x 100 MHz
+ * is the clock that XCD held under a saturated matrix pipe.  bench.py launches it back to back for >= 2 s and reports the
+ * rate of the whole window (roofline.peak_measured_sustained) with the slowest / fastest XCD clock of the last launch, so
+ * that a box timing 576 instead of 540 ms per step is attributable from the bench line alone.  clocks: device memory,
+ * >= CUs * waves_per_simd * 3 entries, or NULL (then exactly fnssl_mfma_f32_peak). */
+int fnssl_mfma_f32_peak_clocks(float* out, size_t out_floats, int iters, int waves_per_simd, double* flop,
+                               unsigned long long* clocks, size_t clocks_len, void* stream);
 
 /* enable = 1: every kernel launch is bracketed by hipEvents on its stream. */
 int fnssl_timing_enable(int enable);

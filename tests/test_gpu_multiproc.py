@@ -280,7 +280,10 @@ def test_bench_self_launches_n_ranks(tmp_path):
         assert res.returncode == 0, res.stderr[-2000:]
         lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
         assert len(lines) == 1, res.stdout[-500:]
+        assert len(lines[0]) < 4096, "the stdout line must stay compact (the driver keeps ~10 KB): %d bytes" % len(lines[0])
         line = json.loads(lines[0])
+        assert line["roofline"] is None or "frac" in line["roofline"]
+        assert os.path.exists(os.path.join(ROOT, line["detail"])), "the full record was not written"
         assert line["n_gpus"] == 2 and len(line["ms_per_step_per_rank"]) == 2 and line["backend"] == "gloo"
         assert line["value"] > 0 and line["scaling"] == "weak"
         # whole-job value = frames of BOTH ranks over the slowest rank's time

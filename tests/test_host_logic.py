@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.fnssl_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.fnssl_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_shape_helpers_match_reference_formulas():
@@ -321,6 +321,93 @@ def test_bench_gpus_n_refuses_to_run_with_fewer_devices():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=300)
     assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
+
+
+def _stub_bench_line(n_nested=7, prose=600):
+    """A full bench record shaped like run_workload()'s, with every prose field blown up to `prose` characters and a
+    40-kernel table per configuration: far larger than anything a real run produces."""
+    long = "x" * prose
+
+    def one(cfg):
+        return {"metric": "TF-frames/sec DP-IPD forward, 4-mic 257-bin x 300-frame " + long[:80], "value": 17766.12, "unit": "frames/s",
+                "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 540.312, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[%s]: %s" % (cfg, long), "utterances_per_gpu": 32, "global_batch": 32, "mics": 4,
+                           "pairs_per_utterance": 6, "frames": 300, "bins": 257, "parallelism": "dp1 " + long, "chunk_pairs": 0,
+                           "gflop_per_frame": 7.676, "stream_chunk_frames": 0},
+                "roofline": {"bound": "mfma", "kernel": "lstm_static3_kernel<H=256> " + long, "achieved": 137.01, "peak": 157.3,
+                             "unit": "TFLOP/s", "frac": 0.871, "traffic": 316911581653.3333, "traffic_source": long, "launches": 60,
+                             "avg_ms": 113.146, "flop_per_launch": 15502147584000.0, "peak_measured": 155.2,
+                             "frac_of_peak_measured": 0.8827, "peak_measured_how": long, "peak_measured_sustained": 151.3,
+                             "slowest_xcd_mhz": 2238.1, "fastest_xcd_mhz": 2381.9,
+                             "peak_sustained_detail": {"xcd_mhz": {str(i): 2300.0 + i for i in range(8)}}},
+                "cpu_baseline": {"value": 47.48, "unit": "frames/s", "cores": 16, "kind": "port", "sample": long},
+                "parity": {"max_abs_err": 3.725290298461914e-08, "rtol": 1e-4, "atol": 1e-5, "sample": long, "ok": True,
+                           "gradients": {"tensors": 38, "worst": long}},
+                "ms_per_step_median_hip_events": 540.3, "ms_per_step_per_rank": [540.312], "rccl_world_size": 1, "backend": None,
+                "cluster_fallbacks": 0, "peak_mem_gb": 84.8, "whole_path_tflops": 136.4,
+                "kernels": {"kernel_%02d" % i: {"ms_per_step": 1.234, "launches_per_step": 3.0, "tflops": 12.34} for i in range(40)},
+                "kernels_source": long,
+                "frontend": {"bound": "hbm", "kernel": long, "achieved": 1850.6, "peak": 8000.0, "unit": "GB/s", "frac": 0.2313,
+                             "traffic": None, "ms_per_step": 0.1487, "algorithmic_bytes_per_step": 275251200},
+                "ab": {"leg_%d_%s" % (i, long[:50]): {"A_ms_per_step": [1.0, 2.0], "B_ms_per_step": [1.0, 2.0], "env_B": {"K": "1"},
+                                                     "order": long, "gain_of_default_pct": 1.06} for i in range(3)}}
+
+    line = one(1)
+    line["other_configs"] = {k: one(k) for k in ["2M", "2off", "2b1", "2s", "3", "4", "5", "6", "7", "8"][:n_nested]}
+    if n_nested:
+        line["other_configs"]["4"]["error"] = None
+        line["other_configs"][list(line["other_configs"])[0]] = {"error": "RuntimeError('" + long + "')"}
+    return line
+
+
+def test_bench_stdout_line_is_compact_and_carries_the_contract(tmp_path):
+    """The driver keeps ~10 KB of bench.py's stdout: round 5's 26 KB line was cut mid-way and parsed as null.  compact_line()
+    must give < 4 KB that json-round-trips for ANY full record — here one with every prose field blown up and 7 (and 10)
+    nested configurations — and keep the contract keys, the roofline / cpu_baseline numbers and five numbers per nested
+    configuration; the full record goes to the detail file untouched.  Also on round 5's real 26 KB record."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("fnssl_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fulls = [_stub_bench_line(7), _stub_bench_line(10, prose=3000), _stub_bench_line(0)]
+    real = os.path.join(ROOT, "profiles", "r05", "o2_bench_default_steps20_last_build_slowest_box.json")
+    fulls.append(json.loads(open(real).read()))
+    assert len(json.dumps(fulls[-1])) > 20000
+    for full in fulls:
+        path = bench.write_detail(full, str(tmp_path / "sub" / "bench_detail.json"))
+        assert path and json.load(open(path)) == json.loads(json.dumps(full))
+        small = bench.compact_line(full, "gpurun_out/bench_detail.json")
+        text = json.dumps(small)
+        assert len(text) < 4096 and "\n" not in text, len(text)
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data"):
+            assert back[k] == full[k], k
+        assert back["config"]["workload"].startswith("BASELINE configs[")
+        r, fr = back["roofline"], full["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_ms", "flop_per_launch", "peak_measured"):
+            assert r[k] == fr[k], k
+        assert "traffic_source" not in r and "peak_measured_how" not in r
+        c = back["cpu_baseline"]
+        assert (c["value"], c["unit"], c["cores"], c["kind"]) == tuple(full["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind"))
+        assert isinstance(c["sample"], str) and c["sample"]
+        assert back["parity"]["ok"] is True and back["parity"]["max_abs_err"] == full["parity"]["max_abs_err"]
+        assert back["cluster_fallbacks"] == 0 and back["rccl_world_size"] == 1
+        assert "kernels" not in back and "ab" not in back
+        for key, o in (full.get("other_configs") or {}).items():
+            b = back["other_configs"][key]
+            if "error" in o and o.get("error"):
+                assert "error" in b
+                continue
+            assert b["value"] == o["value"] and b["ms_per_step"] == o["ms_per_step"]
+            if len(full["other_configs"]) <= 8:
+                assert b["roofline_frac"] == o["roofline"]["frac"] and b["cpu_baseline"] == o["cpu_baseline"]["value"]
+                assert b["parity_ok"] is True
+    # the peak_measured_sustained pair survives when present
+    small = bench.compact_line(fulls[0])
+    assert small["roofline"]["peak_measured_sustained"] == 151.3 and small["roofline"]["slowest_xcd_mhz"] == 2238.1
 
 
 def test_launch_planner_picks_the_cheapest_rounds():

@@ -93,12 +93,11 @@ class DPIPD(nn.Module):
 
 
 class SourceDetectLocalize(nn.Module):
-    """Iterative localisation and voice-activity detection ('IDL') on device."""
+    """Localisation and voice-activity detection on device: iterative ('IDL', Module.py:525-577) or by peak detection over
+    the spatial spectrum ('PD', Module.py:580-622)."""
 
     def __init__(self, max_num_sources, source_num_mode='kNum', meth_mode='IDL'):
         super(SourceDetectLocalize, self).__init__()
-        if meth_mode != 'IDL':
-            raise NotImplementedError("only the iterative 'IDL' method is part of the path")
         self.max_num_sources = max_num_sources
         self.source_num_mode = source_num_mode
         self.meth_mode = meth_mode
@@ -108,12 +107,39 @@ class SourceDetectLocalize(nn.Module):
         (DOAs [nb, nt, 2, ns], VADs [nb, nt, ns], spatial spectrum [nb, nt, nele, nazi])"""
         nb = pred_ipd.shape[0]
         nele, nazi = dpipd_template.shape[:2]
-        idx, vads, ss = fdoa.localize(pred_ipd.detach(), dpipd_template.to(pred_ipd.device), nb,
-                                      self.max_num_sources, self.source_num_mode)
         ele = torch.as_tensor(np.asarray(doa_candidate[0])).to(pred_ipd.device, torch.float32)
         azi = torch.as_tensor(np.asarray(doa_candidate[1])).to(pred_ipd.device, torch.float32)
+        if self.meth_mode == 'PD':
+            return self._peak_detection(pred_ipd, dpipd_template, ele, azi)
+        if self.meth_mode != 'IDL':
+            raise Exception('Localizion method is unrecognized')                 # Module.py:621
+        idx, vads, ss = fdoa.localize(pred_ipd.detach(), dpipd_template.to(pred_ipd.device), nb,
+                                      self.max_num_sources, self.source_num_mode)
         idx = idx.long()
         doas = torch.stack((ele[idx // nazi], azi[idx % nazi]), dim=2)       # [nb, nt, 2, ns]
+        return doas, vads, ss
+
+    def _peak_detection(self, pred_ipd, dpipd_template, ele, azi):
+        """'PD' as the reference RUNS it (measured on the real reference, tests/golden/make_golden_pd.py): the slice assignment
+        at Module.py:615 only goes through for max_num_sources = 2, and it lands as DOAs[b, t, SOURCE, (ele, azi)] — the
+        transpose of the 'IDL' layout; a frame with one peak gives both sources that peak; any other source count, or a
+        frame without a peak, raises RuntimeError there and here."""
+        ns = int(self.max_num_sources)
+        if ns != 2:
+            raise RuntimeError("SourceDetectLocalize('PD'): the reference's assignment pred_DOAs[b, t, :, :] = pred_DOA.transpose(1, 0) "
+                               "(Module.py:615) only accepts max_num_sources = 2, got %d" % ns)
+        nb = pred_ipd.shape[0]
+        nazi = dpipd_template.shape[1]
+        idx, val, cnt, ss = fdoa.localize_pd(pred_ipd.detach(), dpipd_template.to(pred_ipd.device), nb, ns, self.source_num_mode)
+        if int(cnt.min()) == 0:                                                  # (one 4-byte read-back: 'PD' is not a hot path)
+            raise RuntimeError("SourceDetectLocalize('PD'): a frame of the spatial spectrum has no peak (Module.py:615 raises)")
+        one = (cnt == 1).unsqueeze(-1)
+        idx = torch.where(one, idx[..., :1].expand_as(idx), idx).long()          # a single peak broadcasts to both sources
+        val = torch.where(one, val[..., :1].expand_as(val), val)
+        doas = torch.stack((ele[idx // nazi], azi[idx % nazi]), dim=3)           # [nb, nt, source, (ele, azi)]
+        vads = torch.ones_like(val) if self.source_num_mode == 'kNum' else val
+        if self.source_num_mode not in ('kNum', 'unkNum'):
+            vads = torch.zeros_like(val)                                         # neither branch of :616-619 writes
         return doas, vads, ss
 
 

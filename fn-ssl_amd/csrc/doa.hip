@@ -169,7 +169,7 @@ dpipd_targets_kernel(const float* __restrict__ doa, const float* __restrict__ va
   const double two_pi = 6.283185307179586476925286766559;
   for (int i = tid; i < nf_used * np; i += 256) {
     const int k = i / np, p = i - k * np;
-    const double f = (double)fre_max * (double)(bin0 + k) / (double)(nbins - 1);      // np.linspace(0, fre_max, nf)[bin0 + k]
+    const double f = (double)(bin0 + k) * ((double)fre_max / (double)(nbins - 1));    // np.linspace(0, fre_max, nf)[bin0 + k] = k * step
     float re = 0.f, im = 0.f;
     for (int src = 0; src < ns; ++src) {
       const double ph = two_pi * f * tau_s[src * np + p];                             // (-2 pi f ITD) * (-1), Module.py:489-490
@@ -198,5 +198,104 @@ extern "C" int fnssl_dpipd_targets(const float* doa, const float* vad, int nb, i
   hipLaunchKernelGGL(dpipd_targets_kernel, dim3(nb * nseg), dim3(256), 0, fnssl::as_stream(stream), doa, vad, nb, nseg, nvad, ns,
                      mic_loc, nmic, ch_mode, np, bin0, nf_used, nbins, fre_max, speed, use_vad, ipd, vad_mean);
   FNSSL_CHECK_LAUNCH("dpipd_targets_kernel");
+  return FNSSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Peak detection over the spatial spectrum (reference: SourceDetectLocalize.forward, meth_mode 'PD',
+// FN-SSL/Lightning/Module.py:580-611): the last azimuth column is dropped as redundant (:581); a cell is a peak when it is
+// strictly larger than its 8 neighbours — azimuth circular over the remaining columns, elevation clamped (:583-598; the clamp
+// compares the first and last elevation row with themselves, so they never hold a peak) —; per frame the peaks are sorted by
+// value, descending, equal values in ascending flat-index order (python's stable sorted(), :608-609) and the first nsrc kept.
+// One workgroup per frame: the spectrum (<= 12 K cells) in LDS, every thread marks its cells, then nsrc rounds of a
+// block-wide (value desc, index asc) argmax.  The reference does this in a Python double loop with a sort per frame.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256)
+doa_peaks_kernel(const float* __restrict__ ss, int nele, int nazi, int nsrc, int* __restrict__ idx, float* __restrict__ val,
+                 int* __restrict__ count) {
+  extern __shared__ float smem[];
+  float* g = smem;                          // [nele * nazi]
+  float* pk = smem + nele * nazi;           // [nele * nazi]: the cell's value if it is a peak, else -inf
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  __shared__ int npk_s;
+  const int ncell = nele * nazi, w = nazi - 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = ss + (size_t)blockIdx.x * ncell;
+  if (tid == 0) npk_s = 0;
+  for (int i = tid; i < ncell; i += 256) g[i] = src[i];
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < ncell; i += 256) {
+    const int e = i / nazi, a = i - e * nazi;
+    bool ok = a < w;
+    if (ok) {
+      const float v = g[i];
+      const int e0 = e > 0 ? e - 1 : 0, e1 = e < nele - 1 ? e + 1 : nele - 1;
+      const int a0 = a > 0 ? a - 1 : w - 1, a1 = a < w - 1 ? a + 1 : 0;
+      ok = v > g[e0 * nazi + a] && v > g[e1 * nazi + a] && v > g[e * nazi + a0] && v > g[e * nazi + a1] &&
+           v > g[e0 * nazi + a0] && v > g[e0 * nazi + a1] && v > g[e1 * nazi + a0] && v > g[e1 * nazi + a1];
+    }
+    pk[i] = ok ? g[i] : -INFINITY;
+    mine += ok ? 1 : 0;
+  }
+  if (mine) atomicAdd(&npk_s, mine);
+  __syncthreads();
+  const int npk = npk_s;
+  if (tid == 0) count[blockIdx.x] = npk < nsrc ? npk : nsrc;
+  for (int s = 0; s < nsrc; ++s) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (s < npk)
+      for (int i = tid; i < ncell; i += 256)
+        if (pk[i] > bv) {                  // ascending i per thread: the first of equal values stays
+          bv = pk[i];
+          bi = i;
+        }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ov = __shfl_xor(bv, d, 64);
+      const int oi = __shfl_xor(bi, d, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      wv[wave] = bv;
+      wi[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < 4; ++k)
+        if (wv[k] > bv || (wv[k] == bv && wi[k] < bi)) {
+          bv = wv[k];
+          bi = wi[k];
+        }
+      const bool have = s < npk;
+      idx[(size_t)blockIdx.x * nsrc + s] = have ? bi : -1;
+      val[(size_t)blockIdx.x * nsrc + s] = have ? bv : 0.f;
+      if (have) pk[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int fnssl_doa_peaks(const float* ss, int nframes, int nele, int nazi, int nsrc, int* idx, float* val, int* count,
+                               void* stream) {
+  FNSSL_REQUIRE(nframes >= 0 && nele >= 1 && nazi >= 2 && nsrc >= 1 && nsrc <= 8, "doa_peaks: %d frames, grid %d x %d, %d sources (1..8)",
+                nframes, nele, nazi, nsrc);
+  if (nframes == 0) return FNSSL_OK;
+  FNSSL_REQUIRE(ss && idx && val && count, "doa_peaks: null pointer");
+  const size_t lds = (size_t)nele * nazi * 2 * sizeof(float);
+  FNSSL_REQUIRE(lds <= 96 * 1024, "doa_peaks: a %d x %d grid does not fit the LDS budget", nele, nazi);
+  if (lds > 48 * 1024)
+    FNSSL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doa_peaks_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fnssl::TimedLaunch tl("doa_peaks", fnssl::as_stream(stream));
+  hipLaunchKernelGGL(doa_peaks_kernel, dim3(nframes), dim3(256), lds, fnssl::as_stream(stream), ss, nele, nazi, nsrc, idx, val, count);
+  FNSSL_CHECK_LAUNCH("doa_peaks_kernel");
   return FNSSL_OK;
 }

@@ -43,7 +43,7 @@ SYMBOLS = [
     "fnssl_num_frames_ex", "fnssl_stft_ex", "fnssl_array_frontend",
     "fnssl_forgetting_coefs", "fnssl_pair_features", "fnssl_nchw_to_seq", "fnssl_lstm_packed_floats",
     "fnssl_lstm_pack", "fnssl_lstm_workspace_bytes", "fnssl_lstm_workspace_bytes_ex", "fnssl_lstm_plan_rounds", "fnssl_lstm_plan", "fnssl_lstm_forward", "fnssl_lstm_cluster_status", "fnssl_head", "fnssl_linear",
-    "fnssl_ipd2doa", "fnssl_dpipd_targets", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
+    "fnssl_ipd2doa", "fnssl_doa_peaks", "fnssl_dpipd_targets", "fnssl_conv3x3_packed_floats", "fnssl_conv3x3_pack", "fnssl_conv3x3_causal",
     "fnssl_avgpool_time", "fnssl_array_features", "fnssl_conv3x3_packed_floats_bf16", "fnssl_conv3x3_pack_bf16",
     "fnssl_conv3x3_causal_bf16", "fnssl_conv3x3_causal_bf16a",
     "fnssl_conv3x3_packed_bytes_bf16x", "fnssl_conv3x3_pack_bf16x", "fnssl_conv3x3_causal_bf16x",
@@ -215,6 +215,7 @@ def load():
     lib.fnssl_head.argtypes = [vp, i, i, i, vp, vp, vp, vp]
     lib.fnssl_linear.argtypes = [vp, i, i, vp, vp, i, vp, vp]
     lib.fnssl_ipd2doa.argtypes = [vp, ll, ll, ll, ll, vp, i, i, i, i, i, i, i, vp, vp, vp, vp]
+    lib.fnssl_doa_peaks.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
     lib.fnssl_dpipd_targets.argtypes = [vp, vp, i, i, i, i, vp, i, i, i, i, i, f, f, i, vp, vp, vp]
     lib.fnssl_lstm_packed_floats_bf16.argtypes = [i, i, i]
     lib.fnssl_lstm_packed_floats_bf16.restype = sz

@@ -134,3 +134,23 @@ def localize(pred: torch.Tensor, bank: torch.Tensor, nb: int, max_num_sources: i
                                          1 if source_num_mode == "unkNum" else 0, _ptr(ss),
                                          C.c_void_p(idx.data_ptr()), _ptr(vad), _stream()), "ipd2doa")
     return idx, vad, ss
+
+
+@on_device
+def localize_pd(pred: torch.Tensor, bank: torch.Tensor, nb: int, max_num_sources: int = 2,
+                source_num_mode: str = "kNum"):
+    """Peak-detection localisation on device (SourceDetectLocalize, meth_mode 'PD', Module.py:580-622): the spatial
+    spectrum (fnssl_ipd2doa) and the ``max_num_sources`` largest local maxima of every frame (fnssl_doa_peaks).
+
+    Returns (idx int32 [nb, nt, ns] flat (ele, azi) cell or -1, val [nb, nt, ns] the peaks' spectrum values,
+    count int32 [nb, nt] = min(peaks, ns), ss [nb, nt, nele, nazi])."""
+    ns = int(max_num_sources)
+    _idx, _vad, ss = localize(pred, bank, nb, 1, "kNum")         # the spectrum of the first pass (the argmax is not used)
+    nele, nazi = bank.shape[:2]
+    nt = ss.shape[1]
+    idx = torch.empty((nb, nt, ns), dtype=torch.int32, device=pred.device)
+    val = torch.empty((nb, nt, ns), dtype=torch.float32, device=pred.device)
+    cnt = torch.empty((nb, nt), dtype=torch.int32, device=pred.device)
+    _lib.check(_lib.load().fnssl_doa_peaks(_ptr(ss), nb * nt, nele, nazi, ns, C.c_void_p(idx.data_ptr()), _ptr(val),
+                                           C.c_void_p(cnt.data_ptr()), _stream()), "doa_peaks")
+    return idx, val, cnt, ss

@@ -567,6 +567,19 @@ int fnssl_ipd2doa(const float* pred, long long sb, long long sp, long long st, l
                   int ncand, int nsrc, int unk_num, float* ss, int* idx, float* vad, void* stream);
 
 /*
+ * Replaces the peak search of SourceDetectLocalize.forward, meth_mode 'PD' (FN-SSL/Lightning/Module.py:580-611; the
+ * reference: eight shifted copies of the spectrum, then a Python double loop with a sort per frame).
+ *   ss     [nframes, nele, nazi]  spatial spectrum (fnssl_ipd2doa's `ss`)
+ *   a cell (e, a), a < nazi - 1 (the last azimuth column is redundant, :581), is a peak when strictly larger than its 8
+ *   neighbours: azimuth circular over nazi - 1 columns, elevation clamped (rows 0 and nele - 1 never hold a peak, :583-598)
+ *   idx    [nframes, nsrc]  flat cell index e * nazi + a of the nsrc largest peaks, descending by value, equal values in
+ *                           ascending index order (:608-609); -1 where a frame has fewer peaks
+ *   val    [nframes, nsrc]  their spectrum values (0 where idx = -1)
+ *   count  [nframes]        min(number of peaks, nsrc)
+ */
+int fnssl_doa_peaks(const float* ss, int nframes, int nele, int nazi, int nsrc, int* idx, float* val, int* count, void* stream);
+
+/*
  * IPDnet's all-channel features (replaces IPDnet/runIPDnetOn.py:240-254: abs, forgetting_norm over
  * all channels with sample_length 280, real/imag normalise, cat, DC-drop).
  *   spec, magsum  outputs of fnssl_stft;  coef_a/b  DEVICE [nt] from fnssl_forgetting_coefs

@@ -427,6 +427,59 @@ def source_detect_localize(pred_ipd: np.ndarray, bank: np.ndarray, cand, max_num
     return doas, vads, ss0
 
 
+def source_detect_localize_pd(pred_ipd: np.ndarray, bank: np.ndarray, cand, max_num_sources: int = 1,
+                              source_num_mode: str = "kNum"):
+    """SourceDetectLocalize.forward, meth_mode 'PD' (peak detection), Module.py:580-622.
+
+    The spatial spectrum of the first pass; the last azimuth column is dropped as redundant (:581); a cell is a peak when it
+    is strictly larger than its 8 neighbours, azimuth circular over the remaining columns, elevation CLAMPED (:583-598 — the
+    clamp compares rows 0 and nele - 1 with themselves, so they never hold a peak); per frame the peaks are sorted by value,
+    descending, ties in ascending flat-index order (python's stable `sorted`, :608-609), and the first max_num_sources kept.
+    What the reference's slice assignment `pred_DOAs[b, t, :, :] = pred_DOA.transpose(1, 0)` (:615) then does, measured on the
+    real reference (tests/golden/make_golden_pd.py): the picked indices are a LIST of one-element tensors, so pred_DOA is
+    [n, 1, 2] and its transpose [1, n, 2] — for max_num_sources = 2 that lands as doa[b, t, SOURCE, (ele, azi)], the
+    TRANSPOSE of the 'IDL' branch's [.., (ele, azi), source] layout (reproduced here as it is: a drop-in returns what the
+    reference returns); for any other number of sources the assignment raises, as does a frame without a peak; a frame with
+    exactly one peak broadcasts it to both sources.  Same here (ValueError where the reference raises RuntimeError).
+    -> (doa [nb, nt, 2 (source), 2 (ele, azi)], vad [nb, nt, 2], ss [nb, nt, nele, nazi])"""
+    pred = np.asarray(pred_ipd, dtype=F32)
+    nb, nt, nf2, npair = pred.shape
+    nele, nazi = bank.shape[:2]
+    flat = bank.reshape(nele * nazi, nf2 * npair).astype(F32)
+    ss = (pred.reshape(nb, nt, -1) @ flat.T / F32(npair * nf2 / 2)).astype(F32).reshape(nb, nt, nele, nazi)
+    ns = max_num_sources
+    if ns != 2:
+        raise ValueError("the reference's 'PD' branch only runs with max_num_sources = 2 (Module.py:615 raises otherwise)")
+    doas = np.zeros((nb, nt, 2, ns), dtype=F32)
+    vads = np.zeros((nb, nt, ns), dtype=F32)
+    w = nazi - 1
+    for b in range(nb):
+        for t in range(nt):
+            g = ss[b, t, :, :w]
+            found = []
+            for e in range(nele):
+                for a in range(w):
+                    v, ok = g[e, a], True
+                    for de in (-1, 0, 1):
+                        for da in (-1, 0, 1):
+                            if de == 0 and da == 0:
+                                continue
+                            if not v > g[min(max(e + de, 0), nele - 1), (a + da) % w]:
+                                ok = False
+                    if ok:
+                        found.append((e * nazi + a, v))
+            found.sort(key=lambda kv: -kv[1])                                   # stable: ties stay in index order
+            found = found[:ns]
+            if len(found) == 0:
+                raise ValueError("frame (%d, %d): no peak" % (b, t))
+            for s in range(ns):
+                k, v = found[s if len(found) > 1 else 0]
+                doas[b, t, s, 0] = cand[0][k // nazi]                            # [source, (ele, azi)]: see above
+                doas[b, t, s, 1] = cand[1][k % nazi]
+                vads[b, t, s] = 1 if source_num_mode == "kNum" else v
+    return doas, vads, ss
+
+
 def pred_to_doa(pred: np.ndarray, nb: int, mic_location, ch_mode: str = "MM", max_num_sources: int = 1,
                 source_num_mode: str = "kNum", speed: float = 340.0):
     """PredDOA.predgt2DOA (prediction half), Module.py:690-727: network output

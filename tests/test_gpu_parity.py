@@ -461,6 +461,50 @@ def test_doa_backend_golden(dev):
     assert_close(ss.cpu().numpy(), g["m4_ss"], 1e-5, 1e-6, "4-mic spatial spectrum")
 
 
+def test_doa_peak_detection_golden(dev):
+    """SourceDetectLocalize(meth_mode='PD') (fnssl_ipd2doa + fnssl_doa_peaks) against the REAL reference's outputs (G17) and
+    against the oracle on a frame with a single peak (broadcast) and with none (RuntimeError, like Module.py:615)."""
+    import Module as at_module
+    from fnssl import doa as fdoa
+    from oracle import fnssl_oracle as O
+    g = load_golden("g17_doa_pd")
+    mics = g["mics"]
+    for ci in range(int(g["ncases"][0])):
+        seed, nb, nt, nele, nazi, mm, ns, knum = [int(v) for v in g["c%d_cfg" % ci]]
+        gen = at_module.DPIPD([nele, nazi], mics, nf=257, fre_max=8000, ch_mode="MM" if mm else "M", speed=340)
+        t, _, cand = gen()
+        bank = np.concatenate((t.real[:, :, 1:257, :], t.imag[:, :, 1:257, :]), axis=2).astype(np.float32)
+        pred = np.tanh(rs_randn(seed, (nb, nt, 512, bank.shape[-1])))
+        mix = float(g["c%d_mix" % ci][0])
+        if mix:
+            pred = (pred * 0.3 + mix * bank[nele // 2 + 1, 4][None, None]).astype(np.float32)
+        sdl = at_module.SourceDetectLocalize(max_num_sources=ns, source_num_mode="kNum" if knum else "unkNum", meth_mode="PD")
+        doa, vad, ss = sdl(pred_ipd=to_dev(pred, dev), dpipd_template=to_dev(bank, dev), doa_candidate=cand)
+        assert_close(ss.cpu().numpy(), g["c%d_ss" % ci], 1e-5, 1e-6, "pd spectrum %d" % ci)
+        np.testing.assert_array_equal(doa.cpu().numpy(), g["c%d_doa" % ci])
+        assert_close(vad.cpu().numpy(), g["c%d_vad" % ci], 1e-4, 1e-6, "pd vad %d" % ci)
+    for ns in (1, 3):
+        with pytest.raises(RuntimeError):
+            at_module.SourceDetectLocalize(max_num_sources=ns, meth_mode="PD")(to_dev(pred, dev), to_dev(bank, dev), cand)
+    # the kernel alone on hand-made spectra: ties keep index order, a frame with one peak, a frame with none
+    ss = np.zeros((3, 5, 7), dtype=np.float32)
+    ss[0, 2, 1] = ss[0, 3, 4] = 2.0                       # two equal peaks: the lower flat index first
+    ss[0, 1, 6] = 9.0                                     # last azimuth column: never a peak (:581)
+    ss[0, 0, 3] = 9.0                                     # elevation row 0: never a peak (clamped neighbour = itself)
+    ss[1, 2, 0] = 1.0                                     # one peak; its circular neighbour is column 5, not 6
+    ss[1, 2, 6] = 5.0
+    idx = torch.empty((3, 2), dtype=torch.int32, device=dev)
+    val = torch.empty((3, 2), dtype=torch.float32, device=dev)
+    cnt = torch.empty((3,), dtype=torch.int32, device=dev)
+    import ctypes as C
+    lib = fdoa._lib.load()
+    fdoa._lib.check(lib.fnssl_doa_peaks(C.c_void_p(to_dev(ss, dev).data_ptr()), 3, 5, 7, 2, C.c_void_p(idx.data_ptr()),
+                                        C.c_void_p(val.data_ptr()), C.c_void_p(cnt.data_ptr()), None), "doa_peaks")
+    torch.cuda.synchronize(dev)
+    assert cnt.tolist() == [2, 1, 0]
+    assert idx.tolist() == [[2 * 7 + 1, 3 * 7 + 4], [2 * 7 + 0, -1], [-1, -1]] and val.tolist() == [[2.0, 2.0], [1.0, 0.0], [0.0, 0.0]]
+
+
 def test_data_preprocess_nor_flag_false_is_the_raw_real_imag_pairs(dev):
     """main.py:219-221: with nor_flag=False the features are the pairs' real / imaginary STFT parts as they are."""
     import predict_step as ps

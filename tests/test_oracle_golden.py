@@ -4,6 +4,7 @@ The golden .npz files were produced by tests/golden/make_golden.py, which import
 the reference's own Model.py / Module.py / utils_.py.  CPU only.
 """
 import numpy as np
+import pytest
 
 from conftest import assert_close, load_golden, rs_randn
 from fnssl import weights as W
@@ -169,6 +170,33 @@ def test_g12_doa_backend():
     np.testing.assert_array_equal(doa, g["m4_doa"])
     assert_close(vad, g["m4_vad"], 1e-4, 1e-6, "4-mic vad")
     assert_close(ss, g["m4_ss"], 1e-5, 1e-6, "4-mic ss")
+
+
+def test_g17_doa_peak_detection():
+    """'PD' branch of SourceDetectLocalize (Module.py:580-622) against the REAL reference's outputs (tests/golden/
+    make_golden_pd.py): DOAs exact — in the reference's [.., source, (ele, azi)] layout for two sources —, peak values and
+    spectrum within fp32 tolerance; one or three sources raise, as the reference does."""
+    g = load_golden("g17_doa_pd")
+    mics = g["mics"]
+    for ci in range(int(g["ncases"][0])):
+        seed, nb, nt, nele, nazi, mm, ns, knum = [int(v) for v in g["c%d_cfg" % ci]]
+        mode = "MM" if mm else "M"
+        t, cand = O.dpipd_templates(mics, nele, nazi, 257, 8000, mode, 340)
+        np.testing.assert_allclose(cand[0], g["c%d_cand_ele" % ci])
+        np.testing.assert_allclose(cand[1], g["c%d_cand_azi" % ci])
+        bank = np.concatenate((t.real[:, :, 1:257, :], t.imag[:, :, 1:257, :]), axis=2).astype(np.float32)
+        pred = np.tanh(rs_randn(seed, (nb, nt, 512, bank.shape[-1])))
+        mix = float(g["c%d_mix" % ci][0])
+        if mix:
+            pred = (pred * 0.3 + mix * bank[nele // 2 + 1, 4][None, None]).astype(np.float32)
+        doa, vad, ss = O.source_detect_localize_pd(pred, bank, cand, ns, "kNum" if knum else "unkNum")
+        assert_close(ss, g["c%d_ss" % ci], 1e-5, 1e-6, "pd ss %d" % ci)
+        np.testing.assert_array_equal(doa, g["c%d_doa" % ci])
+        assert_close(vad, g["c%d_vad" % ci], 1e-5, 1e-6, "pd vad %d" % ci)
+    assert list(g["raises_for_ns_1_3"]) == [1, 1]
+    for ns in (1, 3):
+        with pytest.raises(ValueError):
+            O.source_detect_localize_pd(pred, bank, cand, ns, "kNum")
 
 
 # --- IPDnet (fixed array) ------------------------------------------------------------------------------

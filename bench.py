@@ -367,6 +367,10 @@ class IpdnetForward:
                          "the one-stream instrumented pass")
         return r
 
+    def ab_knobs(self):
+        # round 6: full-band layers as 60 clusters x 20 tiles (3 + 2 parts per SIMD) against the full clusters of 24 (3 + 3)
+        return [] if self.fp32 else [("full_band_clusters_of_20_vs_24_tiles", {"FNSSL_CLUSTER_FULL_TILES": "1"})]
+
     def cpu_baseline(self):
         from oracle import torch_ref as R
         cores = usable_cores()
@@ -788,6 +792,8 @@ def compact_line(full, detail_path=None, limit=LINE_LIMIT):
             small[key] = {"value": o.get("value"), "ms_per_step": o.get("ms_per_step"), "dtype": o.get("dtype"),
                           "roofline_frac": r.get("frac"), "cpu_baseline": c.get("value"), "parity_ok": p.get("ok"),
                           "cluster_fallbacks": o.get("cluster_fallbacks"), "peak_mem_gb": o.get("peak_mem_gb")}
+            if isinstance(o.get("ab"), dict):
+                small[key]["ab_gain_pct"] = [v.get("gain_of_default_pct") for v in o["ab"].values()]
         line["other_configs"] = small
     if detail_path:
         line["detail"] = detail_path
@@ -1166,7 +1172,7 @@ def main():
         sub = argparse.Namespace(**vars(args))
         sub.nb, sub.frames, sub.nch, sub.ch_mode, sub.chunk_pairs = 0, 300, 4, "MM", 0
         sub.offline = sub.bf16 = sub.c_step = False
-        sub.ab_steps, sub.scaling, sub.stream_chunk, sub.sustained_seconds = 0, "weak", 0, 0.0
+        sub.ab_steps, sub.scaling, sub.stream_chunk, sub.sustained_seconds = (4 if key == "3" else 0), "weak", 0, 0.0
         nsteps = max(1, min(args.steps, args.other_steps))
         if variant:
             # "2b1" / "2s": the reference's real predict shape (Learner.py:219-272: ONE recording) — one 4-mic utterance as a

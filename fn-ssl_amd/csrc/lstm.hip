@@ -167,7 +167,9 @@ static size_t pair_stream_bytes(int hidden, int ndir) {
 static size_t cluster_bytes(int nseq, int hidden, int ndir, int precision) {
   if (hidden != 256 && hidden != 128) return 0;
   if (precision == FNSSL_PRECISION_BF16W) {
-    const size_t ncl = (size_t)ndir * ((nseq + cluster_seqs(hidden) - 1) / cluster_seqs(hidden));
+    // clusters of the call: full ones (8 NP tiles of 32 sequences) — or, H = 128, up to tiles / 17 smaller ones (forward_bf16c)
+    const size_t tiles = (size_t)(nseq + 31) / 32;
+    const size_t ncl = (size_t)ndir * std::max<size_t>((nseq + cluster_seqs(hidden) - 1) / cluster_seqs(hidden), hidden == 128 ? tiles / 17 : 0);
     return 256 + ncl * (kClusterTagWords * 4) + ncl * 2 * cluster_parity_bytes(hidden);
   }
   if (precision != FNSSL_PRECISION_FP32) return 256;

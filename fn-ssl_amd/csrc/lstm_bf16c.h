@@ -48,8 +48,13 @@ namespace fnssl_lstm {
 //   H = 128 (full-band):   4 members x 4 tiles, 3 parts  -> 768 sequences per cluster (config 3: 19200 sequences per
 //                          direction = exactly 25 clusters, 50 clusters x 4 CUs in ONE launch; with 2 parts it would be
 //                          76 clusters = 304 workgroups, i.e. two rounds)
-// "part" = one 32-sequence tile per wave; a wave cycles through its NP parts, so a part's h_t has NP - 1 part-times
+// "part" = one 32-sequence tile per wave; a wave cycles through its parts, so a part's h_t has (parts - 1) part-times
 // to reach the other members.
+// Round 6: the tiles per cluster are a launch parameter (ClusterParams::tpc <= 8 NP).  Tile t = 8 pt + w is part pt of wave w;
+// a wave runs the parts it has (at least two: with fewer than two live tiles the second is a phantom, as every tile past the
+// end of the batch always was), a wave without any leaves after the weight load.  Config 3's full-band layers (1200 tiles)
+// ran as 50 clusters x 24 tiles on 200 CUs = 3 + 3 parts per SIMD; the launcher now cuts them into 60 clusters x 20 tiles
+// (240 CUs): waves 0-3 three parts, waves 4-7 two = 5 per SIMD (forward_bf16c picks the split by that count).
 
 struct ClusterParams {
   char* hx;                 // [parity 2][cluster][part][sequence tile 8][block H/16][1 KiB]; parity 1 zeroed before the launch (h_{-1} = 0)
@@ -59,6 +64,7 @@ struct ClusterParams {
   int cl0;                  // first cluster of this launch (global index over directions)
   int ncl;                  // clusters in this launch
   int cl_per_dir;
+  int tpc;                  // 32-sequence tiles per cluster (<= 8 NP): cluster cd of a direction owns sequences [cd * 32 tpc, (cd + 1) * 32 tpc)
   int spread;               // test knob (FNSSL_CLUSTER_SPREAD=1): members of a cluster = CONSECUTIVE blocks, i.e. different XCDs
   unsigned spin_limit;      // spins (~1.5 us each) a wave waits for a tag before it gives up (cluster_spin_limit())
   int stall_member;         // test knob: this member of the call's first cluster exits at once (-1: none)
@@ -116,10 +122,14 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   unsigned vo0[3], vo2[3], voo[3];
   bool valid[3];
   long long off0[3], off2[3], offo[3];
+  int npresent = 0;               // parts of this wave that hold at least one live sequence (a prefix of 0 .. NP - 1)
 #pragma unroll
   for (int pt = 0; pt < 3; ++pt) {
-    int q = cd * (NP * 256) + (pt < NP ? pt : 0) * 256 + w * 32 + n;
-    valid[pt] = q < p.nseq;
+    const int tile = (pt < NP ? pt : 0) * 8 + w;
+    int q = cd * (cp.tpc * 32) + tile * 32 + n;
+    const bool present = pt < NP && tile < cp.tpc && cd * (cp.tpc * 32) + tile * 32 < p.nseq;   // wave-uniform
+    npresent += present ? 1 : 0;
+    valid[pt] = present && q < p.nseq;
     if (q >= p.nseq) q = p.nseq - 1;
     const long long qo = q / p.q_inner, qi = q - qo * p.q_inner;
     off0[pt] = qo * p.src0.so + qi * p.src0.si + 8 * hb;
@@ -136,6 +146,9 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   auto RX2 = [&](int pt) { return pt == 0 ? rx2_0 : pt == 1 ? rx2_1 : rx2_2; };
   auto RO = [&](int pt) { return pt == 0 ? ro_0 : pt == 1 ? ro_1 : ro_2; };
   const unsigned st0 = (unsigned)(p.src0.st * 2), st2 = (unsigned)(p.src2.st * 4), sto = (unsigned)(p.out_st * 2);
+  // a wave without a live tile has nothing to publish and nobody waits for it (presence depends on (cluster, part, wave) only,
+  // the same in every member); no workgroup barrier follows the weight load
+  if (__builtin_amdgcn_readfirstlane(npresent) == 0) return;
   const rsrc_t rhx = make_rsrc(cp.hx + (size_t)cg * cluster_parity_bytes(H));
   const unsigned vlane = lane * 16;
   unsigned* const tag_base = cp.tags + (size_t)cg * kClusterTagWords;
@@ -223,12 +236,12 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt unconstrained
 
   // one part (32 sequences per wave) at step `step`
-  auto part_step = [&](auto ptc, int step) {
-    constexpr int PT = decltype(ptc)::value;
-    constexpr int PN = (PT + 1) % NP, PP = (PT + NP - 1) % NP;        // the part after / before this one
+  auto part_step = [&](auto ptc, auto npwc, int step) {
+    constexpr int PT = decltype(ptc)::value, NPW = decltype(npwc)::value;   // NPW: parts this wave cycles through
+    constexpr int PN = (PT + 1) % NPW, PP = (PT + NPW - 1) % NPW;     // the part after / before this one
     const unsigned tt = rev ? p.nsteps - 1 - step : step;
     // the part after this one: same step, or the next step's part 0
-    const int nstep = PT + 1 < NP ? step : (step + 1 < p.nsteps ? step + 1 : step);
+    const int nstep = PT + 1 < NPW ? step : (step + 1 < p.nsteps ? step + 1 : step);
     const unsigned ttn = rev ? p.nsteps - 1 - nstep : nstep;
     // h_{step - 1} was published under parity (step - 1) & 1; step 0 reads the parity-1 records the host zeroed
     const int par = (step + 1) & 1;
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
       load_tags(PN);
     } else {
       // the NEXT part's recurrent operands and fp32 block: requested now, they land under this part's gate math
-      if (PT + 1 < NP || step + 1 < p.nsteps) {
+      if (PT + 1 < NPW || step + 1 < p.nsteps) {
         if constexpr (!(ABL & 1)) {
           if (nstep > 0) wait_tags(PN, (unsigned)nstep);
         }
@@ -359,8 +372,19 @@ __global__ void __launch_bounds__(512) lstm_bf16c_kernel(const LstmParams p, con
     }
   };
 
-  for (int step = 0; step < p.nsteps && !dead; ++step) static_for<NP>([&](auto pt) { part_step(pt, step); });
-  if (!dead) pub_flush(NP - 1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
+  auto run = [&](auto npwc) {
+    constexpr int NPW = decltype(npwc)::value;
+    for (int step = 0; step < p.nsteps && !dead; ++step) static_for<NPW>([&](auto pt) { part_step(pt, npwc, step); });
+    if (!dead) pub_flush(NPW - 1);   // (nobody waits for the last step's tags; kept so that a finished launch leaves uniform tags)
+  };
+  if constexpr (NP == 3) {
+    if (__builtin_amdgcn_readfirstlane(npresent) == 3)
+      run(ic<3>{});
+    else
+      run(ic<2>{});   // two live tiles — or one and a phantom (stores and publishes nothing that anybody reads)
+  } else {
+    run(ic<NP>{});
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

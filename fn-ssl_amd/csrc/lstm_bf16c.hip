@@ -1,4 +1,5 @@
 // Cluster-resident bf16 LSTM kernel (lstm_bf16c.h): instantiation for IPDnet's narrow-band layer shape and its launcher.
+#include <algorithm>
 #include <cstdlib>
 
 #include "lstm_bf16c.h"
@@ -59,7 +60,26 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   const int ncu = fnssl::device_cus();
   const int per_launch = ncu / cluster_members(H);
   FNSSL_REQUIRE(per_launch >= 1, "lstm_forward: the cluster kernel needs at least %d CUs", cluster_members(H));
-  const int cl_per_dir = (p.nseq + cluster_seqs(H) - 1) / cluster_seqs(H);
+  // How many clusters per direction.  A cluster holds at most 8 NP tiles of 32 sequences; tile 8 pt + w is part pt of wave w, and
+  // waves w and w + 4 share a SIMD, so a step costs a SIMD parts(0) + parts(4) part-times (parts(w) = ceil((tpc - w) / 8), a
+  // running wave cycles through at least two).  With three parts per wave (H = 128) the fullest clusters cost 3 + 3; cutting the
+  // batch into MORE clusters of 17 - 20 tiles costs 3 + 2 while they still fit one launch (config 3's full-band layers: 1200
+  // tiles, 50 clusters x 24 on 200 CUs -> 60 x 20 on 240).  The smallest count with the lowest cost is taken; 16 tiles or fewer
+  // per cluster (2 + 2) would need a third more CUs than the batch's 17 tiles per cluster bound allows the workspace (lstm.hip).
+  const int tiles = (p.nseq + 31) / 32, np = cluster_parts(H);
+  int cl_per_dir = (tiles + 8 * np - 1) / (8 * np);
+  auto cost = [&](int cl) {
+    const int tpc = (tiles + cl - 1) / cl;
+    auto parts = [&](int w) { const int n = tpc > w ? (tpc - w + 7) / 8 : 0; return n == 0 ? 0 : n < 2 ? 2 : n; };
+    return parts(0) + parts(4);
+  };
+  if (np == 3 && !fnssl::tune(FNSSL_TUNE_CLUSTER_FULL_TILES)) {
+    const int most = std::min(per_launch / p.ndir, tiles / 17);     // one launch, and >= 17 tiles per cluster
+    int best = cl_per_dir;
+    for (int cl = cl_per_dir + 1; cl <= most; ++cl)
+      if (cost(cl) < cost(best)) best = cl;
+    cl_per_dir = best;
+  }
   const int ncl = cl_per_dir * p.ndir;
   const size_t head = 256 + (size_t)ncl * (kClusterTagWords * 4);
   ClusterParams cp;
@@ -69,6 +89,7 @@ int forward_bf16c(LstmParams p, int H, int flags, hipStream_t st) {
   FNSSL_REQUIRE((size_t)ncl * 2 * cluster_parity_bytes(H) < 0xf0000000ull, "lstm_forward: too many sequences for one call of the cluster kernel");
   cp.parity_stride = (unsigned)((size_t)ncl * cluster_parity_bytes(H));
   cp.cl_per_dir = cl_per_dir;
+  cp.tpc = (tiles + cl_per_dir - 1) / cl_per_dir;
   // placement is a speed matter only; the knob puts the members of a cluster on DIFFERENT XCDs so that tests can show it
   cp.spread = fnssl::tune(FNSSL_TUNE_CLUSTER_SPREAD) ? 1 : 0;
   cp.spin_limit = cluster_spin_limit();

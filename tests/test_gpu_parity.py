@@ -1308,6 +1308,66 @@ def test_lstm_bf16_cluster_kernel_matches_oracle_and_pair_split(dev, monkeypatch
     assert torch.equal(a, a2), "cluster kernel is not repeatable"
 
 
+@pytest.mark.parametrize("c0,c2,nb,nt,nf", [
+    (256, 16, 64, 300, 24),      # config 3's full-band batch (blocks 2-3): 1200 tiles -> 30 clusters x 20 tiles per direction (3 + 2 parts per SIMD)
+    (16, 0, 64, 300, 24),        # block 1's layer (the fp32 feature block only: the recurrent operands are the whole window)
+    (256, 16, 37, 300, 9),       # 11100 sequences = 347 tiles (the last one 28 sequences) -> 18 clusters x 20 per direction; the last
+                                 # cluster holds 7 tiles: waves 0-6 one live part + a phantom, wave 7 leaves after the weight load
+    (256, 16, 30, 300, 7),       # 9000 sequences = 282 tiles -> 15 clusters x 19 per direction (waves 0-2 three parts, 3-7 two)
+])
+def test_lstm_bf16_full_band_cluster_split_equals_full_clusters_and_pair_split(dev, monkeypatch, c0, c2, nb, nt, nf):
+    """Round 6: the bf16 cluster kernel's tiles per cluster are a launch parameter and forward_bf16c cuts the H = 128 full-band
+    layers into MORE clusters of 17 - 20 tiles (waves with three and with two parts, waves with none leave) instead of full
+    clusters of 24.  Bit-for-bit against the full clusters (FNSSL_CLUSTER_FULL_TILES=1) and against the pair-split kernels
+    (FNSSL_NO_CLUSTER_H128=1, what both replace), twice, no bounded wait ran out; a few sequences against the bf16 oracle."""
+    from fnssl import ops
+    from oracle import fnssl_oracle as O
+    H, ndir = 128, 2
+    sd = lstm_state(c0 + c2, H, True, 7100 + c0)
+    sfx = ["", "_reverse"]
+    w = [ops.pack_lstm_bf16w(sd["L.weight_ih_l0" + s_], sd["L.weight_hh_l0" + s_], sd["L.bias_ih_l0" + s_], sd["L.bias_hh_l0" + s_],
+                             c0, c2, dev) for s_ in sfx]
+    g = torch.Generator(device="cpu").manual_seed(7101 + nb)
+    x = (torch.randn((nb, nt, nf, c0 + c2), generator=g) * 0.7).bfloat16().float()          # bf16-representable
+    xd = x.to(dev)
+    x0 = xd[..., :c0].contiguous()
+    x0 = x0.bfloat16() if c2 else x0                                                       # block 1: the fp32 feature channels
+    x2 = xd[..., c0:].contiguous() if c2 else None
+
+    def run():
+        out = torch.full((nb, nt, nf, ndir * H), float("nan"), device=dev, dtype=torch.bfloat16)
+        ops.lstm_layer("full", x0, None, x2, w, H, out, bf16=True, wide=True)
+        return out
+
+    def plan():
+        return ops.lstm_plan("full", x0, None, x2, w, H, torch.empty((nb, nt, nf, ndir * H), device=dev, dtype=torch.bfloat16),
+                             bf16=True, wide=True)[0]
+
+    for k in ("FNSSL_NO_CLUSTER", "FNSSL_NO_CLUSTER_H128", "FNSSL_NO_CLUSTER_B1", "FNSSL_CLUSTER_FULL_TILES", "FNSSL_CLUSTER_SPREAD"):
+        monkeypatch.delenv(k, raising=False)
+    assert plan() == "bf16_cluster", plan()
+    a, a2 = run(), run()
+    with torch.cuda.device(dev):
+        assert ops.lstm_cluster_status(nb * nt, H, ndir, dev) == 0
+    assert not torch.isnan(a.float()).any()
+    assert torch.equal(a, a2), "not repeatable"
+    monkeypatch.setenv("FNSSL_CLUSTER_FULL_TILES", "1")
+    assert plan() == "bf16_cluster"
+    b = run()
+    assert torch.equal(a, b), "clusters of 17 - 20 tiles differ from full clusters"
+    monkeypatch.delenv("FNSSL_CLUSTER_FULL_TILES")
+    monkeypatch.setenv("FNSSL_NO_CLUSTER_H128", "1")
+    monkeypatch.setenv("FNSSL_NO_CLUSTER_B1", "1")
+    assert plan() == "bf16_pair", plan()
+    c = run()
+    assert torch.equal(a, c), "cluster kernel differs from the pair-split kernels"
+    rows = [(0, 0), (nb // 2, nt // 2), (nb - 1, nt - 1)]
+    seq = np.stack([x[b_, t_].numpy() for b_, t_ in rows])
+    want = O.lstm(seq, sd, "L.", True, bf16=True)
+    got = np.stack([a[b_, t_].float().cpu().numpy() for b_, t_ in rows])
+    assert np.abs(got - want).max() <= BF_ATOL + 2e-3, np.abs(got - want).max()
+
+
 @pytest.mark.parametrize("mode,H,bidir,c0,c2,nb,nt,nf", [
     ("narrow", 256, False, 256, 16, 64, 60, 256),  # config 3's narrow-band batch: 16384 sequences x 60 steps
     ("full", 128, True, 256, 16, 64, 300, 48),     # config 3's full-band batch (blocks 2, 3): 19200 sequences x 2 directions x 48 steps

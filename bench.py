@@ -1057,10 +1057,13 @@ def run_workload(args, cfg, dev, rank, world, dist, backend, steps, warmup):
             line["ab"] = ab
         if strong:
             line["strong_scaling"] = strong
-    # give the memory back before the next configuration (config 2 plans 90 GB, config 4 132 GB)
+    # give the memory back before the next configuration (config 2 plans 90 GB, config 4 132 GB) — including the library-side
+    # workspaces the ops cache per stream (round 5's nested lines carried config 2's 84 GB plan in their `peak_mem_gb`:
+    # config 4 read 214 GB where the step itself peaks at 130)
     del wl, out
     import gc
     gc.collect()
+    ops.release_workspaces()
     torch.cuda.empty_cache()
     return line, failed
 

@@ -56,10 +56,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_TF_POINT = {True: 4997120, False: 4210688}   # LSTM matmuls only, by is_online
-TRAFFIC_JSON = os.path.join("profiles", "r05", "hbm_traffic.json")     # per roofline kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+TRAFFIC_JSON = os.path.join("profiles", "r06", "hbm_traffic.json")     # per roofline kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 TRAFFIC_JSON_R03 = os.path.join("profiles", "r03", "hbm_traffic_lstm_h256.json")
 # same-process A/B legs of the default run: (label, environment of the B leg).  A = the shipped default.
 AB_KNOBS = [
+    # round 6: four hidden slices per pass with an LDS-DMA weight ring (lstm_static4.h) against the two-slice operand-ring kernel
+    ("four_slices_per_pass_vs_two", {"FNSSL_NO_STATIC4": "1"}),
     # round 4: operand-ring narrow-band kernel (lstm_static3.h) against the one-slice rounds it replaced (round 3's two-slice
     # kernel was removed in round 5); issue priorities by phase and leftover-group rotation in the cluster-resident full-band
     # kernel (lstm_f32c.h)
@@ -91,7 +93,7 @@ def sq_counters_of(kernel):
 def traffic_of(key):
     """(bytes per launch, source) of a roofline kernel from the committed PMC summaries, or (None, None): counter
     passes cannot run inside the timed region (gpurun refuses --pmc next to traces, and they perturb the clock)."""
-    for rel in (TRAFFIC_JSON, os.path.join("profiles", "r04", "hbm_traffic.json")):
+    for rel in (TRAFFIC_JSON, os.path.join("profiles", "r05", "hbm_traffic.json"), os.path.join("profiles", "r04", "hbm_traffic.json")):
         path = os.path.join(ROOT, rel)
         if os.path.exists(path):
             with open(path) as f:
@@ -260,8 +262,11 @@ class FnsslForward:
             return kernel_roof(kern, "lstm_h256", "lstm_bf16_kernel<H=256> (narrow-band LSTM, bf16 MFMA operands)",
                                PEAK_BF16_MFMA_TFLOPS)
         traffic, src = traffic_of("c2_lstm_h256")
-        return kernel_roof(kern, "lstm_h256", "lstm_static3_kernel<H=256> (narrow-band LSTM, two hidden slices per pass, x_t and h_{t-1} streamed)",
-                           PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
+        if os.environ.get("FNSSL_NO_STATIC4"):
+            return kernel_roof(kern, "lstm_h256", "lstm_static3_kernel<H=256> (narrow-band LSTM, two hidden slices per pass, x_t and h_{t-1} streamed)",
+                               PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
+        return kernel_roof(kern, "lstm_h256", "lstm_static4_kernel<H=256> (narrow-band LSTM, four hidden slices per pass, x_t and h_{t-1} "
+                           "streamed, LDS-DMA weight ring)", PEAK_FP32_MFMA_TFLOPS, traffic=traffic, traffic_source=src)
 
     def ab_knobs(self):
         return AB_KNOBS if (self.online and not self.args.bf16) else []

@@ -221,6 +221,21 @@ __global__ void __launch_bounds__(256) pair_stream_kernel(const float4* __restri
   out[i] = in[src];
 }
 
+// standard stream [slice][quad][4 records] -> quad-interleaved [slice quad][quad][slice in quad][4 records] (lstm_static4.h)
+__global__ void __launch_bounds__(256) quad_stream_kernel(const float4* __restrict__ in, int qps, long long n4,
+                                                          float4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int l = (int)(i & 63);                      // float4 inside the 1-KiB record
+  const long long rec = i >> 6;                      // output record index = ((p * qps + q) * 4 + j) * 4 + r
+  const int r = (int)(rec & 3), j = (int)((rec >> 2) & 3);
+  const long long pq = rec >> 4;
+  const int q = (int)(pq % qps);
+  const long long pp = pq / qps;
+  const long long src = (((4 * pp + j) * qps + q) * 4 + r) * 64 + l;
+  out[i] = in[src];
+}
+
 // guarded fallback of a streaming (carry) call, first step: put back the cell state the aborted cluster kernel has advanced.
 // Returns at once unless the cluster kernel left a non-zero status word.
 __global__ void __launch_bounds__(256) restore_cell_kernel(const unsigned* __restrict__ guard, const float4* __restrict__ backup,
@@ -448,15 +463,23 @@ static int lstm_forward_impl(const fnssl_lstm_desc* d, void* stream, bool dry, i
           LstmParams p2 = p;
           const long long n4 = (long long)(H / 16) * p.quads_per_slice * 4 * 64;      // float4 per direction
           char* dst = reinterpret_cast<char*>(d->workspace) + cell_scratch_bytes(d->nseq, H, d->ndir);
+          // round 6: four slices per pass on a QUAD-interleaved copy (lstm_static4.h: half the operand re-reads, the weight ring
+          // staged by LDS-DMA); NO_STATIC4 keeps the two-slice kernel: A/B, same bits
+          const bool s4 = !fnssl::tune(FNSSL_TUNE_NO_STATIC4);
           for (int di = 0; di < d->ndir; ++di) {
             float4* o = reinterpret_cast<float4*>(dst + (size_t)di * n4 * 16);
-            if (!dry)
-              hipLaunchKernelGGL(pair_stream_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
-                               reinterpret_cast<const float4*>(p.wpack[di]), p.quads_per_slice, n4, o);
+            if (!dry) {
+              if (s4)
+                hipLaunchKernelGGL(quad_stream_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                                   reinterpret_cast<const float4*>(p.wpack[di]), p.quads_per_slice, n4, o);
+              else
+                hipLaunchKernelGGL(pair_stream_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                                   reinterpret_cast<const float4*>(p.wpack[di]), p.quads_per_slice, n4, o);
+            }
             p2.wpack[di] = reinterpret_cast<const float*>(o);
           }
           FNSSL_CHECK_LAUNCH("pair_stream_kernel");
-          rc = launch_static3_h256(p2, mode, nwg, st);
+          rc = s4 ? launch_static4_h256(p2, mode, nwg, st) : launch_static3_h256(p2, mode, nwg, st);
           if (rc != kNoStatic) {
             report(FNSSL_LSTM_FAMILY_STATIC3);
             return rc;

@@ -317,6 +317,7 @@ inline int cluster_test_stall() { return fnssl::tune(FNSSL_TUNE_CLUSTER_TEST_STA
 int launch_static_h128(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static_h256(const LstmParams& p, int mode, int NW, int nwg, hipStream_t st);
 int launch_static3_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static3.h, pair-interleaved stream
+int launch_static4_h256(const LstmParams& p, int mode, int nwg, hipStream_t st);   // lstm_static4.h, quad-interleaved stream
 int launch_static_ipdnet(const LstmParams& p, int mode, int H, int NW, int nwg, hipStream_t st);
 
 }  // namespace fnssl_lstm

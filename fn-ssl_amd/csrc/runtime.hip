@@ -80,10 +80,11 @@ const char* const kTuneNames[] = {
     "NO_F32_SMALL",
     "F32C_MIN_GROUPS",
     "F32C_GATE_SPLIT",
-    "CLUSTER_FULL_TILES"};
+    "CLUSTER_FULL_TILES",
+    "NO_STATIC4"};
 constexpr int kTuneNamed = (int)(sizeof(kTuneNames) / sizeof(kTuneNames[0]));
 static_assert(kTuneNamed <= FNSSL_TUNE_COUNT, "more knob names than slots");
-static_assert(kTuneNamed == FNSSL_TUNE_CLUSTER_FULL_TILES + 1, "knob names out of step with include/fnssl.h");
+static_assert(kTuneNamed == FNSSL_TUNE_NO_STATIC4 + 1, "knob names out of step with include/fnssl.h");
 }  // namespace
 
 const fnssl_tuning& tuning() {

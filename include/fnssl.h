@@ -96,6 +96,7 @@ const char* fnssl_last_error(void);
 #define FNSSL_TUNE_F32C_MIN_GROUPS 38        /* smallest (groups x directions) count the fp32 cluster kernels take for inference (default: see lstm_f32c.hip) */
 #define FNSSL_TUNE_F32C_GATE_SPLIT 39        /* fp32 cluster kernels: 1 = every wave owns a group, 4 = the four waves of a slot share one (one gate each); default: by groups per cluster */
 #define FNSSL_TUNE_CLUSTER_FULL_TILES 40    /* bf16 cluster kernels, H = 128: full clusters of 24 tiles (rounds 3 - 5) instead of more clusters of 17 - 20 */
+#define FNSSL_TUNE_NO_STATIC4 41             /* H = 256 narrow-band layers at full-chip size: two hidden slices per pass (lstm_static3.h) instead of four (lstm_static4.h) */
 #define FNSSL_TUNE_COUNT 48               /* room for more without changing the struct */
 
 typedef struct fnssl_tuning {

@@ -1663,11 +1663,19 @@ def test_lstm_operand_ring_kernel_equals_one_slice_kernel(dev, monkeypatch, c2, 
         r = ops.lstm_layer("narrow", x0, None, x2, w, H, out, skip=skip, out_sum=osum, plan_only=plan)
         return r if plan else (out, osum)
 
-    for k in ("FNSSL_NO_STATIC3", "FNSSL_NO_STATIC2"):
+    for k in ("FNSSL_NO_STATIC3", "FNSSL_NO_STATIC2", "FNSSL_NO_STATIC4"):
         monkeypatch.delenv(k, raising=False)
     assert run(plan=True) == ("static3", 1), run(plan=True)
-    a, asum = run()
+    a, asum = run()                                      # round 6: four slices per pass, LDS-DMA weight ring (lstm_static4.h)
     a6, a6sum = run()                                    # (and again: repeatable)
+    for _ in range(3):                                   # the DMA ring's counted waits: a race would show between launches
+        r_, rs_ = run()
+        assert torch.equal(r_, a) and (not summed or torch.equal(rs_, asum)), "four-slice kernel is not repeatable"
+    monkeypatch.setenv("FNSSL_NO_STATIC4", "1")          # two slices per pass (lstm_static3.h), same family name
+    assert run(plan=True) == ("static3", 1)
+    p2, p2sum = run()
+    assert torch.equal(a, p2) and (not summed or torch.equal(asum, p2sum)), "four slices per pass differ from two"
+    monkeypatch.delenv("FNSSL_NO_STATIC4")
     monkeypatch.setenv("FNSSL_NO_STATIC3", "1")
     assert run(plan=True)[0] == "static"
     b, bsum = run()

@@ -17,7 +17,13 @@ Dropout (Model.py:40,48): nn.Dropout's Bernoulli stream cannot be reproduced out
 library's hash of (seed, call, layer, GLOBAL element index) — ``module.dropout_seed`` (default ``torch.initial_seed()``)
 and ``module.dropout_calls`` (incremented per train-mode forward) form the base seed with the engine's formula,
 ``module.pair_offset`` (default rank * pairs under an initialised process group) keys the element index so that N ranks
-draw the masks of one rank on the concatenated batch.
+draw the masks of one rank on the concatenated batch.  REQUIREMENT under a process group (not checked: it would cost a
+collective per forward): every rank passes the SAME number of pairs per call and the same ``dropout_seed`` — the default seed is
+``torch.initial_seed()``, which differs per rank unless the ranks were seeded identically (Lightning's ``seed_everything`` /
+``torch.manual_seed(s)`` on every rank).  With uneven last batches, or a module that is not data-parallel although a group
+is initialised, set ``module.pair_offset`` (and ``module.dropout_seed``) explicitly; masks of different ranks otherwise overlap
+or differ from the one-process batch.  ``_lib.tuning(...)`` around a train-mode forward is PROCESS-wide (``fnssl_tuning_set``) and
+does not cover the backward, which autograd runs later: pass knobs for the backward through ``TrainGraph(bwd_tuning=...)``.
 
 The gradient w.r.t. the input FEATURES (``in_batch.requires_grad_()``, Learner.py:102 — set, never read by the
 reference) is not produced: block 1's layers have no input-gradient path in the BPTT kernels (c0g = 0).  ``backward``
@@ -96,6 +102,11 @@ class FNSSLTrainFunction(torch.autograd.Function):
             fw, bw = train.pack_streams(plan.layers, plan.maps, theta)
             graph = train.TrainGraph(plan.layers, _fresh)
             pred, saved = graph.forward(x.detach().contiguous(), fw, seeds, b0, lambda n: plan.view(theta, n))
+            # head_backward needs tanh's output: keep an ALIAS (same storage, another tensor object), not the returned tensor
+            # itself — the output object on ctx would close the cycle output -> grad_fn -> ctx -> output and keep ~100 GB of
+            # activations alive until the cyclic collector runs whenever backward is never called (round-5 advisor note).
+            # The caller must not modify `pred` in place before backward (no version counter watches the alias).
+            saved["pred"] = pred.detach()
         ctx.plan, ctx.graph, ctx.saved, ctx.bw, ctx.theta = plan, graph, saved, bw, theta
         ctx.seeds, ctx.b0 = seeds, b0
         ctx.set_materialize_grads(False)

@@ -385,7 +385,12 @@ def make_tuning(base: Tuning = None, **knobs) -> Tuning:
 
 class tuning:
     """``with _lib.tuning(no_static3=1, cluster_spin_limit=20000): ...`` — the calls inside the block use
-    these knobs on top of the current ones; the previous tuning is restored on exit."""
+    these knobs on top of the current ones; the previous tuning is restored on exit.
+
+    PROCESS-WIDE and not thread-safe: it swaps the library's default tuning (``fnssl_tuning_set``), so calls issued by other
+    threads / on other streams during the block see the knobs too, and a backward that autograd runs AFTER the block (on its
+    worker thread) does not.  For per-call knobs pass a ``Tuning`` (``make_tuning(...)``) through the op's ``tuning=`` argument
+    (``ops.lstm_layer``, ``ops.lstm_backward``) or ``TrainGraph(bwd_tuning=...)``: that travels in the descriptor of the call."""
 
     def __init__(self, **knobs):
         self.knobs = knobs
